@@ -1,0 +1,180 @@
+/*
+ * dl3.h — C ABI of libdl3.so: the MI355X (gfx950) native operator set behind
+ * Deeplabv3() (reference: deeplabv3p.py:209-466, subpixel.py:41-103, utils.py:127-130,169-214).
+ *
+ * The reference has no FFI of its own: every FLOP of its hot path runs inside
+ * Keras/TensorFlow layer objects (Conv2D, DepthwiseConv2D, BatchNormalization, ...,
+ * imported at deeplabv3p.py:29-40).  Each entry point below replaces the device-side
+ * work of one of those layer types (forward and gradients); the Python host layer in
+ * keras-segmentation-deeplab-v3.1_amd/ re-exposes the reference's Deeplabv3()/Subpixel/
+ * SegModel surface on top of them.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *  - every op returns int: 0 OK, -1 bad argument, -2 HIP error, -3 workspace too small,
+ *    -4 unsupported configuration; dl3_last_error() gives a thread-local message.
+ *  - all tensor pointers are caller-owned DEVICE pointers (fp32 unless noted), NHWC,
+ *    weights in Keras layouts (pointwise [K][N]; depthwise [3][3][C]; dense [3][3][Cin][Cout]).
+ *  - no allocation, no synchronisation, no global mutable state inside ops; the last
+ *    argument is the hipStream_t to enqueue on.  Ops are hipGraph-capturable.
+ *  - "input transform": a tensor is handed over as (raw, scale[C], shift[C], act) and is
+ *    read as act(scale*raw+shift) — BatchNorm + ReLU/ReLU6 of the PRODUCER are applied on
+ *    load by the consumer, so an activation is written once and read once.  scale==NULL
+ *    means identity affine.
+ *  - "gradient operand": dY is handed over as (g, yraw, cA[C], cB[C], cC[C]) and read as
+ *    cA*g + cB*yraw + cC — the BatchNorm backward of the producer applied on load
+ *    (cA==NULL means dY = g).
+ *  - "partials": per-channel reductions (BN batch statistics, BN backward sums, weight
+ *    gradients) are written as P deterministic partial rows; dl3_*_partials() returns P
+ *    for a shape, dl3_bn_finalize()/dl3_bn_bwd_finalize()/dl3_reduce_partials() fold them
+ *    in a fixed order.  No float atomics anywhere: results are run-to-run bit-identical.
+ */
+#ifndef DL3_H
+#define DL3_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DL3_OK 0
+#define DL3_EINVAL (-1)
+#define DL3_EHIP (-2)
+#define DL3_EWORKSPACE (-3)
+#define DL3_EUNSUPPORTED (-4)
+
+#define DL3_ACT_NONE 0
+#define DL3_ACT_RELU 1  /* Activation('relu')            deeplabv3p.py:72,77,82,287,380,387,409 */
+#define DL3_ACT_RELU6 2 /* relu(x, max_value=6.)         deeplabv3p.py:181,192,325 */
+
+#define DL3_IMPL_AUTO 0
+#define DL3_IMPL_GATHER 1 /* generic 9-tap gather kernel (any stride / rate / pad) */
+#define DL3_IMPL_MARCH 2  /* stride-1 row-marching kernel (each input row read once) */
+
+int dl3_version(void);
+const char *dl3_last_error(void);
+
+/* ---- DepthwiseConv2D 3x3 (deeplabv3p.py:73-74, :186-188) ------------------------------ */
+/* number of partial rows P written by dwconv fwd (stat_partial [P][C][2]) and bwd
+ * (dstat_partial [P][C][2], dw_partial [P][9][C]) for this shape/impl */
+int dl3_dwconv3x3_partials(int N, int H, int W, int C, int stride, int rate, int Ho, int Wo, int impl);
+/* y[n,oy,ox,c] = sum_{i,j} T(x)[n, oy*stride-pad_t+i*rate, ox*stride-pad_l+j*rate, c] * w[i][j][c];
+ * stat_partial (nullable): per-channel sum(y), sum(y^2) partials */
+int dl3_dwconv3x3_fwd(const float *x, const float *in_scale, const float *in_shift, int in_act,
+                      const float *w, float *y, int N, int H, int W, int C, int stride, int rate,
+                      int pad_t, int pad_l, int Ho, int Wo, float *stat_partial, int impl, void *stream);
+/* fused bwd-data + bwd-weight.
+ *   dY = cA*g + cB*yraw + cC                                   [N,Ho,Wo,C]
+ *   dw_partial[p][i][j][c] = partial sum_{n,oy,ox} T(x)[...tap...] * dY
+ *   dx = mask_{in_act}(conv^T(dY, w)) + dx_add                 [N,H,W,C]   (dx nullable)
+ *   dstat_partial (nullable): sum(dx), sum(dx * (x-x_mean)*x_invstd) partials */
+int dl3_dwconv3x3_bwd(const float *g, const float *yraw, const float *cA, const float *cB, const float *cC,
+                      const float *x, const float *in_scale, const float *in_shift, int in_act,
+                      const float *w, float *dx, const float *dx_add, const float *x_mean,
+                      const float *x_invstd, float *dstat_partial, float *dw_partial, int N, int H, int W,
+                      int C, int stride, int rate, int pad_t, int pad_l, int Ho, int Wo, int impl, void *stream);
+
+/* ---- Conv2D 1x1 = GEMM on fp32 MFMA (deeplabv3p.py:78-79,:175,:194,:377,:385,:406,:420,:438) -- */
+/* P for the [M,K]x[K,N] GEMM's per-output-channel partials */
+int dl3_pwconv_partials(int M, int K, int N);
+/* y[M,N](ldy) = T(x)[M,K](ldx) . w[K,N] (+bias[N]); stat_partial (nullable) [P][N][2] = sum(y), sum(y^2) */
+int dl3_pwconv_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
+                   const float *w, const float *bias, float *y, int ldy, int M, int K, int N,
+                   float *stat_partial, void *stream);
+/* dx[M,K](lddx) = mask_{in_act}(dY[M,N] . wT[N,K]) + add_scale*dx_add ; dY = cA*g + cB*yraw + cC.
+ * x/in_scale/in_shift/in_act describe the FORWARD input (needed for the mask and x_hat);
+ * dx_add row address = dx_add + (m / add_div)*ldadd (add_div = H*W broadcasts a per-image vector);
+ * dstat_partial (nullable) [P'][K][2] = sum(dx), sum(dx*(x-x_mean)*x_invstd), P' = dl3_pwconv_partials(M,N,K) */
+int dl3_pwconv_bwd_data(const float *g, int ldg, const float *yraw, int ldyraw, const float *cA,
+                        const float *cB, const float *cC, const float *wT, float *dx, int lddx,
+                        const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
+                        const float *dx_add, int ldadd, int add_div, float add_scale, const float *x_mean,
+                        const float *x_invstd, float *dstat_partial, int M, int K, int N, void *stream);
+size_t dl3_pwconv_bwd_weight_workspace(int M, int K, int N);
+/* dw[K,N] = T(x)^T . dY ; dbias[N] (nullable) = colsum(dY) */
+int dl3_pwconv_bwd_weight(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
+                          const float *g, int ldg, const float *yraw, int ldyraw, const float *cA,
+                          const float *cB, const float *cC, float *dw, float *dbias, int M, int K, int N,
+                          void *workspace, size_t workspace_bytes, void *stream);
+/* out[cols][rows] = in[rows][cols]^T  (W[K,N] -> WT[N,K] for bwd_data) */
+int dl3_transpose(const float *in, float *out, int rows, int cols, void *stream);
+
+/* ---- dense Conv2D 3x3 (stem convs: deeplabv3p.py:283,:289,:318) ----------------------- */
+int dl3_conv3x3_partials(int N, int Ho, int Wo, int Cout);
+int dl3_conv3x3_fwd(const float *x, const float *in_scale, const float *in_shift, int in_act, const float *w,
+                    float *y, int N, int H, int W, int Cin, int Cout, int stride, int pad_t, int pad_l,
+                    int Ho, int Wo, float *stat_partial, void *stream);
+/* dw_partial [P][3][3][Cin][Cout] */
+int dl3_conv3x3_bwd_weight(const float *x, const float *in_scale, const float *in_shift, int in_act,
+                           const float *g, const float *yraw, const float *cA, const float *cB,
+                           const float *cC, float *dw_partial, int N, int H, int W, int Cin, int Cout,
+                           int stride, int pad_t, int pad_l, int Ho, int Wo, void *stream);
+/* dx = mask(conv^T(dY,w)) + dx_add, optional dstat partials ([P'][Cin][2], P' = dl3_conv3x3_partials(N,H,W,Cin)) */
+int dl3_conv3x3_bwd_data(const float *g, const float *yraw, const float *cA, const float *cB, const float *cC,
+                         const float *w, float *dx, const float *x, const float *in_scale,
+                         const float *in_shift, int in_act, const float *dx_add, const float *x_mean,
+                         const float *x_invstd, float *dstat_partial, int N, int H, int W, int Cin, int Cout,
+                         int stride, int pad_t, int pad_l, int Ho, int Wo, void *stream);
+
+/* ---- BatchNormalization (54 layers mnv2 / 146 xception; eps 1e-3 or 1e-5) -------------- */
+/* training mode: fold stat partials [P][ldc][2] (channels c0..c0+C-1 at partial + 2*c0) into
+ * scale = gamma*invstd, shift = beta - mean*scale, mean, invstd (biased batch variance) and
+ * update the moving statistics (moving = m*moving + (1-m)*batch).  count = N*H*W. */
+int dl3_bn_finalize(const float *stat_partial, int P, int ldc, int C, double count, const float *gamma,
+                    const float *beta, float eps, float momentum, float *scale, float *shift, float *mean,
+                    float *invstd, float *moving_mean, float *moving_var, void *stream);
+/* inference / frozen mode: scale, shift, mean, invstd from the moving statistics */
+int dl3_bn_frozen(const float *gamma, const float *beta, const float *moving_mean, const float *moving_var,
+                  float eps, int C, float *scale, float *shift, float *mean, float *invstd, void *stream);
+/* fold backward partials (sum g, sum g*x_hat) into dgamma, dbeta and the on-load coefficients
+ * dY = cA*g + cB*yraw + cC.  batch_mode=1: full BN backward; 0: frozen statistics (cB=cC=0). */
+int dl3_bn_bwd_finalize(const float *dstat_partial, int P, int ldc, int C, double count, const float *gamma,
+                        const float *mean, const float *invstd, int batch_mode, float *cA, float *cB,
+                        float *cC, float *dgamma, float *dbeta, void *stream);
+
+/* ---- element-wise / reductions ------------------------------------------------------- */
+int dl3_rows_partials(int M); /* P for row-wise reducing kernels over M rows */
+/* out = act_a(sa*a+ta) + act_b(sb*b+tb)  (b nullable): Add (deeplabv3p.py:147-149,:201) and
+ * materialisation of a BN(+act) output.  Optional Dropout (deeplabv3p.py:410): if drop_rate>0,
+ * out *= keep_mask(seed, element index)/(1-drop_rate). */
+int dl3_affine_add(const float *a, int lda, const float *sa, const float *ta, int act_a, const float *b,
+                   int ldb, const float *sb, const float *tb, int act_b, float *out, int ldo, int M, int C,
+                   float drop_rate, unsigned long long drop_seed, void *stream);
+/* gout = mask_{act}(gin * dropmask/(1-rate)) + add ; dstat partials [P][C][2] (nullable), P=dl3_rows_partials(M) */
+int dl3_grad_finish(const float *gin, int ldgin, float *gout, int ldgout, const float *add, int ldadd,
+                    const float *xraw, int ldx, const float *scale, const float *shift, int act,
+                    const float *mean, const float *invstd, float *dstat_partial, int M, int C,
+                    float drop_rate, unsigned long long drop_seed, void *stream);
+/* AveragePooling2D over the whole map (deeplabv3p.py:375): out[n][c] = out_scale * sum_hw T(x)[n,hw,c] */
+int dl3_gap_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act, float *out,
+                int N, int HW, int C, float out_scale, void *stream);
+/* tf.image.resize_bilinear, TF1 legacy (align_corners=False, no half-pixel): deeplabv3p.py:382,:418,:439 */
+int dl3_resize_bilinear_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
+                            float *y, int ldy, int N, int Hi, int Wi, int Ho, int Wo, int C, void *stream);
+/* dx[N,Hi,Wi,C] (+= if accumulate) = resize^T(dy) — deterministic gather form */
+int dl3_resize_bilinear_bwd(const float *dy, int lddy, float *dx, int lddx, int N, int Hi, int Wi, int Ho,
+                            int Wo, int C, int accumulate, void *stream);
+/* Subpixel._phase_shift (subpixel.py:77-88): out[n,ia*r+q,ib*r+p,ch] = in[n,ia,ib,ch*r*r+p*r+q];
+ * inverse!=0 applies the inverse permutation (the backward pass) */
+int dl3_phase_shift(const float *in, float *out, int N, int H, int W, int Cout, int r, int inverse, void *stream);
+/* softmax over the last axis (deeplabv3p.py:441,:444) */
+int dl3_softmax_fwd(const float *logits, float *probs, int M, int C, void *stream);
+/* argmax over the last axis -> int32 (first maximum wins, like np.argmax) */
+int dl3_argmax(const float *x, int *out, int M, int C, void *stream);
+/* count of non-zero sample weights -> *out (float) ; sparse_crossentropy_ignoring_last_label
+ * (utils.py:127-130) with Keras temporal sample weights:
+ *   loss = sum_m w[m]*(-log clip(p[m,label]))/nnz ; dlogits = (p - onehot)*w/nnz ; label==C (void): onehot=0.
+ * loss_partial [P] (P = dl3_rows_partials(M)); probs nullable. */
+int dl3_count_nonzero(const float *w, int M, float *out, void *stream);
+int dl3_softmax_xent(const float *logits, const float *labels, const float *weights, const float *nnz,
+                     float *probs, float *dlogits, float *loss_partial, int M, int C, void *stream);
+/* out[i] = sum_p partial[p][i]  (fixed order) */
+int dl3_reduce_partials(const float *partial, int P, int n, float *out, void *stream);
+int dl3_fill(float *p, float value, size_t n, void *stream);
+/* Keras Adam with decay (notebook cell 2): lr_t is computed on the host;
+ * g is first multiplied by grad_scale (1/world_size after the RCCL sum) */
+int dl3_adam_step(float *p, const float *g, float *m, float *v, size_t n, float lr_t, float beta1, float beta2,
+                  float eps, float grad_scale, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

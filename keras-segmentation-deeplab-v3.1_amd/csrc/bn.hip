@@ -1,0 +1,373 @@
+// bn.hip — BatchNormalization folding kernels, deterministic partial reductions and the
+// element-wise glue (Add / materialise / gradient finish) of the DeepLabV3+ path.
+//
+// BatchNorm never runs as its own pass over an activation: the producer conv reduces
+// sum / sum-of-squares partials in its epilogue, dl3_bn_finalize folds them into
+// (scale, shift) and every consumer applies act(scale*x+shift) on load.  The backward pass
+// mirrors it: consumers' bwd-data epilogues reduce (sum g, sum g*x_hat), dl3_bn_bwd_finalize
+// folds them into the three per-channel coefficients of dY = cA*g + cB*y + cC that the
+// producer's backward kernels apply on load.
+// Reference layers: BatchNormalization at deeplabv3p.py:75,:80,:146,:178,:189,:197,:286,:290,
+// :322,:379,:386,:408,:422; training semantics [TF 1.13 FusedBatchNorm]: biased batch variance
+// for normalisation, Bessel-corrected variance into moving_variance.
+#include "common.h"
+
+namespace {
+
+// sum over P partial rows of two interleaved values per channel; 8 channels x 32 row lanes
+// per block, fixed order, double accumulation.  Result valid for threads with pl == 0.
+__device__ __forceinline__ void fold2(const float *part, int P, int ldc, int c, bool cok, double &o1, double &o2,
+                                      double *red /* [32][8][2] */) {
+  const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  double s1 = 0.0, s2 = 0.0;
+  if (cok)
+    for (int p = pl; p < P; p += 32) {
+      const float *q = part + ((size_t)p * ldc + c) * 2;
+      s1 += (double)q[0];
+      s2 += (double)q[1];
+    }
+  red[(pl * 8 + cl) * 2 + 0] = s1;
+  red[(pl * 8 + cl) * 2 + 1] = s2;
+  __syncthreads();
+  o1 = 0.0;
+  o2 = 0.0;
+  if (pl == 0)
+    for (int q = 0; q < 32; q++) {
+      o1 += red[(q * 8 + cl) * 2 + 0];
+      o2 += red[(q * 8 + cl) * 2 + 1];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ part, int P, int ldc, int C,
+                                                          double count, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float eps,
+                                                          float momentum, float *scale, float *shift, float *mean,
+                                                          float *invstd, float *mmean, float *mvar) {
+  __shared__ double red[32 * 8 * 2];
+  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+  const bool cok = c < C;
+  double s1, s2;
+  fold2(part, P, ldc, c, cok, s1, s2, red);
+  if ((threadIdx.x >> 3) == 0 && cok) {
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    const double sc = (double)gamma[c] * is;
+    scale[c] = (float)sc;
+    shift[c] = (float)((double)beta[c] - m * sc);
+    mean[c] = (float)m;
+    invstd[c] = (float)is;
+    if (mmean) {
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      mmean[c] = (float)((double)momentum * mmean[c] + (1.0 - (double)momentum) * m);
+      mvar[c] = (float)((double)momentum * mvar[c] + (1.0 - (double)momentum) * unb);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_frozen_kernel(const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta,
+                                                        const float *__restrict__ mmean,
+                                                        const float *__restrict__ mvar, float eps, int C,
+                                                        float *scale, float *shift, float *mean, float *invstd) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C) {
+    const double is = 1.0 / sqrt((double)mvar[c] + (double)eps);
+    const double sc = (double)gamma[c] * is;
+    scale[c] = (float)sc;
+    shift[c] = (float)((double)beta[c] - (double)mmean[c] * sc);
+    if (mean) mean[c] = mmean[c];
+    if (invstd) invstd[c] = (float)is;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__restrict__ part, int P, int ldc, int C,
+                                                              double count, const float *__restrict__ gamma,
+                                                              const float *__restrict__ mean,
+                                                              const float *__restrict__ invstd, int batch_mode,
+                                                              float *cA, float *cB, float *cC, float *dgamma,
+                                                              float *dbeta) {
+  __shared__ double red[32 * 8 * 2];
+  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+  const bool cok = c < C;
+  double s1, s2;
+  fold2(part, P, ldc, c, cok, s1, s2, red);
+  if ((threadIdx.x >> 3) == 0 && cok) {
+    // s1 = sum g = dbeta ; s2 = sum g * x_hat = dgamma
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+    const double a = (double)gamma[c] * (double)invstd[c];
+    if (batch_mode) {
+      // dy = a*(g - s1/M - x_hat*s2/M), x_hat = (y - mean)*invstd
+      const double b = -a * (double)invstd[c] * s2 / count;
+      cA[c] = (float)a;
+      cB[c] = (float)b;
+      cC[c] = (float)(-a * s1 / count - b * (double)mean[c]);
+    } else {
+      cA[c] = (float)a;
+      cB[c] = 0.f;
+      cC[c] = 0.f;
+    }
+  }
+}
+
+// out[i] = sum_p part[p][i]; COLS columns x PL row lanes per block
+template <int COLS, int PL>
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ part, int P, int n,
+                                                              float *__restrict__ out) {
+  static_assert(COLS * PL == 256, "256 threads");
+  __shared__ float red[256];
+  const int cl = threadIdx.x % COLS, pl = threadIdx.x / COLS;
+  const long col = (long)blockIdx.x * COLS + cl;
+  float s = 0.f;
+  if (col < n)
+    for (int p = pl; p < P; p += PL) s += part[(size_t)p * n + col];
+  red[pl * COLS + cl] = s;
+  __syncthreads();
+  if (pl == 0 && col < n) {
+    float t = 0.f;
+    for (int q = 0; q < PL; q++) t += red[q * COLS + cl];
+    out[col] = t;
+  }
+}
+
+// out = act_a(sa*a+ta) + act_b(sb*b+tb), optional dropout; one thread per element, channel fastest
+__global__ __launch_bounds__(256) void affine_add_kernel(const float *__restrict__ a, int lda,
+                                                         const float *__restrict__ sa,
+                                                         const float *__restrict__ ta, int act_a,
+                                                         const float *__restrict__ b, int ldb,
+                                                         const float *__restrict__ sb,
+                                                         const float *__restrict__ tb, int act_b,
+                                                         float *__restrict__ out, int ldo, long M, int C,
+                                                         float drop_rate, unsigned long long seed) {
+  const long total = M * C;
+  const float keep_scale = drop_rate > 0.f ? 1.f / (1.f - drop_rate) : 1.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long m = i / C;
+    const int c = (int)(i - m * C);
+    float v = a[(size_t)m * lda + c];
+    if (sa) v = sa[c] * v + ta[c];
+    v = dl3_act(v, act_a);
+    if (b) {
+      float u = b[(size_t)m * ldb + c];
+      if (sb) u = sb[c] * u + tb[c];
+      v += dl3_act(u, act_b);
+    }
+    if (drop_rate > 0.f) v = (dl3_uniform(seed, (unsigned long long)i) >= drop_rate) ? v * keep_scale : 0.f;
+    out[(size_t)m * ldo + c] = v;
+  }
+}
+
+// gout = mask_act(gin*dropmask) + add ; stats partial [gridDim.y][C][2]; 32 columns x 8 row lanes
+__global__ __launch_bounds__(256) void grad_finish_kernel(const float *__restrict__ gin, int ldgin,
+                                                          float *__restrict__ gout, int ldgout,
+                                                          const float *__restrict__ add, int ldadd,
+                                                          const float *__restrict__ xraw, int ldx,
+                                                          const float *__restrict__ scale,
+                                                          const float *__restrict__ shift, int act,
+                                                          const float *__restrict__ mean,
+                                                          const float *__restrict__ invstd,
+                                                          float *__restrict__ part, long M, int C, float drop_rate,
+                                                          unsigned long long seed) {
+  __shared__ float red[256 * 2];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const bool cok = c < C;
+  const float keep_scale = drop_rate > 0.f ? 1.f / (1.f - drop_rate) : 1.f;
+  float es = 1.f, et = 0.f, mu = 0.f, is = 0.f;
+  if (cok) {
+    if (scale) { es = scale[c]; et = shift[c]; }
+    if (mean) { mu = mean[c]; is = invstd[c]; }
+  }
+  float s1 = 0.f, s2 = 0.f;
+  if (cok)
+    for (long m = (long)blockIdx.y * 8 + rl; m < M; m += (long)gridDim.y * 8) {
+      float v = gin[(size_t)m * ldgin + c];
+      if (drop_rate > 0.f)
+        v = (dl3_uniform(seed, (unsigned long long)(m * C + c)) >= drop_rate) ? v * keep_scale : 0.f;
+      float xr = 0.f;
+      if (xraw) {
+        xr = xraw[(size_t)m * ldx + c];
+        v *= dl3_act_mask(es * xr + et, act);
+      }
+      if (add) v += add[(size_t)m * ldadd + c];
+      gout[(size_t)m * ldgout + c] = v;
+      s1 += v;
+      s2 += v * ((xr - mu) * is);
+    }
+  if (part) {
+    red[threadIdx.x * 2] = s1;
+    red[threadIdx.x * 2 + 1] = s2;
+    __syncthreads();
+    if (rl == 0 && cok) {
+      float a1 = 0.f, a2 = 0.f;
+      for (int q = 0; q < 8; q++) {
+        a1 += red[(q * 32 + cl) * 2];
+        a2 += red[(q * 32 + cl) * 2 + 1];
+      }
+      part[((size_t)blockIdx.y * C + c) * 2] = a1;
+      part[((size_t)blockIdx.y * C + c) * 2 + 1] = a2;
+    }
+  }
+}
+
+// out[n][c] = out_scale * sum_hw T(x)[n,hw,c]; grid (ceil(C/32), N); 32 columns x 8 row lanes
+__global__ __launch_bounds__(256) void gap_kernel(const float *__restrict__ x, int ldx,
+                                                  const float *__restrict__ sc, const float *__restrict__ sh,
+                                                  int act, float *__restrict__ out, int HW, int C, float out_scale) {
+  __shared__ float red[256];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl, n = blockIdx.y;
+  float s = 0.f;
+  if (c < C) {
+    float es = 1.f, et = 0.f;
+    if (sc) { es = sc[c]; et = sh[c]; }
+    const float *p = x + (size_t)n * HW * ldx + c;
+    for (int i = rl; i < HW; i += 8) s += dl3_act(es * p[(size_t)i * ldx] + et, act);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float t = 0.f;
+    for (int q = 0; q < 8; q++) t += red[q * 32 + cl];
+    out[(size_t)n * C + c] = t * out_scale;
+  }
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float *p, float v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
+}
+
+// Keras Adam (notebook cell 2): p -= lr_t * m / (sqrt(v) + eps), bias correction folded into lr_t
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                   float *__restrict__ m, float *__restrict__ v, size_t n,
+                                                   float lr_t, float b1, float b2, float eps, float gs) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float gi = g[i] * gs;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+inline int ew_blocks(size_t n) {
+  size_t b = (n + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int dl3_rows_partials(int M) {
+  int p = M / 64;
+  if (p < 1) p = 1;
+  if (p > 512) p = 512;
+  return p;
+}
+
+extern "C" int dl3_bn_finalize(const float *stat_partial, int P, int ldc, int C, double count, const float *gamma,
+                               const float *beta, float eps, float momentum, float *scale, float *shift,
+                               float *mean, float *invstd, float *moving_mean, float *moving_var, void *stream) {
+  DL3_CHECK_ARG(stat_partial && gamma && beta && scale && shift && mean && invstd, "bn_finalize: null pointer");
+  DL3_CHECK_ARG(P > 0 && C > 0 && ldc >= C && count > 0, "bn_finalize: bad dimension");
+  DL3_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "bn_finalize: moving stats come together");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(dl3_cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, stat_partial, P,
+                     ldc, C, count, gamma, beta, eps, momentum, scale, shift, mean, invstd, moving_mean,
+                     moving_var);
+  DL3_LAUNCH_CHECK("bn_finalize");
+  return DL3_OK;
+}
+
+extern "C" int dl3_bn_frozen(const float *gamma, const float *beta, const float *moving_mean,
+                             const float *moving_var, float eps, int C, float *scale, float *shift, float *mean,
+                             float *invstd, void *stream) {
+  DL3_CHECK_ARG(gamma && beta && moving_mean && moving_var && scale && shift && C > 0, "bn_frozen: bad argument");
+  hipLaunchKernelGGL(bn_frozen_kernel, dim3(dl3_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                     moving_mean, moving_var, eps, C, scale, shift, mean, invstd);
+  DL3_LAUNCH_CHECK("bn_frozen");
+  return DL3_OK;
+}
+
+extern "C" int dl3_bn_bwd_finalize(const float *dstat_partial, int P, int ldc, int C, double count,
+                                   const float *gamma, const float *mean, const float *invstd, int batch_mode,
+                                   float *cA, float *cB, float *cC, float *dgamma, float *dbeta, void *stream) {
+  DL3_CHECK_ARG(dstat_partial && gamma && mean && invstd && cA && cB && cC, "bn_bwd_finalize: null pointer");
+  DL3_CHECK_ARG(P > 0 && C > 0 && ldc >= C && count > 0, "bn_bwd_finalize: bad dimension");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dl3_cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream,
+                     dstat_partial, P, ldc, C, count, gamma, mean, invstd, batch_mode, cA, cB, cC, dgamma, dbeta);
+  DL3_LAUNCH_CHECK("bn_bwd_finalize");
+  return DL3_OK;
+}
+
+extern "C" int dl3_reduce_partials(const float *partial, int P, int n, float *out, void *stream) {
+  DL3_CHECK_ARG(partial && out && P > 0 && n > 0, "reduce_partials: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (P <= 32)
+    hipLaunchKernelGGL((reduce_partials_kernel<64, 4>), dim3(dl3_cdiv(n, 64)), dim3(256), 0, st, partial, P, n, out);
+  else if (P <= 256)
+    hipLaunchKernelGGL((reduce_partials_kernel<32, 8>), dim3(dl3_cdiv(n, 32)), dim3(256), 0, st, partial, P, n, out);
+  else
+    hipLaunchKernelGGL((reduce_partials_kernel<8, 32>), dim3(dl3_cdiv(n, 8)), dim3(256), 0, st, partial, P, n, out);
+  DL3_LAUNCH_CHECK("reduce_partials");
+  return DL3_OK;
+}
+
+extern "C" int dl3_affine_add(const float *a, int lda, const float *sa, const float *ta, int act_a,
+                              const float *b, int ldb, const float *sb, const float *tb, int act_b, float *out,
+                              int ldo, int M, int C, float drop_rate, unsigned long long drop_seed, void *stream) {
+  DL3_CHECK_ARG(a && out && M > 0 && C > 0, "affine_add: bad argument");
+  DL3_CHECK_ARG((sa == nullptr) == (ta == nullptr) && (sb == nullptr) == (tb == nullptr),
+                "affine_add: scale/shift must come together");
+  DL3_CHECK_ARG(drop_rate >= 0.f && drop_rate < 1.f, "affine_add: drop_rate must be in [0,1)");
+  hipLaunchKernelGGL(affine_add_kernel, dim3(ew_blocks((size_t)M * C)), dim3(256), 0, (hipStream_t)stream, a, lda,
+                     sa, ta, act_a, b, ldb, sb, tb, act_b, out, ldo, (long)M, C, drop_rate, drop_seed);
+  DL3_LAUNCH_CHECK("affine_add");
+  return DL3_OK;
+}
+
+extern "C" int dl3_grad_finish(const float *gin, int ldgin, float *gout, int ldgout, const float *add, int ldadd,
+                               const float *xraw, int ldx, const float *scale, const float *shift, int act,
+                               const float *mean, const float *invstd, float *dstat_partial, int M, int C,
+                               float drop_rate, unsigned long long drop_seed, void *stream) {
+  DL3_CHECK_ARG(gin && gout && M > 0 && C > 0, "grad_finish: bad argument");
+  DL3_CHECK_ARG(act == DL3_ACT_NONE || xraw, "grad_finish: activation mask needs xraw");
+  DL3_CHECK_ARG(!dstat_partial || (xraw && mean && invstd), "grad_finish: dstat needs xraw, mean, invstd");
+  DL3_CHECK_ARG((scale == nullptr) == (shift == nullptr), "grad_finish: scale/shift must come together");
+  dim3 grid(dl3_cdiv(C, 32), dl3_rows_partials(M));
+  hipLaunchKernelGGL(grad_finish_kernel, grid, dim3(256), 0, (hipStream_t)stream, gin, ldgin, gout, ldgout, add,
+                     ldadd, xraw, ldx, scale, shift, act, mean, invstd, dstat_partial, (long)M, C, drop_rate,
+                     drop_seed);
+  DL3_LAUNCH_CHECK("grad_finish");
+  return DL3_OK;
+}
+
+extern "C" int dl3_gap_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
+                           float *out, int N, int HW, int C, float out_scale, void *stream) {
+  DL3_CHECK_ARG(x && out && N > 0 && HW > 0 && C > 0 && ldx >= C, "gap_fwd: bad argument");
+  DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "gap_fwd: scale/shift must come together");
+  DL3_UNSUPPORTED(N > 65535, "gap_fwd: N too large");
+  hipLaunchKernelGGL(gap_kernel, dim3(dl3_cdiv(C, 32), N), dim3(256), 0, (hipStream_t)stream, x, ldx, in_scale,
+                     in_shift, in_act, out, HW, C, out_scale);
+  DL3_LAUNCH_CHECK("gap_fwd");
+  return DL3_OK;
+}
+
+extern "C" int dl3_fill(float *p, float value, size_t n, void *stream) {
+  DL3_CHECK_ARG(p && n > 0, "fill: bad argument");
+  hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, value, n);
+  DL3_LAUNCH_CHECK("fill");
+  return DL3_OK;
+}
+
+extern "C" int dl3_adam_step(float *p, const float *g, float *m, float *v, size_t n, float lr_t, float beta1,
+                             float beta2, float eps, float grad_scale, void *stream) {
+  DL3_CHECK_ARG(p && g && m && v && n > 0, "adam_step: bad argument");
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, beta1,
+                     beta2, eps, grad_scale);
+  DL3_LAUNCH_CHECK("adam_step");
+  return DL3_OK;
+}

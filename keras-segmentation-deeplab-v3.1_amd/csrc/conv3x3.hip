@@ -1,0 +1,291 @@
+// conv3x3.hip — dense Conv2D 3x3 for the three stem convolutions (deeplabv3p.py:283 entry_flow_conv1_1,
+// :289 entry_flow_conv1_2, :318 Conv).  Cin is 3 or 32: direct convolution on the vector ALU (the
+// north star keeps MFMA for the 1x1 GEMMs only); the input scale x/127.5-1 (deeplabv3p.py:270)
+// arrives as the input transform and is applied on load, so the raw 0-255 image is read once.
+// Thread = (4 output channels, output pixel); weights [3][3][Cin][Cout] are read as float4 along
+// Cout (L1 resident: 3.4 KB for the MobileNetV2 stem).
+#include "common.h"
+
+namespace {
+
+struct CGeom {
+  int N, H, W, Cin, Cout, stride, pad_t, pad_l, Ho, Wo;
+};
+
+// block-level fixed-order reduction of NV floats over the pixel lanes that share a channel quad.
+// tid = pl*CQ + cq.  Result valid for tid < CQ.
+template <int NV>
+__device__ __forceinline__ void reduce_over_pixels(float (&v)[NV], float *lds /* [256][NV] */, int CQ) {
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; i++) lds[threadIdx.x * NV + i] = v[i];
+  __syncthreads();
+  if ((int)threadIdx.x < CQ) {
+    const int PL = 256 / CQ;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      float s = 0.f;
+      for (int q = 0; q < PL; q++) s += lds[(q * CQ + threadIdx.x) * NV + i];
+      v[i] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void conv3x3_fwd_kernel(const float *__restrict__ x, const float *__restrict__ sc,
+                                                          const float *__restrict__ sh, int act,
+                                                          const float *__restrict__ w, float *__restrict__ y,
+                                                          CGeom G, float *__restrict__ part) {
+  __shared__ float red[256 * 8];
+  const int CQ = G.Cout / 4;
+  const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ, PL = 256 / CQ;
+  const int co = cq * 4;
+  f32x4 s1 = splat4(0.f), s2 = splat4(0.f);
+  const long NP = (long)G.N * G.Ho * G.Wo;
+  for (long p = (long)blockIdx.x * PL + pl; p < NP; p += (long)gridDim.x * PL) {
+    const int ox = (int)(p % G.Wo);
+    const int oy = (int)((p / G.Wo) % G.Ho);
+    const int n = (int)(p / ((long)G.Wo * G.Ho));
+    f32x4 acc = splat4(0.f);
+    for (int i = 0; i < 3; i++) {
+      const int iy = oy * G.stride - G.pad_t + i;
+      if (iy < 0 || iy >= G.H) continue;
+      for (int j = 0; j < 3; j++) {
+        const int ix = ox * G.stride - G.pad_l + j;
+        if (ix < 0 || ix >= G.W) continue;
+        const float *xp = x + (((size_t)n * G.H + iy) * G.W + ix) * G.Cin;
+        const float *wp = w + ((size_t)(i * 3 + j) * G.Cin) * G.Cout + co;
+        for (int ci = 0; ci < G.Cin; ci++) {
+          float v = xp[ci];
+          if (sc) v = sc[ci] * v + sh[ci];
+          v = dl3_act(v, act);
+          acc += splat4(v) * ld4(wp + (size_t)ci * G.Cout);
+        }
+      }
+    }
+    st4(y + (size_t)p * G.Cout + co, acc);
+    s1 += acc;
+    s2 += acc * acc;
+  }
+  if (part) {
+    float v[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
+    reduce_over_pixels<8>(v, red, CQ);
+    if ((int)threadIdx.x < CQ) {
+      float *d = part + ((size_t)blockIdx.x * G.Cout + co) * 2;
+      d[0] = v[0]; d[1] = v[4]; d[2] = v[1]; d[3] = v[5];
+      d[4] = v[2]; d[5] = v[6]; d[6] = v[3]; d[7] = v[7];
+    }
+  }
+}
+
+// dW partial [gridDim.x][3][3][Cin][Cout]; blockIdx.y selects a chunk of 3 input channels
+constexpr int CI_CHUNK = 3;
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float *__restrict__ x,
+                                                            const float *__restrict__ sc,
+                                                            const float *__restrict__ sh, int act,
+                                                            const float *__restrict__ g,
+                                                            const float *__restrict__ yraw,
+                                                            const float *__restrict__ cA,
+                                                            const float *__restrict__ cB,
+                                                            const float *__restrict__ cC, float *__restrict__ wpart,
+                                                            CGeom G) {
+  __shared__ float red[256 * 12];
+  const int CQ = G.Cout / 4;
+  const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ, PL = 256 / CQ;
+  const int co = cq * 4;
+  const int ci0 = blockIdx.y * CI_CHUNK;
+  f32x4 kA = splat4(1.f), kB = splat4(0.f), kC = splat4(0.f);
+  const bool two = cA != nullptr;
+  if (two) { kA = ld4(cA + co); kB = ld4(cB + co); kC = ld4(cC + co); }
+  f32x4 acc[9][CI_CHUNK];
+#pragma unroll
+  for (int t = 0; t < 9; t++)
+#pragma unroll
+    for (int k = 0; k < CI_CHUNK; k++) acc[t][k] = splat4(0.f);
+  const long NP = (long)G.N * G.Ho * G.Wo;
+  for (long p = (long)blockIdx.x * PL + pl; p < NP; p += (long)gridDim.x * PL) {
+    const int ox = (int)(p % G.Wo);
+    const int oy = (int)((p / G.Wo) % G.Ho);
+    const int n = (int)(p / ((long)G.Wo * G.Ho));
+    f32x4 dd = ld4(g + (size_t)p * G.Cout + co);
+    if (two) dd = kA * dd + kB * ld4(yraw + (size_t)p * G.Cout + co) + kC;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int iy = oy * G.stride - G.pad_t + i;
+      if (iy < 0 || iy >= G.H) continue;
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int ix = ox * G.stride - G.pad_l + j;
+        if (ix < 0 || ix >= G.W) continue;
+        const float *xp = x + (((size_t)n * G.H + iy) * G.W + ix) * G.Cin;
+#pragma unroll
+        for (int k = 0; k < CI_CHUNK; k++) {
+          const int ci = ci0 + k;
+          if (ci < G.Cin) {
+            float v = xp[ci];
+            if (sc) v = sc[ci] * v + sh[ci];
+            v = dl3_act(v, act);
+            acc[i * 3 + j][k] += splat4(v) * dd;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; t++) {
+    float v[4 * CI_CHUNK];
+#pragma unroll
+    for (int k = 0; k < CI_CHUNK; k++) {
+      v[k * 4 + 0] = acc[t][k].x; v[k * 4 + 1] = acc[t][k].y;
+      v[k * 4 + 2] = acc[t][k].z; v[k * 4 + 3] = acc[t][k].w;
+    }
+    reduce_over_pixels<4 * CI_CHUNK>(v, red, CQ);
+    if ((int)threadIdx.x < CQ) {
+#pragma unroll
+      for (int k = 0; k < CI_CHUNK; k++) {
+        const int ci = ci0 + k;
+        if (ci < G.Cin) {
+          f32x4 o = {v[k * 4], v[k * 4 + 1], v[k * 4 + 2], v[k * 4 + 3]};
+          st4(wpart + (((size_t)blockIdx.x * 9 + t) * G.Cin + ci) * G.Cout + co, o);
+        }
+      }
+    }
+  }
+}
+
+// bwd-data (xception entry_flow_conv1_2 only): thread = (input pixel, 4 input channels)
+__global__ __launch_bounds__(256) void conv3x3_dgrad_kernel(
+    const float *__restrict__ g, const float *__restrict__ yraw, const float *__restrict__ cA,
+    const float *__restrict__ cB, const float *__restrict__ cC, const float *__restrict__ w, float *__restrict__ dx,
+    const float *__restrict__ x, const float *__restrict__ sc, const float *__restrict__ sh, int act,
+    const float *__restrict__ dx_add, const float *__restrict__ xmean, const float *__restrict__ xinvstd,
+    float *__restrict__ part, CGeom G) {
+  __shared__ float red[256 * 8];
+  const int CQ = G.Cin / 4;
+  const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ, PL = 256 / CQ;
+  const int ci = cq * 4;
+  const bool two = cA != nullptr;
+  f32x4 s = splat4(1.f), t = splat4(0.f), mu = splat4(0.f), is = splat4(0.f);
+  if (sc) { s = ld4(sc + ci); t = ld4(sh + ci); }
+  if (part) { mu = ld4(xmean + ci); is = ld4(xinvstd + ci); }
+  f32x4 s1 = splat4(0.f), s2 = splat4(0.f);
+  const long NP = (long)G.N * G.H * G.W;
+  for (long p = (long)blockIdx.x * PL + pl; p < NP; p += (long)gridDim.x * PL) {
+    const int ix = (int)(p % G.W);
+    const int iy = (int)((p / G.W) % G.H);
+    const int n = (int)(p / ((long)G.W * G.H));
+    f32x4 acc = splat4(0.f);
+    for (int i = 0; i < 3; i++) {
+      const int ty = iy + G.pad_t - i;
+      if (ty < 0 || (ty % G.stride) != 0) continue;
+      const int oy = ty / G.stride;
+      if (oy >= G.Ho) continue;
+      for (int j = 0; j < 3; j++) {
+        const int tx = ix + G.pad_l - j;
+        if (tx < 0 || (tx % G.stride) != 0) continue;
+        const int ox = tx / G.stride;
+        if (ox >= G.Wo) continue;
+        const size_t off = (((size_t)n * G.Ho + oy) * G.Wo + ox) * G.Cout;
+        const float *wp = w + ((size_t)(i * 3 + j) * G.Cin + ci) * G.Cout;
+        for (int co = 0; co < G.Cout; co++) {
+          float dd = g[off + co];
+          if (two) dd = cA[co] * dd + cB[co] * yraw[off + co] + cC[co];
+          f32x4 wv = {wp[co], wp[G.Cout + co], wp[2 * (size_t)G.Cout + co], wp[3 * (size_t)G.Cout + co]};
+          acc += splat4(dd) * wv;
+        }
+      }
+    }
+    f32x4 out = acc;
+    f32x4 xr = splat4(0.f);
+    if (x) {
+      xr = ld4(x + (size_t)p * G.Cin + ci);
+      out = out * dl3_mask4(s * xr + t, act);
+    }
+    if (dx_add) out += ld4(dx_add + (size_t)p * G.Cin + ci);
+    st4(dx + (size_t)p * G.Cin + ci, out);
+    s1 += out;
+    s2 += out * ((xr - mu) * is);
+  }
+  if (part) {
+    float v[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
+    reduce_over_pixels<8>(v, red, CQ);
+    if ((int)threadIdx.x < CQ) {
+      float *d = part + ((size_t)blockIdx.x * G.Cin + ci) * 2;
+      d[0] = v[0]; d[1] = v[4]; d[2] = v[1]; d[3] = v[5];
+      d[4] = v[2]; d[5] = v[6]; d[6] = v[3]; d[7] = v[7];
+    }
+  }
+}
+
+int conv_blocks(long NP) {
+  long b = (NP + 31) / 32;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+int conv_check(const char *name, const CGeom &G) {
+  DL3_CHECK_ARG(G.N > 0 && G.H > 0 && G.W > 0 && G.Cin > 0 && G.Cout > 0 && G.Ho > 0 && G.Wo > 0 && G.stride >= 1,
+                "%s: bad dimension", name);
+  DL3_UNSUPPORTED(G.Cout % 4 != 0 || 256 % (G.Cout / 4) != 0 || G.Cout / 4 > 256,
+                  "%s: Cout=%d must be 4*(a divisor of 256)", name, G.Cout);
+  return DL3_OK;
+}
+
+}  // namespace
+
+extern "C" int dl3_conv3x3_partials(int N, int Ho, int Wo, int Cout) {
+  (void)Cout;
+  return conv_blocks((long)N * Ho * Wo);
+}
+
+extern "C" int dl3_conv3x3_fwd(const float *x, const float *in_scale, const float *in_shift, int in_act,
+                               const float *w, float *y, int N, int H, int W, int Cin, int Cout, int stride,
+                               int pad_t, int pad_l, int Ho, int Wo, float *stat_partial, void *stream) {
+  CGeom G{N, H, W, Cin, Cout, stride, pad_t, pad_l, Ho, Wo};
+  int rc = conv_check("conv3x3_fwd", G);
+  if (rc) return rc;
+  DL3_CHECK_ARG(x && w && y, "conv3x3_fwd: null pointer");
+  DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "conv3x3_fwd: scale/shift must come together");
+  hipLaunchKernelGGL(conv3x3_fwd_kernel, dim3(conv_blocks((long)N * Ho * Wo)), dim3(256), 0, (hipStream_t)stream,
+                     x, in_scale, in_shift, in_act, w, y, G, stat_partial);
+  DL3_LAUNCH_CHECK("conv3x3_fwd");
+  return DL3_OK;
+}
+
+extern "C" int dl3_conv3x3_bwd_weight(const float *x, const float *in_scale, const float *in_shift, int in_act,
+                                      const float *g, const float *yraw, const float *cA, const float *cB,
+                                      const float *cC, float *dw_partial, int N, int H, int W, int Cin, int Cout,
+                                      int stride, int pad_t, int pad_l, int Ho, int Wo, void *stream) {
+  CGeom G{N, H, W, Cin, Cout, stride, pad_t, pad_l, Ho, Wo};
+  int rc = conv_check("conv3x3_bwd_weight", G);
+  if (rc) return rc;
+  DL3_CHECK_ARG(x && g && dw_partial, "conv3x3_bwd_weight: null pointer");
+  DL3_CHECK_ARG(!cA || (yraw && cB && cC), "conv3x3_bwd_weight: cA needs yraw, cB, cC");
+  DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "conv3x3_bwd_weight: scale/shift must come together");
+  dim3 grid(conv_blocks((long)N * Ho * Wo), dl3_cdiv(Cin, CI_CHUNK));
+  hipLaunchKernelGGL(conv3x3_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, in_scale, in_shift, in_act,
+                     g, yraw, cA, cB, cC, dw_partial, G);
+  DL3_LAUNCH_CHECK("conv3x3_bwd_weight");
+  return DL3_OK;
+}
+
+extern "C" int dl3_conv3x3_bwd_data(const float *g, const float *yraw, const float *cA, const float *cB,
+                                    const float *cC, const float *w, float *dx, const float *x,
+                                    const float *in_scale, const float *in_shift, int in_act, const float *dx_add,
+                                    const float *x_mean, const float *x_invstd, float *dstat_partial, int N, int H,
+                                    int W, int Cin, int Cout, int stride, int pad_t, int pad_l, int Ho, int Wo,
+                                    void *stream) {
+  CGeom G{N, H, W, Cin, Cout, stride, pad_t, pad_l, Ho, Wo};
+  DL3_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0 && stride >= 1,
+                "conv3x3_bwd_data: bad dimension");
+  DL3_UNSUPPORTED(Cin % 4 != 0 || 256 % (Cin / 4) != 0, "conv3x3_bwd_data: Cin=%d must be 4*(a divisor of 256)", Cin);
+  DL3_CHECK_ARG(g && w && dx, "conv3x3_bwd_data: null pointer");
+  DL3_CHECK_ARG(!cA || (yraw && cB && cC), "conv3x3_bwd_data: cA needs yraw, cB, cC");
+  DL3_CHECK_ARG(in_act == DL3_ACT_NONE || x, "conv3x3_bwd_data: activation mask needs x");
+  DL3_CHECK_ARG(!dstat_partial || (x && x_mean && x_invstd), "conv3x3_bwd_data: dstat needs x, x_mean, x_invstd");
+  const int blocks = conv_blocks((long)N * H * W);
+  hipLaunchKernelGGL(conv3x3_dgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, yraw, cA, cB, cC, w,
+                     dx, x, in_scale, in_shift, in_act, dx_add, x_mean, x_invstd, dstat_partial, G);
+  DL3_LAUNCH_CHECK("conv3x3_bwd_data");
+  return DL3_OK;
+}

@@ -1,0 +1,535 @@
+// dwconv.hip — DepthwiseConv2D 3x3 (deeplabv3p.py:73-74, :186-188): forward and fused backward.
+//
+// HBM-bound (9 MAC per 8 B).  Layout NHWC fp32, 4 channels (16 B) per lane; a workgroup is
+// 8 channel-quads x 32 pixels, so one wave-instruction touches 8 pixels x 128 B (one full
+// cache line per pixel of a 32-channel slab).
+//
+//  * march kernels (stride 1, SAME): im2col-free direct dilated convolution.  A dilated conv
+//    with rate r couples only rows y == a (mod r): each workgroup walks ONE such row phase
+//    (rows a, a+r, a+2r, ...) top to bottom, so the vertical taps are the lane's own history
+//    held in registers — every input row is fetched once from HBM regardless of the rate
+//    (the "space-to-batch" trick of TF done virtually, no data movement).  The two horizontal
+//    taps x-r / x+r are served by L1/L2 (same row, same time, neighbouring lanes/waves).
+//  * gather kernels: generic 9-tap form for stride 2 / explicit pads (2 layers in MobileNetV2).
+//
+// BatchNorm + ReLU6 of the producer are applied on load ("input transform"); the BN batch
+// statistics of THIS layer's output are reduced in the epilogue into deterministic partials.
+#include "common.h"
+
+namespace {
+
+struct DwGeom {
+  int N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo;
+};
+
+// ---- block reduction over the 32 pixel lanes that share a channel quad -----------------
+// lane layout: tid = pl*8 + cq.  Result valid in threads tid < 8 (pl == 0), fixed order.
+template <int NV>
+__device__ __forceinline__ void reduce_px(float (&v)[NV], float *lds /* [4][8][NV] */) {
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, cq = tid & 7;
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    float s = v[i];
+    s += __shfl_xor(s, 8, 64);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    v[i] = s;
+  }
+  __syncthreads();
+  if ((tid & 63) < 8) {
+#pragma unroll
+    for (int i = 0; i < NV; i++) lds[(wave * 8 + cq) * NV + i] = v[i];
+  }
+  __syncthreads();
+  if (tid < 8) {
+#pragma unroll
+    for (int i = 0; i < NV; i++)
+      v[i] = ((lds[(0 * 8 + cq) * NV + i] + lds[(1 * 8 + cq) * NV + i]) + lds[(2 * 8 + cq) * NV + i]) +
+             lds[(3 * 8 + cq) * NV + i];
+  }
+}
+
+__device__ __forceinline__ void write_stat_partial(float *part, int p, int C, int c, f32x4 s1, f32x4 s2) {
+  // part [P][C][2]
+  float *d = part + ((size_t)p * C + c) * 2;
+  d[0] = s1.x; d[1] = s2.x; d[2] = s1.y; d[3] = s2.y;
+  d[4] = s1.z; d[5] = s2.z; d[6] = s1.w; d[7] = s2.w;
+}
+
+// ======================================================================================
+// march forward: grid (nslab*nxseg, nphase*nchunk, N), block 256
+// ======================================================================================
+__global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x, const float *__restrict__ sc,
+                                                    const float *__restrict__ sh, int act,
+                                                    const float *__restrict__ w, float *__restrict__ y,
+                                                    int H, int W, int C, int r, int nchunk, int TK, int nxseg,
+                                                    float *__restrict__ part) {
+  __shared__ float red[4 * 8 * 8];
+  const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
+  const int xs = blockIdx.x % nxseg, slab = blockIdx.x / nxseg;
+  const int pc = blockIdx.y, n = blockIdx.z;
+  const int a = pc / nchunk, ch = pc % nchunk;
+  const int c = slab * 32 + cq * 4;
+  const int xx = xs * 32 + pl;
+  const bool active = (c < C) && (xx < W);
+  const int Ka = (a < H) ? (H - a + r - 1) / r : 0;
+  const int k0 = ch * TK;
+  const int k1 = min(k0 + TK, Ka);
+
+  f32x4 wv[9], s = splat4(1.f), t = splat4(0.f);
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) wv[i] = ld4(w + (size_t)i * C + c);
+    if (sc) { s = ld4(sc + c); t = ld4(sh + c); }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 9; i++) wv[i] = splat4(0.f);
+  }
+  const bool xl_ok = (xx - r >= 0), xr_ok = (xx + r < W);
+  const float *xbase = x + ((size_t)n * H * W) * C + c;
+  float *ybase = y + ((size_t)n * H * W) * C + c;
+
+  auto ldrow = [&](int k, f32x4 &l, f32x4 &m, f32x4 &rr) {
+    l = m = rr = splat4(0.f);
+    if (active && k >= 0 && k < Ka) {
+      const float *row = xbase + (size_t)(a + k * r) * W * C;
+      m = dl3_act4(s * ld4(row + (size_t)xx * C) + t, act);
+      if (xl_ok) l = dl3_act4(s * ld4(row + (size_t)(xx - r) * C) + t, act);
+      if (xr_ok) rr = dl3_act4(s * ld4(row + (size_t)(xx + r) * C) + t, act);
+    }
+  };
+
+  f32x4 accA = splat4(0.f), accB = splat4(0.f), s1 = splat4(0.f), s2 = splat4(0.f);
+  f32x4 nl, nm, nr;
+  if (k0 < k1) {
+    ldrow(k0 - 1, nl, nm, nr);
+    for (int k = k0 - 1; k <= k1; ++k) {
+      f32x4 l = nl, m = nm, rr = nr;
+      if (k + 1 <= k1) ldrow(k + 1, nl, nm, nr);
+      // input row k feeds out[k+1] (tap row 0), out[k] (tap row 1), out[k-1] (tap row 2)
+      f32x4 h0 = wv[0] * l + wv[1] * m + wv[2] * rr;
+      f32x4 h1 = wv[3] * l + wv[4] * m + wv[5] * rr;
+      f32x4 h2 = wv[6] * l + wv[7] * m + wv[8] * rr;
+      f32x4 out = accA + h2;
+      if (active && k - 1 >= k0 && k - 1 < k1) {
+        st4(ybase + ((size_t)(a + (k - 1) * r) * W + xx) * C, out);
+        s1 += out;
+        s2 += out * out;
+      }
+      accA = accB + h1;
+      accB = h0;
+    }
+  }
+  if (part) {
+    float v[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
+    reduce_px<8>(v, red);
+    if (tid < 8 && c < C) {
+      const int p = (n * gridDim.y + pc) * nxseg + xs;
+      f32x4 r1 = {v[0], v[1], v[2], v[3]}, r2 = {v[4], v[5], v[6], v[7]};
+      write_stat_partial(part, p, C, c, r1, r2);
+    }
+  }
+}
+
+// ======================================================================================
+// march backward (fused bwd-data + bwd-weight): same decomposition as the forward
+// ======================================================================================
+__global__ __launch_bounds__(256) void dw_march_bwd(
+    const float *__restrict__ g, const float *__restrict__ yraw, const float *__restrict__ cA,
+    const float *__restrict__ cB, const float *__restrict__ cC, const float *__restrict__ x,
+    const float *__restrict__ sc, const float *__restrict__ sh, int act, const float *__restrict__ w,
+    float *__restrict__ dx, const float *__restrict__ dx_add, const float *__restrict__ xmean,
+    const float *__restrict__ xinvstd, float *__restrict__ dpart, float *__restrict__ wpart, int H, int W, int C,
+    int r, int nchunk, int TK, int nxseg) {
+  __shared__ float red[4 * 8 * 36];
+  const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
+  const int xs = blockIdx.x % nxseg, slab = blockIdx.x / nxseg;
+  const int pc = blockIdx.y, n = blockIdx.z;
+  const int a = pc / nchunk, ch = pc % nchunk;
+  const int c = slab * 32 + cq * 4;
+  const int xx = xs * 32 + pl;
+  const bool active = (c < C) && (xx < W);
+  const int Ka = (a < H) ? (H - a + r - 1) / r : 0;
+  const int k0 = ch * TK;
+  const int k1 = min(k0 + TK, Ka);
+
+  f32x4 wv[9], s = splat4(1.f), t = splat4(0.f);
+  f32x4 kA = splat4(1.f), kB = splat4(0.f), kC = splat4(0.f), mu = splat4(0.f), is = splat4(0.f);
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) wv[i] = ld4(w + (size_t)i * C + c);
+    if (sc) { s = ld4(sc + c); t = ld4(sh + c); }
+    if (cA) { kA = ld4(cA + c); kB = ld4(cB + c); kC = ld4(cC + c); }
+    if (dpart) { mu = ld4(xmean + c); is = ld4(xinvstd + c); }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 9; i++) wv[i] = splat4(0.f);
+  }
+  const bool two = (cA != nullptr);
+  const bool xl_ok = (xx - r >= 0), xr_ok = (xx + r < W);
+  const size_t img = ((size_t)n * H * W) * C + c;
+
+  auto ld_dd1 = [&](size_t off) -> f32x4 {
+    f32x4 gv = ld4(g + off);
+    if (two) return kA * gv + kB * ld4(yraw + off) + kC;
+    return gv;
+  };
+  auto ld_dd = [&](int k, f32x4 &l, f32x4 &m, f32x4 &rr) {
+    l = m = rr = splat4(0.f);
+    if (active && k >= 0 && k < Ka) {
+      const size_t row = img + (size_t)(a + k * r) * W * C;
+      m = ld_dd1(row + (size_t)xx * C);
+      if (xl_ok) l = ld_dd1(row + (size_t)(xx - r) * C);
+      if (xr_ok) rr = ld_dd1(row + (size_t)(xx + r) * C);
+    }
+  };
+  // forward input row k at own column: raw value and validity
+  auto ld_e = [&](int k, f32x4 &raw, bool &ok) {
+    ok = active && k >= 0 && k < Ka;
+    raw = splat4(0.f);
+    if (ok) raw = ld4(x + img + ((size_t)(a + k * r) * W + xx) * C);
+  };
+  auto eact = [&](f32x4 raw, bool ok) -> f32x4 {
+    return ok ? dl3_act4(s * raw + t, act) : splat4(0.f);
+  };
+
+  f32x4 dwv[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) dwv[i] = splat4(0.f);
+  f32x4 accA = splat4(0.f), accB = splat4(0.f), s1 = splat4(0.f), s2 = splat4(0.f);
+
+  if (k0 < k1) {
+    f32x4 nl, nm, nr, e_prev = splat4(0.f), e_cur, e_next;
+    bool ok_prev = false, ok_cur, ok_next;
+    ld_dd(k0 - 1, nl, nm, nr);
+    ld_e(k0 - 1, e_cur, ok_cur);
+    ld_e(k0, e_next, ok_next);
+    for (int k = k0 - 1; k <= k1; ++k) {
+      f32x4 l = nl, m = nm, rr = nr;
+      f32x4 e_nn;
+      bool ok_nn;
+      if (k + 1 <= k1) ld_dd(k + 1, nl, nm, nr);
+      ld_e(k + 2, e_nn, ok_nn);
+      if (k >= k0 && k < k1) {
+        // dW[i][j] += T(x)[k+i-1][x] * dY[k][x-(j-1)r] : j=0 -> right tap, j=2 -> left tap
+        f32x4 ea0 = eact(e_prev, ok_prev), ea1 = eact(e_cur, ok_cur), ea2 = eact(e_next, ok_next);
+        dwv[0] += ea0 * rr; dwv[1] += ea0 * m; dwv[2] += ea0 * l;
+        dwv[3] += ea1 * rr; dwv[4] += ea1 * m; dwv[5] += ea1 * l;
+        dwv[6] += ea2 * rr; dwv[7] += ea2 * m; dwv[8] += ea2 * l;
+      }
+      // dY row k feeds dx[k-1] (tap row 0), dx[k] (tap row 1), dx[k+1] (tap row 2)
+      f32x4 h0 = wv[0] * rr + wv[1] * m + wv[2] * l;
+      f32x4 h1 = wv[3] * rr + wv[4] * m + wv[5] * l;
+      f32x4 h2 = wv[6] * rr + wv[7] * m + wv[8] * l;
+      f32x4 out = accA + h0;
+      if (dx && active && k - 1 >= k0 && k - 1 < k1) {
+        const size_t off = img + ((size_t)(a + (k - 1) * r) * W + xx) * C;
+        out = out * dl3_mask4(s * e_prev + t, act);
+        if (dx_add) out += ld4(dx_add + off);
+        st4(dx + off, out);
+        s1 += out;
+        s2 += out * ((e_prev - mu) * is);
+      }
+      accA = accB + h1;
+      accB = h2;
+      e_prev = e_cur; ok_prev = ok_cur;
+      e_cur = e_next; ok_cur = ok_next;
+      e_next = e_nn; ok_next = ok_nn;
+    }
+  }
+  const int p = (n * gridDim.y + pc) * nxseg + xs;
+  {
+    float v[36];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      v[i * 4 + 0] = dwv[i].x; v[i * 4 + 1] = dwv[i].y; v[i * 4 + 2] = dwv[i].z; v[i * 4 + 3] = dwv[i].w;
+    }
+    reduce_px<36>(v, red);
+    if (tid < 8 && c < C) {
+#pragma unroll
+      for (int i = 0; i < 9; i++) {
+        f32x4 o = {v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]};
+        st4(wpart + ((size_t)p * 9 + i) * C + c, o);
+      }
+    }
+  }
+  if (dpart) {
+    float v[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
+    reduce_px<8>(v, red);
+    if (tid < 8 && c < C) {
+      f32x4 r1 = {v[0], v[1], v[2], v[3]}, r2 = {v[4], v[5], v[6], v[7]};
+      write_stat_partial(dpart, p, C, c, r1, r2);
+    }
+  }
+}
+
+// ======================================================================================
+// gather forward: grid (nslab, PB), each block loops over output pixels
+// ======================================================================================
+__global__ __launch_bounds__(256) void dw_gather_fwd(const float *__restrict__ x, const float *__restrict__ sc,
+                                                     const float *__restrict__ sh, int act,
+                                                     const float *__restrict__ w, float *__restrict__ y, DwGeom G,
+                                                     float *__restrict__ part) {
+  __shared__ float red[4 * 8 * 8];
+  const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
+  const int c = blockIdx.x * 32 + cq * 4;
+  const bool cok = c < G.C;
+  f32x4 wv[9], s = splat4(1.f), t = splat4(0.f);
+#pragma unroll
+  for (int i = 0; i < 9; i++) wv[i] = cok ? ld4(w + (size_t)i * G.C + c) : splat4(0.f);
+  if (cok && sc) { s = ld4(sc + c); t = ld4(sh + c); }
+  f32x4 s1 = splat4(0.f), s2 = splat4(0.f);
+  const long NP = (long)G.N * G.Ho * G.Wo;
+  for (long p = (long)blockIdx.y * 32 + pl; p < NP && cok; p += (long)gridDim.y * 32) {
+    const int ox = (int)(p % G.Wo);
+    const int oy = (int)((p / G.Wo) % G.Ho);
+    const int n = (int)(p / ((long)G.Wo * G.Ho));
+    f32x4 acc = splat4(0.f);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int iy = oy * G.stride - G.pad_t + i * G.rate;
+      if (iy < 0 || iy >= G.H) continue;
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int ix = ox * G.stride - G.pad_l + j * G.rate;
+        if (ix < 0 || ix >= G.W) continue;
+        f32x4 v = ld4(x + (((size_t)n * G.H + iy) * G.W + ix) * G.C + c);
+        acc += wv[i * 3 + j] * dl3_act4(s * v + t, act);
+      }
+    }
+    st4(y + (size_t)p * G.C + c, acc);
+    s1 += acc;
+    s2 += acc * acc;
+  }
+  if (part) {
+    float v[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
+    reduce_px<8>(v, red);
+    if (tid < 8 && cok) {
+      f32x4 r1 = {v[0], v[1], v[2], v[3]}, r2 = {v[4], v[5], v[6], v[7]};
+      write_stat_partial(part, blockIdx.y, G.C, c, r1, r2);
+    }
+  }
+}
+
+// ======================================================================================
+// gather backward: loops over INPUT pixels; each (input pixel, tap) pair maps to one output
+// pixel and feeds both dx (x w) and dW (x T(x))
+// ======================================================================================
+__global__ __launch_bounds__(256) void dw_gather_bwd(
+    const float *__restrict__ g, const float *__restrict__ yraw, const float *__restrict__ cA,
+    const float *__restrict__ cB, const float *__restrict__ cC, const float *__restrict__ x,
+    const float *__restrict__ sc, const float *__restrict__ sh, int act, const float *__restrict__ w,
+    float *__restrict__ dx, const float *__restrict__ dx_add, const float *__restrict__ xmean,
+    const float *__restrict__ xinvstd, float *__restrict__ dpart, float *__restrict__ wpart, DwGeom G) {
+  __shared__ float red[4 * 8 * 36];
+  const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
+  const int c = blockIdx.x * 32 + cq * 4;
+  const bool cok = c < G.C;
+  f32x4 wv[9], s = splat4(1.f), t = splat4(0.f);
+  f32x4 kA = splat4(1.f), kB = splat4(0.f), kC = splat4(0.f), mu = splat4(0.f), is = splat4(0.f);
+#pragma unroll
+  for (int i = 0; i < 9; i++) wv[i] = cok ? ld4(w + (size_t)i * G.C + c) : splat4(0.f);
+  if (cok) {
+    if (sc) { s = ld4(sc + c); t = ld4(sh + c); }
+    if (cA) { kA = ld4(cA + c); kB = ld4(cB + c); kC = ld4(cC + c); }
+    if (dpart) { mu = ld4(xmean + c); is = ld4(xinvstd + c); }
+  }
+  const bool two = (cA != nullptr);
+  f32x4 dwv[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) dwv[i] = splat4(0.f);
+  f32x4 s1 = splat4(0.f), s2 = splat4(0.f);
+  const long NP = (long)G.N * G.H * G.W;
+  for (long p = (long)blockIdx.y * 32 + pl; p < NP && cok; p += (long)gridDim.y * 32) {
+    const int ix = (int)(p % G.W);
+    const int iy = (int)((p / G.W) % G.H);
+    const int n = (int)(p / ((long)G.W * G.H));
+    const f32x4 eraw = ld4(x + (size_t)p * G.C + c);
+    const f32x4 z = s * eraw + t;
+    const f32x4 ea = dl3_act4(z, act);
+    f32x4 acc = splat4(0.f);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int ty = iy + G.pad_t - i * G.rate;
+      if (ty < 0 || (ty % G.stride) != 0) continue;
+      const int oy = ty / G.stride;
+      if (oy >= G.Ho) continue;
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int tx = ix + G.pad_l - j * G.rate;
+        if (tx < 0 || (tx % G.stride) != 0) continue;
+        const int ox = tx / G.stride;
+        if (ox >= G.Wo) continue;
+        const size_t off = (((size_t)n * G.Ho + oy) * G.Wo + ox) * G.C + c;
+        f32x4 dd = ld4(g + off);
+        if (two) dd = kA * dd + kB * ld4(yraw + off) + kC;
+        acc += dd * wv[i * 3 + j];
+        dwv[i * 3 + j] += ea * dd;
+      }
+    }
+    if (dx) {
+      f32x4 out = acc * dl3_mask4(z, act);
+      if (dx_add) out += ld4(dx_add + (size_t)p * G.C + c);
+      st4(dx + (size_t)p * G.C + c, out);
+      s1 += out;
+      s2 += out * ((eraw - mu) * is);
+    }
+  }
+  {
+    float v[36];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      v[i * 4 + 0] = dwv[i].x; v[i * 4 + 1] = dwv[i].y; v[i * 4 + 2] = dwv[i].z; v[i * 4 + 3] = dwv[i].w;
+    }
+    reduce_px<36>(v, red);
+    if (tid < 8 && cok) {
+#pragma unroll
+      for (int i = 0; i < 9; i++) {
+        f32x4 o = {v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]};
+        st4(wpart + ((size_t)blockIdx.y * 9 + i) * G.C + c, o);
+      }
+    }
+  }
+  if (dpart) {
+    float v[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
+    reduce_px<8>(v, red);
+    if (tid < 8 && cok) {
+      f32x4 r1 = {v[0], v[1], v[2], v[3]}, r2 = {v[4], v[5], v[6], v[7]};
+      write_stat_partial(dpart, blockIdx.y, G.C, c, r1, r2);
+    }
+  }
+}
+
+// ---- host-side decomposition (shared by *_partials and the launchers) -------------------
+struct DwPlan {
+  int impl;                      // DL3_IMPL_MARCH / DL3_IMPL_GATHER
+  int nslab, nxseg, nphase, nchunk, TK;  // march
+  int PB;                        // gather
+  int P;
+};
+
+bool march_ok(int H, int W, int stride, int rate, int pad_t, int pad_l, int Ho, int Wo) {
+  return stride == 1 && pad_t == rate && pad_l == rate && Ho == H && Wo == W;
+}
+
+DwPlan dw_plan(int N, int H, int W, int C, int stride, int rate, int Ho, int Wo, int impl, bool bwd) {
+  DwPlan p{};
+  p.nslab = dl3_cdiv(C, 32);
+  p.impl = impl;
+  if (impl == DL3_IMPL_MARCH) {
+    p.nxseg = dl3_cdiv(W, 32);
+    p.nphase = rate < H ? rate : H;
+    const int Kmax = dl3_cdiv(H, rate);
+    // rows per block: as long as possible (halo re-read = 2/TK) while keeping >= ~2048 blocks
+    int TK = Kmax;
+    while (TK > 8 && (long)N * p.nslab * p.nxseg * p.nphase * dl3_cdiv(Kmax, TK) < 2048) TK = (TK + 1) / 2;
+    p.TK = TK;
+    p.nchunk = dl3_cdiv(Kmax, TK);
+    p.P = N * p.nphase * p.nchunk * p.nxseg;
+  } else {
+    const long NP = bwd ? (long)N * H * W : (long)N * Ho * Wo;
+    long pb = (NP + 31) / 32;
+    long cap = 4096 / p.nslab;
+    if (cap < 1) cap = 1;
+    if (pb > cap) pb = cap;
+    p.PB = (int)pb;
+    p.P = p.PB;
+  }
+  return p;
+}
+
+int resolve_impl(int impl, int H, int W, int stride, int rate, int pad_t, int pad_l, int Ho, int Wo) {
+  const bool ok = march_ok(H, W, stride, rate, pad_t, pad_l, Ho, Wo);
+  if (impl == DL3_IMPL_AUTO) return ok ? DL3_IMPL_MARCH : DL3_IMPL_GATHER;
+  if (impl == DL3_IMPL_MARCH && !ok) return -1;
+  return impl;
+}
+
+}  // namespace
+
+extern "C" int dl3_dwconv3x3_partials(int N, int H, int W, int C, int stride, int rate, int Ho, int Wo,
+                                      int impl) {
+  // pads are implied: march needs SAME stride-1 geometry, which the caller guarantees when it asks for it
+  int im = impl;
+  if (im == DL3_IMPL_AUTO) im = (stride == 1 && Ho == H && Wo == W) ? DL3_IMPL_MARCH : DL3_IMPL_GATHER;
+  // fwd and bwd gather plans differ in pixel count; report the larger so one buffer fits both
+  DwPlan a = dw_plan(N, H, W, C, stride, rate, Ho, Wo, im, false);
+  DwPlan b = dw_plan(N, H, W, C, stride, rate, Ho, Wo, im, true);
+  return a.P > b.P ? a.P : b.P;
+}
+
+static int dw_check(int N, int H, int W, int C, int stride, int rate, int Ho, int Wo) {
+  DL3_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0, "dwconv3x3: non-positive dimension");
+  DL3_CHECK_ARG(stride >= 1 && rate >= 1, "dwconv3x3: stride/rate must be >= 1");
+  DL3_UNSUPPORTED(C % 4 != 0, "dwconv3x3: C=%d must be a multiple of 4", C);
+  DL3_UNSUPPORTED(N > 65535, "dwconv3x3: N=%d too large for grid.z", N);
+  return DL3_OK;
+}
+
+extern "C" int dl3_dwconv3x3_fwd(const float *x, const float *in_scale, const float *in_shift, int in_act,
+                                 const float *w, float *y, int N, int H, int W, int C, int stride, int rate,
+                                 int pad_t, int pad_l, int Ho, int Wo, float *stat_partial, int impl,
+                                 void *stream) {
+  int rc = dw_check(N, H, W, C, stride, rate, Ho, Wo);
+  if (rc) return rc;
+  DL3_CHECK_ARG(x && w && y, "dwconv3x3_fwd: null pointer");
+  DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "dwconv3x3_fwd: scale/shift must come together");
+  const int im = resolve_impl(impl, H, W, stride, rate, pad_t, pad_l, Ho, Wo);
+  DL3_UNSUPPORTED(im < 0, "dwconv3x3_fwd: march impl needs stride 1, pad == rate, Ho == H, Wo == W");
+  DwPlan p = dw_plan(N, H, W, C, stride, rate, Ho, Wo, im, false);
+  hipStream_t st = (hipStream_t)stream;
+  if (im == DL3_IMPL_MARCH) {
+    dim3 grid(p.nslab * p.nxseg, p.nphase * p.nchunk, N);
+    hipLaunchKernelGGL(dw_march_fwd, grid, dim3(256), 0, st, x, in_scale, in_shift, in_act, w, y, H, W, C, rate,
+                       p.nchunk, p.TK, p.nxseg, stat_partial);
+  } else {
+    DwGeom G{N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo};
+    dim3 grid(p.nslab, p.PB);
+    hipLaunchKernelGGL(dw_gather_fwd, grid, dim3(256), 0, st, x, in_scale, in_shift, in_act, w, y, G,
+                       stat_partial);
+    // gather fwd writes PB partial rows; pad the rest (caller sized the buffer with *_partials)
+    const int Pmax = dl3_dwconv3x3_partials(N, H, W, C, stride, rate, Ho, Wo, im);
+    if (stat_partial && Pmax > p.P)
+      (void)hipMemsetAsync(stat_partial + (size_t)p.P * C * 2, 0, (size_t)(Pmax - p.P) * C * 2 * sizeof(float), st);
+  }
+  DL3_LAUNCH_CHECK("dwconv3x3_fwd");
+  return DL3_OK;
+}
+
+extern "C" int dl3_dwconv3x3_bwd(const float *g, const float *yraw, const float *cA, const float *cB,
+                                 const float *cC, const float *x, const float *in_scale, const float *in_shift,
+                                 int in_act, const float *w, float *dx, const float *dx_add,
+                                 const float *x_mean, const float *x_invstd, float *dstat_partial,
+                                 float *dw_partial, int N, int H, int W, int C, int stride, int rate, int pad_t,
+                                 int pad_l, int Ho, int Wo, int impl, void *stream) {
+  int rc = dw_check(N, H, W, C, stride, rate, Ho, Wo);
+  if (rc) return rc;
+  DL3_CHECK_ARG(g && x && w && dw_partial, "dwconv3x3_bwd: null pointer");
+  DL3_CHECK_ARG(!cA || (yraw && cB && cC), "dwconv3x3_bwd: cA needs yraw, cB, cC");
+  DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "dwconv3x3_bwd: scale/shift must come together");
+  DL3_CHECK_ARG(!dstat_partial || (dx && x_mean && x_invstd), "dwconv3x3_bwd: dstat needs dx, x_mean, x_invstd");
+  const int im = resolve_impl(impl, H, W, stride, rate, pad_t, pad_l, Ho, Wo);
+  DL3_UNSUPPORTED(im < 0, "dwconv3x3_bwd: march impl needs stride 1, pad == rate, Ho == H, Wo == W");
+  DwPlan p = dw_plan(N, H, W, C, stride, rate, Ho, Wo, im, true);
+  hipStream_t st = (hipStream_t)stream;
+  if (im == DL3_IMPL_MARCH) {
+    dim3 grid(p.nslab * p.nxseg, p.nphase * p.nchunk, N);
+    hipLaunchKernelGGL(dw_march_bwd, grid, dim3(256), 0, st, g, yraw, cA, cB, cC, x, in_scale, in_shift, in_act,
+                       w, dx, dx_add, x_mean, x_invstd, dstat_partial, dw_partial, H, W, C, rate, p.nchunk, p.TK,
+                       p.nxseg);
+  } else {
+    DwGeom G{N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo};
+    dim3 grid(p.nslab, p.PB);
+    hipLaunchKernelGGL(dw_gather_bwd, grid, dim3(256), 0, st, g, yraw, cA, cB, cC, x, in_scale, in_shift, in_act,
+                       w, dx, dx_add, x_mean, x_invstd, dstat_partial, dw_partial, G);
+    const int Pmax = dl3_dwconv3x3_partials(N, H, W, C, stride, rate, Ho, Wo, im);
+    if (Pmax > p.P) {
+      (void)hipMemsetAsync(dw_partial + (size_t)p.P * 9 * C, 0, (size_t)(Pmax - p.P) * 9 * C * sizeof(float), st);
+      if (dstat_partial)
+        (void)hipMemsetAsync(dstat_partial + (size_t)p.P * C * 2, 0, (size_t)(Pmax - p.P) * C * 2 * sizeof(float), st);
+    }
+  }
+  DL3_LAUNCH_CHECK("dwconv3x3_bwd");
+  return DL3_OK;
+}

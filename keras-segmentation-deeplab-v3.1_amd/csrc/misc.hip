@@ -1,0 +1,266 @@
+// misc.hip — the tail of the DeepLabV3+ path: TF1-legacy bilinear resize (deeplabv3p.py:382,:418,
+// :439; utils.py:190), Subpixel phase shift (subpixel.py:77-88), softmax (deeplabv3p.py:441,:444),
+// sparse_crossentropy_ignoring_last_label with temporal sample weights (utils.py:127-130) and argmax.
+// All HBM-bound, one pass each; backward kernels are gather-form (no atomics, deterministic).
+#include "common.h"
+
+namespace {
+
+// tf.image.resize_bilinear(align_corners=False) of TF 1.x: src = dst * (in/out), no half-pixel
+// offset; lower = floor(src), upper = min(lower+1, in-1), lerp = src - lower.
+struct Lerp {
+  int lo, hi;
+  float w;
+};
+__device__ __forceinline__ Lerp tf1_lerp(int o, float scale, int in_size) {
+  const float f = (float)o * scale;
+  Lerp r;
+  r.lo = (int)floorf(f);
+  if (r.lo > in_size - 1) r.lo = in_size - 1;
+  r.hi = min(r.lo + 1, in_size - 1);
+  r.w = f - (float)r.lo;
+  return r;
+}
+
+__global__ __launch_bounds__(256) void resize_fwd_kernel(const float *__restrict__ x, int ldx,
+                                                         const float *__restrict__ sc,
+                                                         const float *__restrict__ sh, int act,
+                                                         float *__restrict__ y, int ldy, int N, int Hi, int Wi,
+                                                         int Ho, int Wo, int C, float sy, float sx) {
+  const long total = (long)N * Ho * Wo * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long p = i / C;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const Lerp ly = tf1_lerp(oy, sy, Hi), lx = tf1_lerp(ox, sx, Wi);
+    float es = 1.f, et = 0.f;
+    if (sc) { es = sc[c]; et = sh[c]; }
+    const float *b = x + (size_t)n * Hi * Wi * ldx + c;
+    const float tl = dl3_act(es * b[((size_t)ly.lo * Wi + lx.lo) * ldx] + et, act);
+    const float tr = dl3_act(es * b[((size_t)ly.lo * Wi + lx.hi) * ldx] + et, act);
+    const float bl = dl3_act(es * b[((size_t)ly.hi * Wi + lx.lo) * ldx] + et, act);
+    const float br = dl3_act(es * b[((size_t)ly.hi * Wi + lx.hi) * ldx] + et, act);
+    const float top = tl + (tr - tl) * lx.w;
+    const float bot = bl + (br - bl) * lx.w;
+    y[(((size_t)n * Ho + oy) * Wo + ox) * ldy + c] = top + (bot - top) * ly.w;
+  }
+}
+
+// gather form of the transpose: input pixel (iy,ix) collects from every output pixel whose
+// lower/upper source index hits it; weights are recomputed with the forward formula.
+__global__ __launch_bounds__(256) void resize_bwd_kernel(const float *__restrict__ dy, int lddy,
+                                                         float *__restrict__ dx, int lddx, int N, int Hi, int Wi,
+                                                         int Ho, int Wo, int C, float sy, float sx, int accumulate) {
+  const long total = (long)N * Hi * Wi * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long p = i / C;
+    const int ix = (int)(p % Wi);
+    p /= Wi;
+    const int iy = (int)(p % Hi);
+    const int n = (int)(p / Hi);
+    // candidate output rows: those with floor(oy*sy) in {iy-1, iy} (+1 slack each side for rounding)
+    int oy0 = (int)floorf((float)(iy - 1) / sy) - 1, oy1 = (int)ceilf((float)(iy + 1) / sy) + 1;
+    int ox0 = (int)floorf((float)(ix - 1) / sx) - 1, ox1 = (int)ceilf((float)(ix + 1) / sx) + 1;
+    oy0 = max(oy0, 0); oy1 = min(oy1, Ho - 1);
+    ox0 = max(ox0, 0); ox1 = min(ox1, Wo - 1);
+    float acc = 0.f;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+      const Lerp ly = tf1_lerp(oy, sy, Hi);
+      const float wy = (ly.lo == iy ? 1.f - ly.w : 0.f) + (ly.hi == iy ? ly.w : 0.f);
+      if (wy == 0.f) continue;
+      float racc = 0.f;
+      for (int ox = ox0; ox <= ox1; ++ox) {
+        const Lerp lx = tf1_lerp(ox, sx, Wi);
+        const float wx = (lx.lo == ix ? 1.f - lx.w : 0.f) + (lx.hi == ix ? lx.w : 0.f);
+        if (wx != 0.f) racc += wx * dy[(((size_t)n * Ho + oy) * Wo + ox) * lddy + c];
+      }
+      acc += wy * racc;
+    }
+    float *o = dx + (((size_t)n * Hi + iy) * Wi + ix) * lddx + c;
+    *o = accumulate ? (*o + acc) : acc;
+  }
+}
+
+// out[n, ia*r+q, ib*r+p, ch] = in[n, ia, ib, ch*r*r + p*r + q]   (subpixel.py:81-87)
+__global__ __launch_bounds__(256) void phase_shift_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                          int N, int H, int W, int Cout, int r, int inverse) {
+  const long total = (long)N * H * W * Cout * r * r;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    // i indexes the shuffled tensor [N, H*r, W*r, Cout]
+    const int ch = (int)(i % Cout);
+    long p = i / Cout;
+    const int X = (int)(p % ((long)W * r));
+    p /= (long)W * r;
+    const int Y = (int)(p % ((long)H * r));
+    const int n = (int)(p / ((long)H * r));
+    const int ia = Y / r, q = Y % r, ib = X / r, pp = X % r;
+    const size_t j = (((size_t)n * H + ia) * W + ib) * ((size_t)Cout * r * r) + (size_t)ch * r * r + pp * r + q;
+    if (inverse) out[j] = in[i];
+    else out[i] = in[j];
+  }
+}
+
+__global__ __launch_bounds__(256) void softmax_kernel(const float *__restrict__ x, float *__restrict__ p, long M,
+                                                      int C) {
+  for (long m = (long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long)gridDim.x * 256) {
+    const float *r = x + (size_t)m * C;
+    float mx = r[0];
+    for (int c = 1; c < C; c++) mx = fmaxf(mx, r[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; c++) s += expf(r[c] - mx);
+    const float inv = 1.f / s;
+    for (int c = 0; c < C; c++) p[(size_t)m * C + c] = expf(r[c] - mx) * inv;
+  }
+}
+
+__global__ __launch_bounds__(256) void argmax_kernel(const float *__restrict__ x, int *__restrict__ out, long M,
+                                                     int C) {
+  for (long m = (long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long)gridDim.x * 256) {
+    const float *r = x + (size_t)m * C;
+    float mx = r[0];
+    int am = 0;
+    for (int c = 1; c < C; c++)
+      if (r[c] > mx) { mx = r[c]; am = c; }
+    out[m] = am;
+  }
+}
+
+__global__ __launch_bounds__(256) void count_nz_kernel(const float *__restrict__ w, long M, unsigned int *cnt) {
+  __shared__ unsigned int red[4];
+  unsigned int c = 0;
+  for (long m = (long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long)gridDim.x * 256) c += (w[m] != 0.f);
+  // integer adds commute: the atomic result is order-independent (deterministic)
+  for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(cnt, red[0] + red[1] + red[2] + red[3]);
+}
+__global__ void count_to_float_kernel(unsigned int *cnt) {
+  const unsigned int v = *cnt;
+  *reinterpret_cast<float *>(cnt) = (float)v;
+}
+
+// loss_partial[blockIdx.x] = sum over the block's rows of w*(-log clip(p_label));
+// dlogits = (p - onehot) * w / nnz ; label == C (void) -> onehot = 0 and, by the generator's
+// contract (utils.py:388-399), w = 0.
+__global__ __launch_bounds__(256) void softmax_xent_kernel(const float *__restrict__ x,
+                                                           const float *__restrict__ labels,
+                                                           const float *__restrict__ weights,
+                                                           const float *__restrict__ nnz, float *__restrict__ probs,
+                                                           float *__restrict__ dl, float *__restrict__ loss_part,
+                                                           long M, int C) {
+  __shared__ float red[4];
+  const float inv_nnz = 1.f / fmaxf(*nnz, 1.f);
+  float lsum = 0.f;
+  for (long m = (long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long)gridDim.x * 256) {
+    const float *r = x + (size_t)m * C;
+    float mx = r[0];
+    for (int c = 1; c < C; c++) mx = fmaxf(mx, r[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; c++) s += expf(r[c] - mx);
+    const float inv = 1.f / s;
+    const int t = (int)labels[m];
+    const float w = weights ? weights[m] : 1.f;
+    float psum = 0.f, pt = 0.f;
+    for (int c = 0; c < C; c++) {
+      const float pc = expf(r[c] - mx) * inv;
+      psum += pc;
+      if (c == t) pt = pc;
+      if (probs) probs[(size_t)m * C + c] = pc;
+      if (dl) dl[(size_t)m * C + c] = (pc - (c == t ? 1.f : 0.f)) * w * inv_nnz;
+    }
+    if (t >= 0 && t < C) {
+      // Keras categorical_crossentropy on probabilities: renormalise, clip to [1e-7, 1-1e-7], -log
+      float q = pt / psum;
+      q = fminf(fmaxf(q, 1e-7f), 1.f - 1e-7f);
+      lsum += -logf(q) * w;
+    }
+  }
+  lsum = wave_sum(lsum);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) loss_part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+inline int ew_blocks(size_t n) {
+  size_t b = (n + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int dl3_resize_bilinear_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift,
+                                       int in_act, float *y, int ldy, int N, int Hi, int Wi, int Ho, int Wo, int C,
+                                       void *stream) {
+  DL3_CHECK_ARG(x && y && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "resize_fwd: bad argument");
+  DL3_CHECK_ARG(ldx >= C && ldy >= C, "resize_fwd: leading dimension too small");
+  DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "resize_fwd: scale/shift must come together");
+  const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+  hipLaunchKernelGGL(resize_fwd_kernel, dim3(ew_blocks((size_t)N * Ho * Wo * C)), dim3(256), 0,
+                     (hipStream_t)stream, x, ldx, in_scale, in_shift, in_act, y, ldy, N, Hi, Wi, Ho, Wo, C, sy, sx);
+  DL3_LAUNCH_CHECK("resize_fwd");
+  return DL3_OK;
+}
+
+extern "C" int dl3_resize_bilinear_bwd(const float *dy, int lddy, float *dx, int lddx, int N, int Hi, int Wi,
+                                       int Ho, int Wo, int C, int accumulate, void *stream) {
+  DL3_CHECK_ARG(dy && dx && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "resize_bwd: bad argument");
+  DL3_CHECK_ARG(lddy >= C && lddx >= C, "resize_bwd: leading dimension too small");
+  const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+  hipLaunchKernelGGL(resize_bwd_kernel, dim3(ew_blocks((size_t)N * Hi * Wi * C)), dim3(256), 0,
+                     (hipStream_t)stream, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, sy, sx, accumulate);
+  DL3_LAUNCH_CHECK("resize_bwd");
+  return DL3_OK;
+}
+
+extern "C" int dl3_phase_shift(const float *in, float *out, int N, int H, int W, int Cout, int r, int inverse,
+                               void *stream) {
+  DL3_CHECK_ARG(in && out && N > 0 && H > 0 && W > 0 && Cout > 0 && r > 0, "phase_shift: bad argument");
+  hipLaunchKernelGGL(phase_shift_kernel, dim3(ew_blocks((size_t)N * H * W * Cout * r * r)), dim3(256), 0,
+                     (hipStream_t)stream, in, out, N, H, W, Cout, r, inverse);
+  DL3_LAUNCH_CHECK("phase_shift");
+  return DL3_OK;
+}
+
+extern "C" int dl3_softmax_fwd(const float *logits, float *probs, int M, int C, void *stream) {
+  DL3_CHECK_ARG(logits && probs && M > 0 && C > 0, "softmax_fwd: bad argument");
+  hipLaunchKernelGGL(softmax_kernel, dim3(ew_blocks((size_t)M)), dim3(256), 0, (hipStream_t)stream, logits, probs,
+                     (long)M, C);
+  DL3_LAUNCH_CHECK("softmax_fwd");
+  return DL3_OK;
+}
+
+extern "C" int dl3_argmax(const float *x, int *out, int M, int C, void *stream) {
+  DL3_CHECK_ARG(x && out && M > 0 && C > 0, "argmax: bad argument");
+  hipLaunchKernelGGL(argmax_kernel, dim3(ew_blocks((size_t)M)), dim3(256), 0, (hipStream_t)stream, x, out, (long)M,
+                     C);
+  DL3_LAUNCH_CHECK("argmax");
+  return DL3_OK;
+}
+
+extern "C" int dl3_count_nonzero(const float *w, int M, float *out, void *stream) {
+  DL3_CHECK_ARG(w && out && M > 0, "count_nonzero: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(out, 0, sizeof(float), st);
+  int blocks = ew_blocks((size_t)M);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(count_nz_kernel, dim3(blocks), dim3(256), 0, st, w, (long)M, (unsigned int *)out);
+  hipLaunchKernelGGL(count_to_float_kernel, dim3(1), dim3(1), 0, st, (unsigned int *)out);
+  DL3_LAUNCH_CHECK("count_nonzero");
+  return DL3_OK;
+}
+
+extern "C" int dl3_softmax_xent(const float *logits, const float *labels, const float *weights, const float *nnz,
+                                float *probs, float *dlogits, float *loss_partial, int M, int C, void *stream) {
+  DL3_CHECK_ARG(logits && labels && nnz && loss_partial && M > 0 && C > 0, "softmax_xent: bad argument");
+  hipLaunchKernelGGL(softmax_xent_kernel, dim3(dl3_rows_partials(M)), dim3(256), 0, (hipStream_t)stream, logits,
+                     labels, weights, nnz, probs, dlogits, loss_partial, (long)M, C);
+  DL3_LAUNCH_CHECK("softmax_xent");
+  return DL3_OK;
+}

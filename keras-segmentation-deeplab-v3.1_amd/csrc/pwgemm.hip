@@ -1,0 +1,702 @@
+// pwgemm.hip — Conv2D 1x1 as fp32 GEMM on the CDNA4 matrix cores
+// (deeplabv3p.py:78-79,:175,:194,:377,:385,:406,:420,:438; utils.py:189,:195).
+//
+// v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).  One kernel family serves
+//   forward   Y[M,N]  = T(X)[M,K] . W[K,N]            (prologue: BN+ReLU6 of the producer on load,
+//                                                      epilogue: bias, BN batch-stat partials)
+//   bwd-data  dX[M,K] = dY[M,N] . W^T[N,K]            (prologue: BN-backward affine of two tensors on
+//                                                      load, epilogue: activation mask, residual
+//                                                      gradient add, BN-backward stat partials)
+// and a second one the weight gradient dW[K,N] = T(X)^T . dY (reduction over M = N*H*W, split
+// over workgroups, folded deterministically).
+//
+// Fragment layouts (cdna_hip_programming.md §3): A lane l holds A[i=l&31][k=l>>5], B lane l holds
+// B[k=l>>5][j=l&31]; C/D reg r of lane l is row (r&3)+8*(r>>2)+4*(l>>5), column l&31.
+// LDS tiles are k-major (As[k][m], Bs[k][n]) so fragment reads are 32 consecutive floats per
+// half-wave: conflict-free ds_read_b32.
+#include "common.h"
+
+namespace {
+
+struct GemmArgs {
+  const float *a; int lda;
+  const float *a2; int lda2;
+  const float *ka, *kb, *kc; int a_act;
+  const float *b; int ldb;
+  const float *bias;
+  float *c; int ldc;
+  int M, K, N;
+  const float *ep_x; int ld_epx;
+  const float *ep_scale, *ep_shift; int ep_act;
+  const float *ep_add; int ld_add; int add_div; float add_scale;
+  int stat_mode;  // 0 none, 1: sum c, sum c^2 ; 2: sum c, sum c*xhat
+  const float *ep_mean, *ep_invstd;
+  float *part;
+  int mtiles;
+};
+
+constexpr int BK = 16;
+
+template <int TM, int TN, int WM, int WN, bool AVEC, bool BVEC>
+__global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs P) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+  constexpr int LDA = BM + 2;  // 4*LDA == 8 (mod 32): transposed 4-float stores hit distinct banks
+  constexpr int LDB = BN + 4;
+  constexpr int NA = BM / 64;                   // float4 A loads per thread per K-tile
+  constexpr int NB = (4 * BN + 255) / 256;      // float4 B loads per thread per K-tile
+  __shared__ float lds[BK * LDA + BK * LDB];
+  float *As = lds, *Bs = lds + BK * LDA;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int n0 = blockIdx.x * BN;
+  const int akq = tid & 3, amr = tid >> 2;
+  const int ktiles = (P.K + BK - 1) / BK;
+  const bool xform = (P.ka != nullptr);
+  const bool two = (P.a2 != nullptr);
+
+  float st1[TN], st2[TN];
+#pragma unroll
+  for (int i = 0; i < TN; i++) st1[i] = st2[i] = 0.f;
+
+  for (int mt = blockIdx.y; mt < P.mtiles; mt += gridDim.y) {
+    const int m0 = mt * BM;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    f32x4 ra[NA], ra2[NA], rb[NB];
+
+    auto load_tiles = [&](int kt) {
+      const int k = kt * BK + akq * 4;
+#pragma unroll
+      for (int i = 0; i < NA; i++) {
+        const int row = m0 + amr + 64 * i;
+        ra[i] = splat4(0.f);
+        ra2[i] = splat4(0.f);
+        if (row < P.M) {
+          if (AVEC) {
+            if (k < P.K) {
+              ra[i] = ld4(P.a + (size_t)row * P.lda + k);
+              if (two) ra2[i] = ld4(P.a2 + (size_t)row * P.lda2 + k);
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+              if (k + j < P.K) {
+                ra[i][j] = P.a[(size_t)row * P.lda + k + j];
+                if (two) ra2[i][j] = P.a2[(size_t)row * P.lda2 + k + j];
+              }
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NB; i++) {
+        const int idx = tid + 256 * i;
+        rb[i] = splat4(0.f);
+        if (idx < 4 * BN) {
+          const int kk = idx / (BN / 4), nq = idx % (BN / 4);
+          const int krow = kt * BK + kk, col = n0 + nq * 4;
+          if (krow < P.K) {
+            if (BVEC) {
+              if (col < P.N) rb[i] = ld4(P.b + (size_t)krow * P.ldb + col);
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; j++)
+                if (col + j < P.N) rb[i][j] = P.b[(size_t)krow * P.ldb + col + j];
+            }
+          }
+        }
+      }
+    };
+
+    auto store_tiles = [&](int kt) {
+      const int k = kt * BK + akq * 4;
+      f32x4 fa = splat4(1.f), fb = splat4(0.f), fc = splat4(0.f);
+      bool kok[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) kok[j] = (k + j < P.K);
+      if (xform) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (kok[j]) {
+            fa[j] = P.ka[k + j];
+            fc[j] = P.kc[k + j];
+            if (two) fb[j] = P.kb[k + j];
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < NA; i++) {
+        const int row = m0 + amr + 64 * i;
+        f32x4 v = ra[i];
+        if (xform) {
+          v = fa * v + fc;
+          if (two) v += fb * ra2[i];
+        }
+        v = dl3_act4(v, P.a_act);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float o = (row < P.M && kok[j]) ? v[j] : 0.f;
+          As[(akq * 4 + j) * LDA + amr + 64 * i] = o;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NB; i++) {
+        const int idx = tid + 256 * i;
+        if (idx < 4 * BN) {
+          const int kk = idx / (BN / 4), nq = idx % (BN / 4);
+          st4(&Bs[kk * LDB + nq * 4], rb[i]);
+        }
+      }
+    };
+
+    load_tiles(0);
+    __syncthreads();  // previous tile's (or previous m-tile's) LDS reads are done
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; ++kt) {
+      if (kt + 1 < ktiles) load_tiles(kt + 1);
+#pragma unroll
+      for (int ks = 0; ks < BK / 2; ++ks) {
+        float af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) af[i] = As[(2 * ks + lhi) * LDA + (wm * TM + i) * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < TN; j++) bf[j] = Bs[(2 * ks + lhi) * LDB + (wn * TN + j) * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+      if (kt + 1 < ktiles) {
+        __syncthreads();
+        store_tiles(kt + 1);
+        __syncthreads();
+      }
+    }
+
+    // ---------------- epilogue
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const int col = n0 + (wn * TN + j) * 32 + l31;
+      const bool cok = col < P.N;
+      float bias = 0.f, es = 1.f, et = 0.f, mu = 0.f, is = 0.f;
+      if (cok) {
+        if (P.bias) bias = P.bias[col];
+        if (P.ep_scale) { es = P.ep_scale[col]; et = P.ep_shift[col]; }
+        if (P.stat_mode == 2) { mu = P.ep_mean[col]; is = P.ep_invstd[col]; }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          if (cok && row < P.M) {
+            float v = acc[i][j][r] + bias;
+            float xr = 0.f;
+            if (P.ep_x) {
+              xr = P.ep_x[(size_t)row * P.ld_epx + col];
+              v *= dl3_act_mask(es * xr + et, P.ep_act);
+            }
+            if (P.ep_add) {
+              const int arow = (P.add_div > 1) ? row / P.add_div : row;
+              v += P.add_scale * P.ep_add[(size_t)arow * P.ld_add + col];
+            }
+            P.c[(size_t)row * P.ldc + col] = v;
+            if (P.stat_mode == 1) {
+              st1[j] += v;
+              st2[j] += v * v;
+            } else if (P.stat_mode == 2) {
+              st1[j] += v;
+              st2[j] += v * ((xr - mu) * is);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (P.stat_mode != 0) {
+    // fold the two half-waves (same column), then the WM waves that share columns
+    float *sred = lds;  // [WM][BN][2]
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      float a1 = st1[j] + __shfl_xor(st1[j], 32, 64);
+      float a2 = st2[j] + __shfl_xor(st2[j], 32, 64);
+      if (lhi == 0) {
+        const int cl = (wn * TN + j) * 32 + l31;
+        sred[(wm * BN + cl) * 2 + 0] = a1;
+        sred[(wm * BN + cl) * 2 + 1] = a2;
+      }
+    }
+    __syncthreads();
+    for (int cl = tid; cl < BN; cl += 256) {
+      const int col = n0 + cl;
+      if (col < P.N) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; w++) {
+          a1 += sred[(w * BN + cl) * 2 + 0];
+          a2 += sred[(w * BN + cl) * 2 + 1];
+        }
+        P.part[((size_t)blockIdx.y * P.N + col) * 2 + 0] = a1;
+        P.part[((size_t)blockIdx.y * P.N + col) * 2 + 1] = a2;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// weight gradient: dW[K,N] (+)= sum_m T(X)[m][k] * dY[m][n]; grid (ntn, ntk, S)
+// ---------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float *x; int ldx;
+  const float *xs, *xt; int x_act;
+  const float *g; int ldg;
+  const float *y; int ldy;
+  const float *cA, *cB, *cC;
+  float *ws;  // [S][K][N]
+  int M, K, N, Mper;
+};
+
+template <int TA, int TB, int WA, int WB, bool XVEC, bool DVEC>
+__global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs P) {
+  static_assert(WA * WB == 4, "4 waves per workgroup");
+  constexpr int BKT = 32 * TA * WA, BNT = 32 * TB * WB, MS = 16;
+  constexpr int LDX = BKT + 4, LDD = BNT + 4;
+  constexpr int NX = (4 * BKT + 255) / 256, ND = (4 * BNT + 255) / 256;
+  __shared__ float lds[MS * LDX + MS * LDD];
+  float *Xs = lds, *Ds = lds + MS * LDX;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wa = wave / WB, wb = wave % WB;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int kbase = blockIdx.y * BKT, nbase = blockIdx.x * BNT;
+  const int mbeg = blockIdx.z * P.Mper;
+  const int mend = min(P.M, mbeg + P.Mper);
+  const bool xform = (P.xs != nullptr);
+  const bool two = (P.cA != nullptr);
+
+  f32x16 acc[TA][TB];
+#pragma unroll
+  for (int i = 0; i < TA; i++)
+#pragma unroll
+    for (int j = 0; j < TB; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  f32x4 rx[NX], rg[ND], ry[ND];
+
+  auto load_tiles = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+      const int idx = tid + 256 * i;
+      rx[i] = splat4(0.f);
+      if (idx < 4 * BKT) {
+        const int mr = idx / (BKT / 4), kq = idx % (BKT / 4);
+        const int row = m0 + mr, k = kbase + kq * 4;
+        if (row < mend) {
+          if (XVEC) {
+            if (k < P.K) rx[i] = ld4(P.x + (size_t)row * P.ldx + k);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+              if (k + j < P.K) rx[i][j] = P.x[(size_t)row * P.ldx + k + j];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ND; i++) {
+      const int idx = tid + 256 * i;
+      rg[i] = splat4(0.f);
+      ry[i] = splat4(0.f);
+      if (idx < 4 * BNT) {
+        const int mr = idx / (BNT / 4), nq = idx % (BNT / 4);
+        const int row = m0 + mr, col = nbase + nq * 4;
+        if (row < mend) {
+          if (DVEC) {
+            if (col < P.N) {
+              rg[i] = ld4(P.g + (size_t)row * P.ldg + col);
+              if (two) ry[i] = ld4(P.y + (size_t)row * P.ldy + col);
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+              if (col + j < P.N) {
+                rg[i][j] = P.g[(size_t)row * P.ldg + col + j];
+                if (two) ry[i][j] = P.y[(size_t)row * P.ldy + col + j];
+              }
+          }
+        }
+      }
+    }
+  };
+
+  auto store_tiles = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+      const int idx = tid + 256 * i;
+      if (idx < 4 * BKT) {
+        const int mr = idx / (BKT / 4), kq = idx % (BKT / 4);
+        const int row = m0 + mr, k = kbase + kq * 4;
+        f32x4 v = rx[i];
+        if (xform) {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (k + j < P.K) v[j] = P.xs[k + j] * v[j] + P.xt[k + j];
+        }
+        v = dl3_act4(v, P.x_act);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (!(row < mend && k + j < P.K)) v[j] = 0.f;
+        st4(&Xs[mr * LDX + kq * 4], v);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ND; i++) {
+      const int idx = tid + 256 * i;
+      if (idx < 4 * BNT) {
+        const int mr = idx / (BNT / 4), nq = idx % (BNT / 4);
+        const int row = m0 + mr, col = nbase + nq * 4;
+        f32x4 v = rg[i];
+        if (two) {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (col + j < P.N) v[j] = P.cA[col + j] * v[j] + P.cB[col + j] * ry[i][j] + P.cC[col + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (!(row < mend && col + j < P.N)) v[j] = 0.f;
+        st4(&Ds[mr * LDD + nq * 4], v);
+      }
+    }
+  };
+
+  if (mbeg < mend) {
+    load_tiles(mbeg);
+    store_tiles(mbeg);
+    __syncthreads();
+    for (int m0 = mbeg; m0 < mend; m0 += MS) {
+      const bool more = (m0 + MS < mend);
+      if (more) load_tiles(m0 + MS);
+#pragma unroll
+      for (int ks = 0; ks < MS / 2; ++ks) {
+        float af[TA], bf[TB];
+#pragma unroll
+        for (int i = 0; i < TA; i++) af[i] = Xs[(2 * ks + lhi) * LDX + (wa * TA + i) * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < TB; j++) bf[j] = Ds[(2 * ks + lhi) * LDD + (wb * TB + j) * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < TA; i++)
+#pragma unroll
+          for (int j = 0; j < TB; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+      if (more) {
+        __syncthreads();
+        store_tiles(m0 + MS);
+        __syncthreads();
+      }
+    }
+  }
+  float *out = P.ws + (size_t)blockIdx.z * P.K * P.N;
+#pragma unroll
+  for (int i = 0; i < TA; i++)
+#pragma unroll
+    for (int j = 0; j < TB; j++) {
+      const int col = nbase + (wb * TB + j) * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int krow = kbase + (wa * TA + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (krow < P.K && col < P.N) out[(size_t)krow * P.N + col] = acc[i][j][r];
+      }
+    }
+}
+
+// column sums of dY over row ranges: partial [PR][N]; block = 64 columns x 4 row lanes
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ g, int ldg, int M, int N,
+                                                     float *__restrict__ part) {
+  __shared__ float red[256];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  float s = 0.f;
+  if (col < N)
+    for (long m = (long)blockIdx.y * 4 + rl; m < M; m += (long)gridDim.y * 4) s += g[(size_t)m * ldg + col];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && col < N)
+    part[(size_t)blockIdx.y * N + col] = ((red[cl] + red[64 + cl]) + red[128 + cl]) + red[192 + cl];
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                        int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = in[(size_t)(r0 + i) * cols + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < cols && r0 + tx < rows) out[(size_t)(c0 + i) * rows + r0 + tx] = tile[tx][i];
+}
+
+// ---- configuration choice -------------------------------------------------------------
+struct GemmCfg { int id, BM, BN; };
+const GemmCfg kGemmCfgs[] = {{0, 128, 128}, {1, 256, 64}, {2, 256, 32}, {3, 128, 160}, {4, 128, 96}};
+
+GemmCfg pick_gemm(int M, int K, int N, bool two) {
+  double best = 1e30;
+  GemmCfg bc = kGemmCfgs[0];
+  for (const GemmCfg &c : kGemmCfgs) {
+    const double ntn = dl3_cdiv(N, c.BN), mp = (double)dl3_cdiv(M, c.BM) * c.BM;
+    const double t_mfma = 2.0 * mp * K * ntn * c.BN / 100e12;
+    const double t_mem = 4.0 * ((double)M * K * ntn * (two ? 2 : 1) + (double)M * N) / 3e12;
+    const double cost = (t_mfma > t_mem ? t_mfma : t_mem) + 0.25 * (t_mfma + t_mem);
+    if (cost < best) { best = cost; bc = c; }
+  }
+  return bc;
+}
+
+int gemm_grid_y(int M, int N, const GemmCfg &c) {
+  const int mtiles = dl3_cdiv(M, c.BM), ntn = dl3_cdiv(N, c.BN);
+  int py = 2048 / ntn;
+  if (py < 32) py = 32;
+  return mtiles < py ? mtiles : py;
+}
+
+template <int TM, int TN, int WM, int WN>
+void launch_gemm(const GemmArgs &A, dim3 grid, hipStream_t st, bool vec) {
+  // two instantiations only: 16-byte loads on both operands, or scalar loads on both (tiny GEMMs
+  // with N or K = number of classes)
+  if (vec) hipLaunchKernelGGL((pw_gemm_kernel<TM, TN, WM, WN, true, true>), grid, dim3(256), 0, st, A);
+  else hipLaunchKernelGGL((pw_gemm_kernel<TM, TN, WM, WN, false, false>), grid, dim3(256), 0, st, A);
+}
+
+inline bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+int run_gemm(GemmArgs A, hipStream_t st) {
+  const bool two = A.a2 != nullptr;
+  const GemmCfg c = pick_gemm(A.M, A.K, A.N, two);
+  A.mtiles = dl3_cdiv(A.M, c.BM);
+  dim3 grid(dl3_cdiv(A.N, c.BN), gemm_grid_y(A.M, A.N, c));
+  const bool avec = (A.K % 4 == 0) && (A.lda % 4 == 0) && al16(A.a) && (!two || ((A.lda2 % 4 == 0) && al16(A.a2)));
+  const bool bvec = (A.N % 4 == 0) && (A.ldb % 4 == 0) && al16(A.b);
+  const bool vec = avec && bvec;
+  switch (c.id) {
+    case 0: launch_gemm<2, 2, 2, 2>(A, grid, st, vec); break;
+    case 1: launch_gemm<2, 2, 4, 1>(A, grid, st, vec); break;
+    case 2: launch_gemm<2, 1, 4, 1>(A, grid, st, vec); break;
+    case 3: launch_gemm<1, 5, 4, 1>(A, grid, st, vec); break;
+    default: launch_gemm<1, 3, 4, 1>(A, grid, st, vec); break;
+  }
+  return DL3_OK;
+}
+
+struct WgCfg { int id, BKT, BNT; };
+const WgCfg kWgCfgs[] = {{0, 64, 64},  {1, 128, 128}, {2, 160, 128}, {3, 128, 160}, {4, 64, 128},
+                         {5, 128, 64}, {6, 32, 128},  {7, 128, 32},  {8, 96, 128},  {9, 128, 96}};
+
+WgCfg pick_wgrad(int M, int K, int N, bool two) {
+  double best = 1e30;
+  WgCfg bc = kWgCfgs[0];
+  for (const WgCfg &c : kWgCfgs) {
+    const double ntk = dl3_cdiv(K, c.BKT), ntn = dl3_cdiv(N, c.BNT);
+    const double t_mfma = 2.0 * M * ntk * c.BKT * ntn * c.BNT / 100e12;
+    const double t_mem = 4.0 * ((double)M * K * ntn + (double)M * N * ntk * (two ? 2 : 1)) / 3e12;
+    const double cost = (t_mfma > t_mem ? t_mfma : t_mem) + 0.25 * (t_mfma + t_mem);
+    if (cost < best) { best = cost; bc = c; }
+  }
+  return bc;
+}
+
+int wgrad_splits(int M, int K, int N, const WgCfg &c) {
+  const long tiles = (long)dl3_cdiv(K, c.BKT) * dl3_cdiv(N, c.BNT);
+  long S = 1024 / tiles;
+  const long cap_traffic = (long)((double)M * (K + N) / (4.0 * K * N));
+  const long cap_rows = M / 64;
+  if (S > cap_traffic) S = cap_traffic;
+  if (S > cap_rows) S = cap_rows;
+  if (S < 1) S = 1;
+  return (int)S;
+}
+
+int colsum_rows(int M) {
+  int pr = M / 256;
+  if (pr < 1) pr = 1;
+  if (pr > 256) pr = 256;
+  return pr;
+}
+
+template <int TA, int TB, int WA, int WB>
+void launch_wgrad(const WgradArgs &A, dim3 grid, hipStream_t st, bool vec) {
+  if (vec) hipLaunchKernelGGL((pw_wgrad_kernel<TA, TB, WA, WB, true, true>), grid, dim3(256), 0, st, A);
+  else hipLaunchKernelGGL((pw_wgrad_kernel<TA, TB, WA, WB, false, false>), grid, dim3(256), 0, st, A);
+}
+
+}  // namespace
+
+extern "C" int dl3_reduce_partials(const float *partial, int P, int n, float *out, void *stream);
+
+extern "C" int dl3_pwconv_partials(int M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0) return 0;
+  // the stat partial row count must not depend on which operand form is used: take the max
+  const GemmCfg c1 = pick_gemm(M, K, N, false), c2 = pick_gemm(M, K, N, true);
+  const int p1 = gemm_grid_y(M, N, c1), p2 = gemm_grid_y(M, N, c2);
+  return p1 > p2 ? p1 : p2;
+}
+
+static int gemm_common_check(const char *name, int M, int K, int N) {
+  DL3_CHECK_ARG(M > 0 && K > 0 && N > 0, "%s: non-positive dimension", name);
+  return DL3_OK;
+}
+
+// zero-fill partial rows the chosen grid did not write
+static void pad_partials(float *part, int M, int K, int N, int written, hipStream_t st) {
+  const int total = dl3_pwconv_partials(M, K, N);
+  if (part && total > written)
+    (void)hipMemsetAsync(part + (size_t)written * N * 2, 0, (size_t)(total - written) * N * 2 * sizeof(float), st);
+}
+
+extern "C" int dl3_pwconv_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
+                              const float *w, const float *bias, float *y, int ldy, int M, int K, int N,
+                              float *stat_partial, void *stream) {
+  int rc = gemm_common_check("pwconv_fwd", M, K, N);
+  if (rc) return rc;
+  DL3_CHECK_ARG(x && w && y, "pwconv_fwd: null pointer");
+  DL3_CHECK_ARG(ldx >= K && ldy >= N, "pwconv_fwd: leading dimension too small");
+  DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "pwconv_fwd: scale/shift must come together");
+  GemmArgs A{};
+  A.a = x; A.lda = ldx; A.a2 = nullptr; A.lda2 = 0;
+  A.ka = in_scale; A.kb = nullptr; A.kc = in_shift; A.a_act = in_act;
+  A.b = w; A.ldb = N; A.bias = bias; A.c = y; A.ldc = ldy;
+  A.M = M; A.K = K; A.N = N;
+  A.add_div = 1; A.add_scale = 1.f;
+  A.stat_mode = stat_partial ? 1 : 0;
+  A.part = stat_partial;
+  hipStream_t st = (hipStream_t)stream;
+  run_gemm(A, st);
+  if (stat_partial) {
+    const GemmCfg c = pick_gemm(M, K, N, false);
+    pad_partials(stat_partial, M, K, N, gemm_grid_y(M, N, c), st);
+  }
+  DL3_LAUNCH_CHECK("pwconv_fwd");
+  return DL3_OK;
+}
+
+extern "C" int dl3_pwconv_bwd_data(const float *g, int ldg, const float *yraw, int ldyraw, const float *cA,
+                                   const float *cB, const float *cC, const float *wT, float *dx, int lddx,
+                                   const float *x, int ldx, const float *in_scale, const float *in_shift,
+                                   int in_act, const float *dx_add, int ldadd, int add_div, float add_scale,
+                                   const float *x_mean, const float *x_invstd, float *dstat_partial, int M,
+                                   int K, int N, void *stream) {
+  int rc = gemm_common_check("pwconv_bwd_data", M, K, N);
+  if (rc) return rc;
+  DL3_CHECK_ARG(g && wT && dx, "pwconv_bwd_data: null pointer");
+  DL3_CHECK_ARG(!cA || (yraw && cB && cC), "pwconv_bwd_data: cA needs yraw, cB, cC");
+  DL3_CHECK_ARG(in_act == DL3_ACT_NONE || x, "pwconv_bwd_data: activation mask needs x");
+  DL3_CHECK_ARG(!dstat_partial || (x && x_mean && x_invstd), "pwconv_bwd_data: dstat needs x, x_mean, x_invstd");
+  DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "pwconv_bwd_data: scale/shift must come together");
+  // GEMM [M, N] x [N, K] -> [M, K]
+  GemmArgs A{};
+  A.a = g; A.lda = ldg;
+  A.a2 = cA ? yraw : nullptr; A.lda2 = ldyraw;
+  A.ka = cA; A.kb = cB; A.kc = cC; A.a_act = DL3_ACT_NONE;
+  A.b = wT; A.ldb = K; A.bias = nullptr; A.c = dx; A.ldc = lddx;
+  A.M = M; A.K = N; A.N = K;
+  const bool need_x = (in_act != DL3_ACT_NONE) || dstat_partial;
+  A.ep_x = need_x ? x : nullptr; A.ld_epx = ldx;
+  A.ep_scale = in_scale; A.ep_shift = in_shift; A.ep_act = in_act;
+  A.ep_add = dx_add; A.ld_add = ldadd; A.add_div = add_div < 1 ? 1 : add_div; A.add_scale = add_scale;
+  A.stat_mode = dstat_partial ? 2 : 0;
+  A.ep_mean = x_mean; A.ep_invstd = x_invstd;
+  A.part = dstat_partial;
+  hipStream_t st = (hipStream_t)stream;
+  run_gemm(A, st);
+  if (dstat_partial) {
+    const GemmCfg c = pick_gemm(M, N, K, A.a2 != nullptr);
+    pad_partials(dstat_partial, M, N, K, gemm_grid_y(M, K, c), st);
+  }
+  DL3_LAUNCH_CHECK("pwconv_bwd_data");
+  return DL3_OK;
+}
+
+extern "C" size_t dl3_pwconv_bwd_weight_workspace(int M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0) return 0;
+  // S depends on the operand form; size for the larger
+  const WgCfg c1 = pick_wgrad(M, K, N, false), c2 = pick_wgrad(M, K, N, true);
+  int S1 = wgrad_splits(M, K, N, c1), S2 = wgrad_splits(M, K, N, c2);
+  const int S = S1 > S2 ? S1 : S2;
+  return ((size_t)S * K * N + (size_t)colsum_rows(M) * N) * sizeof(float);
+}
+
+extern "C" int dl3_pwconv_bwd_weight(const float *x, int ldx, const float *in_scale, const float *in_shift,
+                                     int in_act, const float *g, int ldg, const float *yraw, int ldyraw,
+                                     const float *cA, const float *cB, const float *cC, float *dw, float *dbias,
+                                     int M, int K, int N, void *workspace, size_t workspace_bytes, void *stream) {
+  int rc = gemm_common_check("pwconv_bwd_weight", M, K, N);
+  if (rc) return rc;
+  DL3_CHECK_ARG(x && g && dw && workspace, "pwconv_bwd_weight: null pointer");
+  DL3_CHECK_ARG(!cA || (yraw && cB && cC), "pwconv_bwd_weight: cA needs yraw, cB, cC");
+  DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "pwconv_bwd_weight: scale/shift must come together");
+  DL3_UNSUPPORTED(dbias && cA, "pwconv_bwd_weight: dbias with a BN-backward gradient operand is not needed by the path");
+  if (workspace_bytes < dl3_pwconv_bwd_weight_workspace(M, K, N)) {
+    dl3_set_error("pwconv_bwd_weight: workspace %zu < %zu bytes", workspace_bytes,
+                  dl3_pwconv_bwd_weight_workspace(M, K, N));
+    return DL3_EWORKSPACE;
+  }
+  const bool two = cA != nullptr;
+  const WgCfg c = pick_wgrad(M, K, N, two);
+  const int S = wgrad_splits(M, K, N, c);
+  WgradArgs A{};
+  A.x = x; A.ldx = ldx; A.xs = in_scale; A.xt = in_shift; A.x_act = in_act;
+  A.g = g; A.ldg = ldg; A.y = two ? yraw : nullptr; A.ldy = ldyraw;
+  A.cA = cA; A.cB = cB; A.cC = cC;
+  A.ws = (float *)workspace;
+  A.M = M; A.K = K; A.N = N;
+  A.Mper = dl3_cdiv(dl3_cdiv(M, S), 16) * 16;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(dl3_cdiv(N, c.BNT), dl3_cdiv(K, c.BKT), S);
+  const bool xvec = (K % 4 == 0) && (ldx % 4 == 0) && al16(x);
+  const bool dvec = (N % 4 == 0) && (ldg % 4 == 0) && al16(g) && (!two || ((ldyraw % 4 == 0) && al16(yraw)));
+  switch (c.id) {
+    case 0: launch_wgrad<1, 1, 2, 2>(A, grid, st, xvec && dvec); break;
+    case 1: launch_wgrad<2, 2, 2, 2>(A, grid, st, xvec && dvec); break;
+    case 2: launch_wgrad<5, 1, 1, 4>(A, grid, st, xvec && dvec); break;
+    case 3: launch_wgrad<1, 5, 4, 1>(A, grid, st, xvec && dvec); break;
+    case 4: launch_wgrad<2, 1, 1, 4>(A, grid, st, xvec && dvec); break;
+    case 5: launch_wgrad<1, 2, 4, 1>(A, grid, st, xvec && dvec); break;
+    case 6: launch_wgrad<1, 1, 1, 4>(A, grid, st, xvec && dvec); break;
+    case 7: launch_wgrad<1, 1, 4, 1>(A, grid, st, xvec && dvec); break;
+    case 8: launch_wgrad<3, 1, 1, 4>(A, grid, st, xvec && dvec); break;
+    default: launch_wgrad<1, 3, 4, 1>(A, grid, st, xvec && dvec); break;
+  }
+  DL3_LAUNCH_CHECK("pwconv_bwd_weight");
+  rc = dl3_reduce_partials(A.ws, S, K * N, dw, stream);
+  if (rc) return rc;
+  if (dbias) {
+    float *cpart = A.ws + (size_t)S * K * N;
+    const int pr = colsum_rows(M);
+    hipLaunchKernelGGL(colsum_kernel, dim3(dl3_cdiv(N, 64), pr), dim3(256), 0, st, g, ldg, M, N, cpart);
+    DL3_LAUNCH_CHECK("pwconv_bwd_weight(colsum)");
+    rc = dl3_reduce_partials(cpart, pr, N, dbias, stream);
+    if (rc) return rc;
+  }
+  return DL3_OK;
+}
+
+extern "C" int dl3_transpose(const float *in, float *out, int rows, int cols, void *stream) {
+  DL3_CHECK_ARG(in && out && rows > 0 && cols > 0, "transpose: bad argument");
+  dim3 grid(dl3_cdiv(cols, 32), dl3_cdiv(rows, 32));
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out, rows, cols);
+  DL3_LAUNCH_CHECK("transpose");
+  return DL3_OK;
+}
