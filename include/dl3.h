@@ -138,11 +138,13 @@ int dl3_rows_partials(int M); /* P for row-wise reducing kernels over M rows */
 int dl3_affine_add(const float *a, int lda, const float *sa, const float *ta, int act_a, const float *b,
                    int ldb, const float *sb, const float *tb, int act_b, float *out, int ldo, int M, int C,
                    float drop_rate, unsigned long long drop_seed, void *stream);
-/* gout = mask_{act}(gin * dropmask/(1-rate)) + add ; dstat partials [P][C][2] (nullable), P=dl3_rows_partials(M) */
-int dl3_grad_finish(const float *gin, int ldgin, float *gout, int ldgout, const float *add, int ldadd,
-                    const float *xraw, int ldx, const float *scale, const float *shift, int act,
-                    const float *mean, const float *invstd, float *dstat_partial, int M, int C,
-                    float drop_rate, unsigned long long drop_seed, void *stream);
+/* gout = mask_{act}(gin_scale * gin[m / gin_div] * dropmask/(1-rate)) + add ; gin_div = H*W broadcasts a
+ * per-image gradient vector (backward of the global average pool); dstat partials [P][C][2] (nullable),
+ * P = dl3_rows_partials(M).  gout may alias gin (gin_div == 1) and/or add. */
+int dl3_grad_finish(const float *gin, int ldgin, int gin_div, float gin_scale, float *gout, int ldgout,
+                    const float *add, int ldadd, const float *xraw, int ldx, const float *scale,
+                    const float *shift, int act, const float *mean, const float *invstd, float *dstat_partial,
+                    int M, int C, float drop_rate, unsigned long long drop_seed, void *stream);
 /* AveragePooling2D over the whole map (deeplabv3p.py:375): out[n][c] = out_scale * sum_hw T(x)[n,hw,c] */
 int dl3_gap_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act, float *out,
                 int N, int HW, int C, float out_scale, void *stream);

@@ -160,9 +160,9 @@ __global__ __launch_bounds__(256) void affine_add_kernel(const float *__restrict
 }
 
 // gout = mask_act(gin*dropmask) + add ; stats partial [gridDim.y][C][2]; 32 columns x 8 row lanes
-__global__ __launch_bounds__(256) void grad_finish_kernel(const float *__restrict__ gin, int ldgin,
-                                                          float *__restrict__ gout, int ldgout,
-                                                          const float *__restrict__ add, int ldadd,
+__global__ __launch_bounds__(256) void grad_finish_kernel(const float *gin, int ldgin, int gin_div,
+                                                          float gin_scale, float *gout, int ldgout,
+                                                          const float *add, int ldadd,
                                                           const float *__restrict__ xraw, int ldx,
                                                           const float *__restrict__ scale,
                                                           const float *__restrict__ shift, int act,
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void grad_finish_kernel(const float *__restric
   float s1 = 0.f, s2 = 0.f;
   if (cok)
     for (long m = (long)blockIdx.y * 8 + rl; m < M; m += (long)gridDim.y * 8) {
-      float v = gin[(size_t)m * ldgin + c];
+      float v = gin_scale * gin[(size_t)(gin_div > 1 ? m / gin_div : m) * ldgin + c];
       if (drop_rate > 0.f)
         v = (dl3_uniform(seed, (unsigned long long)(m * C + c)) >= drop_rate) ? v * keep_scale : 0.f;
       float xr = 0.f;
@@ -329,7 +329,8 @@ extern "C" int dl3_affine_add(const float *a, int lda, const float *sa, const fl
   return DL3_OK;
 }
 
-extern "C" int dl3_grad_finish(const float *gin, int ldgin, float *gout, int ldgout, const float *add, int ldadd,
+extern "C" int dl3_grad_finish(const float *gin, int ldgin, int gin_div, float gin_scale, float *gout, int ldgout,
+                               const float *add, int ldadd,
                                const float *xraw, int ldx, const float *scale, const float *shift, int act,
                                const float *mean, const float *invstd, float *dstat_partial, int M, int C,
                                float drop_rate, unsigned long long drop_seed, void *stream) {
@@ -338,7 +339,8 @@ extern "C" int dl3_grad_finish(const float *gin, int ldgin, float *gout, int ldg
   DL3_CHECK_ARG(!dstat_partial || (xraw && mean && invstd), "grad_finish: dstat needs xraw, mean, invstd");
   DL3_CHECK_ARG((scale == nullptr) == (shift == nullptr), "grad_finish: scale/shift must come together");
   dim3 grid(dl3_cdiv(C, 32), dl3_rows_partials(M));
-  hipLaunchKernelGGL(grad_finish_kernel, grid, dim3(256), 0, (hipStream_t)stream, gin, ldgin, gout, ldgout, add,
+  hipLaunchKernelGGL(grad_finish_kernel, grid, dim3(256), 0, (hipStream_t)stream, gin, ldgin, gin_div, gin_scale,
+                     gout, ldgout, add,
                      ldadd, xraw, ldx, scale, shift, act, mean, invstd, dstat_partial, (long)M, C, drop_rate,
                      drop_seed);
   DL3_LAUNCH_CHECK("grad_finish");

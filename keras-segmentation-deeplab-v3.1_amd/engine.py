@@ -1,0 +1,916 @@
+"""Executor: lowers a graph.Model into a static plan of libdl3.so launches (forward, loss, backward,
+Adam) over HBM-resident buffers, and replays it — eagerly or as one captured hipGraph.
+
+Design (MI355X-first):
+  * one process per GPU; torch is used only for device memory, streams, graph capture and RCCL.
+  * NHWC fp32.  A conv output is written ONCE as the raw pre-BatchNorm tensor; BatchNorm (+ReLU/ReLU6)
+    of a producer is a per-channel (scale, shift, act) "view" applied on load by its consumers, so
+    the 54 BN + 37 activation passes of the reference graph cost no HBM traffic.
+  * BN batch statistics / BN-backward sums / weight gradients are deterministic partial reductions
+    written by the producing kernel's epilogue and folded by tiny finalize kernels.
+  * Concatenate is zero-copy: producers write channel slices of one buffer (ld = total channels).
+  * gradients w.r.t. a buffer are accumulated by its consumers' bwd-data epilogues (mask -> add ->
+    BN-backward partial sums), residual Adds are gradient aliases.
+Reference call stack being replaced: Keras Model.predict / train_on_batch -> TF Session.run.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import capi
+from .capi import ACT_NONE, ACT_RELU, ACT_RELU6, IMPL_AUTO, ptr
+
+_ACT = {"relu": ACT_RELU, "relu6": ACT_RELU6}
+V_SCALE, V_SHIFT, V_MEAN, V_INVSTD, V_CA, V_CB, V_CC = range(7)
+
+
+def _same_pads(size, k, stride, rate):
+    out = -(-size // stride)
+    total = max((out - 1) * stride + (k - 1) * rate + 1 - size, 0)
+    return out, total // 2
+
+
+class Buf:
+    """One device tensor [N*H*W, ld] + its per-channel vectors + gradient accounting."""
+
+    def __init__(self, eng, N, H, W, ld, name, requires_grad=True):
+        self.eng, self.N, self.H, self.W, self.ld, self.name = eng, N, H, W, ld, name
+        self.M = N * H * W
+        self.t = eng.empty(self.M * ld)
+        v = torch.zeros(7, ld, dtype=torch.float32)
+        v[V_SCALE] = 1.0
+        v[V_CA] = 1.0
+        self.vec = v.to(eng.device)
+        self.bns = []          # (bn_layer, c_off, C)
+        self.requires_grad = requires_grad
+        self.expected = 0      # gradient contributions to come (consumer units)
+        self.done = 0
+        self.grad = None       # tensor [M, ld]
+        self.addend = None     # pending pass-through gradient (tensor [M, ld])
+        self.nonneg = False
+
+    def vptr(self, row, off=0):
+        return self.vec.data_ptr() + 4 * (row * self.ld + off)
+
+
+class View:
+    """A Keras tensor as the engine sees it: channel slice of a Buf, read as act(scale*x+shift)."""
+
+    def __init__(self, buf, off, C, act=ACT_NONE, aff=False, pad=None, shape=None):
+        self.buf, self.off, self.C, self.act, self.aff, self.pad = buf, off, C, act, aff, pad
+        self.shape = shape or (buf.N, buf.H, buf.W, C)
+
+    def derive(self, **kw):
+        d = dict(buf=self.buf, off=self.off, C=self.C, act=self.act, aff=self.aff, pad=self.pad, shape=self.shape)
+        d.update(kw)
+        return View(**d)
+
+    @property
+    def ld(self):
+        return self.buf.ld
+
+    def p(self):
+        return self.buf.t.data_ptr() + 4 * self.off
+
+    def scale(self):
+        return self.buf.vptr(V_SCALE, self.off) if self.aff else None
+
+    def shift(self):
+        return self.buf.vptr(V_SHIFT, self.off) if self.aff else None
+
+    def xform(self):
+        return (self.scale(), self.shift(), self.act)
+
+
+class Engine:
+    def __init__(self, model, batch, training, bn_mode="batch", dropout=True, seed=2, device=None, use_graph=True,
+                 dw_impl=IMPL_AUTO):
+        if not torch.cuda.is_available():
+            raise capi.DL3Error("the dl3 engine needs a GPU (HIP device); there is no CPU fallback")
+        self.lib = capi.lib()
+        self.model, self.B, self.training = model, int(batch), bool(training)
+        self.bn_batch = self.training and bn_mode == "batch"
+        self.dropout = bool(dropout) and self.training
+        self.seed = int(seed)
+        self.device = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
+        self.use_graph = use_graph
+        self.dw_impl = dw_impl
+        self.ops_prep, self.ops_fwd, self.ops_bwd = [], [], []
+        self.units = []
+        self.views = {}
+        self.bufs = []
+        self.scratch_bytes = 0
+        self.iteration = 0
+        self.graph = None
+        self._calls = 0
+        self._keep = []
+        self._build_params()
+        self._lower()
+        if self.training:
+            self._lower_backward()
+        self.scratch = self.empty(max(self.scratch_bytes // 4, 4))
+        for op in self._scratch_users:
+            op[2][op[3]] = self.scratch.data_ptr()
+        self.dirty = True
+
+    # ------------------------------------------------------------------ memory
+    def empty(self, n):
+        t = torch.empty(int(n), dtype=torch.float32, device=self.device)
+        self._keep.append(t)
+        return t
+
+    def zeros(self, n):
+        t = torch.zeros(int(n), dtype=torch.float32, device=self.device)
+        self._keep.append(t)
+        return t
+
+    def _build_params(self):
+        """Flat arenas: trainable parameters (kernels, biases, gamma, beta) | state (moving statistics and the
+        weights of non-trainable layers).  One RCCL all-reduce and one Adam launch cover the whole model."""
+        self.slots = {}
+        np_, ns = 0, 0
+        for l in self.model.layers:
+            for name, w in l.weights.items():
+                n = (w.size + 3) // 4 * 4
+                if l.trainable and "/moving_" not in name:
+                    self.slots[name] = ("p", np_, w.size, w.shape, l)
+                    np_ += n
+                else:
+                    self.slots[name] = ("s", ns, w.size, w.shape, l)
+                    ns += n
+        self.n_param = np_
+        self.params = self.zeros(max(np_, 4))
+        self.state = self.zeros(max(ns, 4))
+        if self.training:
+            self.grads = self.zeros(max(np_, 4))
+            self.adam_m = self.zeros(max(np_, 4))
+            self.adam_v = self.zeros(max(np_, 4))
+            self.dummy_grad = self.zeros(4096)
+        self.sync_all_to_device()
+
+    def _arena(self, kind):
+        return self.params if kind == "p" else self.state
+
+    def wptr(self, name):
+        kind, off, _, _, _ = self.slots[name]
+        return self._arena(kind).data_ptr() + 4 * off
+
+    def gptr(self, name, size=0):
+        """gradient slot of a weight; non-trainable weights get a throw-away slot"""
+        kind, off, n, _, _ = self.slots[name]
+        if kind == "p":
+            return self.grads.data_ptr() + 4 * off
+        if n > self.dummy_grad.numel():
+            self.dummy_grad = self.zeros(n)
+        return self.dummy_grad.data_ptr()
+
+    def trainable(self, name):
+        return self.slots[name][0] == "p"
+
+    def sync_all_to_device(self):
+        hp = np.zeros(self.params.numel(), np.float32)
+        hs = np.zeros(self.state.numel(), np.float32)
+        for name, (kind, off, n, shp, l) in self.slots.items():
+            (hp if kind == "p" else hs)[off:off + n] = l.weights[name].reshape(-1)
+        self.params.copy_(torch.from_numpy(hp))
+        self.state.copy_(torch.from_numpy(hs))
+        self.dirty = True
+
+    def sync_all_to_host(self):
+        hp = self.params.cpu().numpy()
+        hs = self.state.cpu().numpy()
+        for name, (kind, off, n, shp, l) in self.slots.items():
+            l.weights[name] = (hp if kind == "p" else hs)[off:off + n].reshape(shp).copy()
+
+    def sync_layer_to_host(self, layer):
+        for name in layer.weights:
+            kind, off, n, shp, _ = self.slots[name]
+            layer.weights[name] = self._arena(kind)[off:off + n].cpu().numpy().reshape(shp).copy()
+
+    def sync_layer_to_device(self, layer):
+        for name, w in layer.weights.items():
+            kind, off, n, shp, _ = self.slots[name]
+            self._arena(kind)[off:off + n].copy_(torch.from_numpy(np.ascontiguousarray(w.reshape(-1))))
+        self.dirty = True
+
+    def activate(self):
+        """make this engine the one that layer.get_weights()/set_weights() talk to"""
+        for l in self.model.layers:
+            if l._engine is not None and l._engine is not self:
+                pass
+            l._engine = self
+
+    # ------------------------------------------------------------------ op recording
+    def op(self, lst, name, *args):
+        fn = getattr(self.lib, name)
+        rec = (name, fn, list(args), None)
+        lst.append(rec)
+        return rec
+
+    _scratch_users = None
+
+    def op_ws(self, lst, name, nbytes, ws_index, *args):
+        """op that needs the shared scratch workspace (pointer patched in once its size is known)"""
+        self.scratch_bytes = max(self.scratch_bytes, int(nbytes))
+        args = list(args)
+        rec = (name, getattr(self.lib, name), args, ws_index)
+        lst.append(rec)
+        self._scratch_users.append(rec)
+        return rec
+
+    def run_ops(self, lst):
+        st = torch.cuda.current_stream().cuda_stream
+        for name, fn, args, _ in lst:
+            rc = fn(*args, st)
+            if rc != 0:
+                capi.check(rc, name)
+
+    # ------------------------------------------------------------------ forward lowering
+    def _lower(self):
+        self._scratch_users = []
+        m = self.model
+        topo = m._topo
+        self.consumers = {}
+        for l in topo:
+            for t in (l.inbound if l is not m.input.layer else []):
+                self.consumers.setdefault(id(t), []).append(l)
+        self.placement = {}
+        self.concat_bufs = {}
+        for l in topo:
+            if l.kind == "Concatenate":
+                self._place_concat(l)
+        self.unit_of_buf = {}
+        for l in topo:
+            getattr(self, "_lo_" + l.kind)(l)
+        out = self.views[id(m.output)]
+        self.out_view = out
+
+    def _producer_of(self, t):
+        l = t.layer
+        while l.kind in ("BatchNormalization", "Activation") and l.cfg.get("fn") != "softmax":
+            l = l.inbound[0].layer
+        return l
+
+    def _place_concat(self, l):
+        H, W, C = l.output.shape
+        buf = Buf(self, self.B, H, W, C, l.name)
+        self.bufs.append(buf)
+        self.concat_bufs[id(l)] = buf
+        off = 0
+        for t in l.inbound:
+            p = self._producer_of(t)
+            ok = (p.kind in ("Conv2D",) and p.cfg["k"] == 1 and p.cfg["stride"] == 1) or p.kind == "ResizeBilinear"
+            if p.kind == "Dropout" or not ok:
+                raise NotImplementedError("Concatenate input produced by %s (%s) is not on the path" % (p.name, p.kind))
+            self.placement[id(p)] = (buf, off)
+            off += t.shape[2]
+
+    def _new_out(self, l, H, W, C):
+        """output buffer of a producing layer: a concat slice if placed, else a fresh Buf"""
+        if id(l) in self.placement:
+            buf, off = self.placement[id(l)]
+            return buf, off
+        buf = Buf(self, self.B, H, W, C, l.name)
+        self.bufs.append(buf)
+        return buf, 0
+
+    def _in(self, l, i=0):
+        return self.views[id(l.inbound[i])]
+
+    def _consume(self, view):
+        if view.buf.requires_grad:
+            view.buf.expected += 1
+
+    def _bn_follows(self, l):
+        cs = self.consumers.get(id(l.output), [])
+        return len(cs) == 1 and cs[0].kind == "BatchNormalization"
+
+    def _stat_buf(self, P, C):
+        return self.empty(P * C * 2)
+
+    # ---- layers ---------------------------------------------------------------------
+    def _lo_InputLayer(self, l):
+        H, W, C = l.output.shape
+        self.xbuf = Buf(self, self.B, H, W, C, "input", requires_grad=False)
+        self.bufs.append(self.xbuf)
+        self.views[id(l.output)] = View(self.xbuf, 0, C)
+
+    def _lo_Prescale(self, l):
+        v = self._in(l)
+        assert v.buf is self.xbuf and not v.aff
+        vec = v.buf.vec.cpu()
+        vec[V_SCALE] = 1.0 / 127.5
+        vec[V_SHIFT] = -1.0
+        v.buf.vec.copy_(vec)
+        self.views[id(l.output)] = v.derive(aff=True)
+
+    def _lo_ZeroPadding2D(self, l):
+        v = self._in(l)
+        (pt, pb), (pl, pr) = l.cfg["pad"]
+        assert v.pad is None
+        self.views[id(l.output)] = v.derive(pad=(pt, pl))
+
+    def _lo_Activation(self, l):
+        v = self._in(l)
+        fn = l.cfg["fn"]
+        if fn == "softmax":
+            return self._lo_softmax(l, v)
+        if v.act != ACT_NONE:
+            raise NotImplementedError("activation stacked on an activation (%s)" % l.name)
+        self.views[id(l.output)] = v.derive(act=_ACT[fn])
+
+    def _lo_Reshape(self, l):
+        self.views[id(l.output)] = self._in(l)
+
+    def _lo_BatchNormalization(self, l):
+        v = self._in(l)
+        unit = self.unit_of_buf.get((id(v.buf), v.off))
+        if v.aff or v.act != ACT_NONE or unit is None or unit.bn is not None:
+            raise NotImplementedError("BatchNormalization %s must directly follow a convolution" % l.name)
+        unit.bn = l
+        C = v.C
+        n = l.name
+        v.buf.bns.append((l, v.off, C))
+        if self.bn_batch:
+            self.op(self.ops_fwd, "dl3_bn_finalize", ptr(unit.stat), unit.P, C, C, float(v.buf.M),
+                    self.wptr(n + "/gamma:0"), self.wptr(n + "/beta:0"), l.cfg["eps"], l.cfg["momentum"],
+                    v.buf.vptr(V_SCALE, v.off), v.buf.vptr(V_SHIFT, v.off), v.buf.vptr(V_MEAN, v.off),
+                    v.buf.vptr(V_INVSTD, v.off), self.wptr(n + "/moving_mean:0"), self.wptr(n + "/moving_variance:0"))
+        else:
+            self.op(self.ops_prep, "dl3_bn_frozen", self.wptr(n + "/gamma:0"), self.wptr(n + "/beta:0"),
+                    self.wptr(n + "/moving_mean:0"), self.wptr(n + "/moving_variance:0"), l.cfg["eps"], C,
+                    v.buf.vptr(V_SCALE, v.off), v.buf.vptr(V_SHIFT, v.off), v.buf.vptr(V_MEAN, v.off),
+                    v.buf.vptr(V_INVSTD, v.off))
+        self.views[id(l.output)] = v.derive(aff=True)
+
+    def _lo_Conv2D(self, l):
+        v = self._in(l)
+        if l.cfg["k"] == 3:
+            return self._lo_conv3x3(l, v)
+        if l.cfg["stride"] != 1:
+            raise NotImplementedError("strided 1x1 convolution (%s: Xception shortcut) is not built yet" % l.name)
+        Ho, Wo, N = v.shape[1], v.shape[2], l.cfg["filters"]
+        buf, off = self._new_out(l, Ho, Wo, N)
+        u = PwUnit(self, l, v, View(buf, off, N), want_stat=self.bn_batch and self._bn_follows(l))
+        self._register(u, buf, off)
+        self.views[id(l.output)] = View(buf, off, N)
+
+    def _lo_Subpixel(self, l):
+        v = self._in(l)
+        r, co = l.cfg["r"], l.cfg["out_filters"]
+        Ho, Wo, N = v.shape[1], v.shape[2], l.cfg["filters"]
+        buf = Buf(self, self.B, Ho, Wo, N, l.name)
+        self.bufs.append(buf)
+        u = PwUnit(self, l, v, View(buf, 0, N), want_stat=False)
+        self._register(u, buf, 0)
+        obuf = Buf(self, self.B, Ho * r, Wo * r, co, l.name + "_shift")
+        self.bufs.append(obuf)
+        s = ShuffleUnit(self, View(buf, 0, N), View(obuf, 0, co), r, co)
+        self.units.append(s)
+        self.views[id(l.output)] = View(obuf, 0, co)
+
+    def _lo_conv3x3(self, l, v):
+        N_, H, W, Cin = v.shape
+        s = l.cfg["stride"]
+        if l.cfg["padding"] == "same":
+            Ho, pt = _same_pads(H, 3, s, 1)
+            Wo, pl = _same_pads(W, 3, s, 1)
+        else:
+            pt, pl = v.pad or (0, 0)
+            Ho, Wo = l.output.shape[0], l.output.shape[1]
+        buf, off = self._new_out(l, Ho, Wo, l.cfg["filters"])
+        u = Conv3Unit(self, l, v, View(buf, off, l.cfg["filters"]), s, pt, pl,
+                      want_stat=self.bn_batch and self._bn_follows(l))
+        self._register(u, buf, off)
+        self.views[id(l.output)] = View(buf, off, l.cfg["filters"])
+
+    def _lo_DepthwiseConv2D(self, l):
+        v = self._in(l)
+        N_, H, W, C = v.shape
+        if v.off != 0 or v.ld != C:
+            raise NotImplementedError("depthwise conv on a channel slice (%s)" % l.name)
+        s, r = l.cfg["stride"], l.cfg["rate"]
+        if l.cfg["padding"] == "same":
+            Ho, pt = _same_pads(H, 3, s, r)
+            Wo, pl = _same_pads(W, 3, s, r)
+        else:
+            pt, pl = v.pad or (0, 0)
+            Ho, Wo = l.output.shape[0], l.output.shape[1]
+        buf, off = self._new_out(l, Ho, Wo, C)
+        u = DwUnit(self, l, v, View(buf, off, C), s, r, pt, pl, want_stat=self.bn_batch and self._bn_follows(l))
+        self._register(u, buf, off)
+        self.views[id(l.output)] = View(buf, off, C)
+
+    def _register(self, u, buf, off):
+        self.units.append(u)
+        self.unit_of_buf[(id(buf), off)] = u
+
+    def _lo_Add(self, l):
+        a, b = self._in(l, 0), self._in(l, 1)
+        H, W, C = l.output.shape
+        buf = Buf(self, self.B, H, W, C, l.name)
+        self.bufs.append(buf)
+        self.units.append(AddUnit(self, a, b, View(buf, 0, C)))
+        self.views[id(l.output)] = View(buf, 0, C)
+
+    def _lo_Concatenate(self, l):
+        buf = self.concat_bufs[id(l)]
+        acts = set()
+        for t in l.inbound:
+            v = self.views[id(t)]
+            if v.buf is not buf:
+                raise NotImplementedError("concat input %s was not placed" % t.layer.name)
+            if v.act != ACT_NONE:
+                acts.add(v.act)
+            elif not (v.buf.nonneg_slices.get(v.off, False) if hasattr(v.buf, "nonneg_slices") else False):
+                raise NotImplementedError("concat input without activation must be known non-negative")
+        if len(acts) > 1:
+            raise NotImplementedError("concat inputs with different activations")
+        act = acts.pop() if acts else ACT_NONE
+        self.views[id(l.output)] = View(buf, 0, buf.ld, act=act, aff=True)
+
+    def _lo_AveragePooling2D(self, l):
+        v = self._in(l)
+        C = v.C
+        buf = Buf(self, self.B, 1, 1, C, l.name)
+        self.bufs.append(buf)
+        self.units.append(GapUnit(self, v, View(buf, 0, C)))
+        self.views[id(l.output)] = View(buf, 0, C)
+
+    def _lo_ResizeBilinear(self, l):
+        v = self._in(l)
+        Ho, Wo = l.cfg["size"]
+        buf, off = self._new_out(l, Ho, Wo, v.C)
+        nonneg = v.act in (ACT_RELU, ACT_RELU6) or v.buf.nonneg
+        if buf.ld != v.C:
+            if not hasattr(buf, "nonneg_slices"):
+                buf.nonneg_slices = {}
+            buf.nonneg_slices[off] = nonneg
+        else:
+            buf.nonneg = nonneg
+        self.units.append(ResizeUnit(self, v, View(buf, off, v.C), Ho, Wo))
+        self.views[id(l.output)] = View(buf, off, v.C)
+
+    def _lo_Dropout(self, l):
+        v = self._in(l)
+        if not (self.dropout and l.cfg["rate"] > 0):
+            self.views[id(l.output)] = v
+            return
+        N_, H, W, C = v.shape
+        buf = Buf(self, self.B, H, W, C, l.name)
+        buf.nonneg = v.act in (ACT_RELU, ACT_RELU6)
+        self.bufs.append(buf)
+        self.units.append(MaterializeUnit(self, v, View(buf, 0, C), l.cfg["rate"], self.seed))
+        self.views[id(l.output)] = View(buf, 0, C)
+
+    def _lo_softmax(self, l, v):
+        N_, H, W, C = v.shape[0], v.buf.H, v.buf.W, v.C
+        if v.aff or v.act != ACT_NONE or v.off != 0 or v.ld != C:
+            raise NotImplementedError("softmax expects materialised logits")
+        self.logits_view = v
+        M = v.buf.M
+        self.probs = self.empty(M * C)
+        self.out_shape = (self.B,) + tuple(l.output.shape)
+        if self.training:
+            self.labels = self.zeros(M)
+            self.sweights = self.zeros(M)
+            self.nnz = self.zeros(4)
+            self.lossP = self.lib.dl3_rows_partials(M)
+            self.loss_part = self.zeros(self.lossP)
+            self.loss = self.zeros(4)
+            v.buf.expected += 1
+        self.views[id(l.output)] = v
+
+    # ------------------------------------------------------------------ backward lowering
+    def _lower_backward(self):
+        v = self.logits_view
+        buf = v.buf
+        M, C = buf.M, v.C
+        # loss + dlogits (first and only contribution to the logits buffer)
+        buf.grad = self.empty(M * buf.ld)
+        self.op(self.ops_fwd, "dl3_count_nonzero", ptr(self.sweights), M, ptr(self.nnz))
+        self.op(self.ops_fwd, "dl3_softmax_xent", ptr(buf.t), ptr(self.labels), ptr(self.sweights), ptr(self.nnz),
+                None, ptr(buf.grad), ptr(self.loss_part), M, C)
+        self.op(self.ops_fwd, "dl3_reduce_partials", ptr(self.loss_part), self.lossP, 1, ptr(self.loss))
+        buf.done = 1
+        assert buf.expected == 1
+        # weight transposes for bwd-data, then the units in reverse
+        for u in reversed(self.units):
+            u.bwd()
+        for b in self.bufs:
+            if b.requires_grad and b.expected and b.done != b.expected:
+                raise RuntimeError("gradient accounting broken for buffer %s (%d/%d)" % (b.name, b.done, b.expected))
+
+    # ---- gradient contribution protocol ---------------------------------------------
+    def contrib_kernel(self, buf):
+        """A kernel is about to write its contribution into buf.grad.  Returns (gout, add, last)."""
+        add = None
+        if buf.grad is None:
+            buf.grad = self.empty(buf.M * buf.ld)
+            if buf.addend is not None:
+                add, buf.addend = buf.addend, None
+        else:
+            add = buf.grad
+        buf.done += 1
+        return buf.grad, add, buf.done == buf.expected
+
+    def finish_bn_bwd(self, buf, dpart, P, ldc):
+        """after the last contribution: fold the BN-backward partials of every BN living in this buffer"""
+        for bn, off, C in buf.bns:
+            n = bn.name
+            self.op(self.ops_bwd, "dl3_bn_bwd_finalize", dpart.data_ptr() + 4 * 2 * off, P, ldc, C, float(buf.M),
+                    self.wptr(n + "/gamma:0"), buf.vptr(V_MEAN, off), buf.vptr(V_INVSTD, off),
+                    1 if self.bn_batch else 0, buf.vptr(V_CA, off), buf.vptr(V_CB, off), buf.vptr(V_CC, off),
+                    self.gptr(n + "/gamma:0"), self.gptr(n + "/beta:0"))
+
+    def contrib_elementwise(self, buf, view, gin, ldgin, gin_div=1, gin_scale=1.0, drop=(0.0, 0)):
+        """contribution through dl3_grad_finish: gout = mask_view(gin) + existing; handles stats when last"""
+        gout, add, last = self.contrib_kernel(buf)
+        need_stat = last and bool(buf.bns)
+        P = self.lib.dl3_rows_partials(buf.M)
+        dpart = self.empty(P * buf.ld * 2) if need_stat else None
+        masked = view.act != ACT_NONE
+        need_x = masked or need_stat
+        if view.off != 0 or view.C != buf.ld:
+            raise NotImplementedError("element-wise gradient into a channel slice")
+        self.op(self.ops_bwd, "dl3_grad_finish", gin, ldgin, gin_div, gin_scale, ptr(gout), buf.ld,
+                ptr(add), buf.ld, ptr(buf.t) if need_x else None, buf.ld,
+                view.scale() if masked else None, view.shift() if masked else None, view.act,
+                buf.vptr(V_MEAN) if need_stat else None, buf.vptr(V_INVSTD) if need_stat else None, ptr(dpart),
+                buf.M, buf.ld, drop[0], drop[1])
+        if need_stat:
+            self.finish_bn_bwd(buf, dpart, P, buf.ld)
+
+    def contrib_passthrough(self, buf, view, g):
+        """Add backward: the gradient tensor g (same [M, C] shape, ld == C) flows unchanged into buf"""
+        if not buf.requires_grad:
+            return
+        if view.act != ACT_NONE or view.off != 0 or view.C != buf.ld or g.numel() != buf.M * buf.ld:
+            return self.contrib_elementwise(buf, view, ptr(g), view.C)
+        if buf.grad is None and buf.addend is None and buf.done == 0:
+            buf.done += 1
+            if buf.expected == 1:
+                buf.grad = g  # alias
+                if buf.bns:
+                    P = self.lib.dl3_rows_partials(buf.M)
+                    dpart = self.empty(P * buf.ld * 2)
+                    self.op(self.ops_bwd, "dl3_grad_finish", ptr(g), buf.ld, 1, 1.0, ptr(g), buf.ld, None, 0,
+                            ptr(buf.t), buf.ld, None, None, ACT_NONE, buf.vptr(V_MEAN), buf.vptr(V_INVSTD),
+                            ptr(dpart), buf.M, buf.ld, 0.0, 0)
+                    self.finish_bn_bwd(buf, dpart, P, buf.ld)
+            else:
+                buf.addend = g
+            return
+        self.contrib_elementwise(buf, view, ptr(g), buf.ld)
+
+    def grad_operand(self, out_view):
+        """(g, ldg, yraw, ldy, cA, cB, cC) of a conv whose output is out_view"""
+        buf = out_view.buf
+        g = buf.grad.data_ptr() + 4 * out_view.off
+        has_bn = any(off == out_view.off for _, off, _ in buf.bns)
+        if has_bn:
+            return (g, buf.ld, out_view.p(), buf.ld, buf.vptr(V_CA, out_view.off), buf.vptr(V_CB, out_view.off),
+                    buf.vptr(V_CC, out_view.off))
+        return (g, buf.ld, None, 0, None, None, None)
+
+    # ------------------------------------------------------------------ running
+    def _prep(self):
+        if self.dirty:
+            self.run_ops(self.ops_prep)
+            self.dirty = False
+
+    def set_input(self, x):
+        xt = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        self.xbuf.t.copy_(xt.reshape(-1).to(self.device, non_blocking=True))
+
+    def forward(self):
+        self._prep()
+        self.run_ops(self.ops_fwd)
+
+    def predict(self, x):
+        assert not self.training
+        self.set_input(x)
+        self.forward()
+        v = self.logits_view
+        capi.call("dl3_softmax_fwd", ptr(v.buf.t), ptr(self.probs), v.buf.M, v.C,
+                  torch.cuda.current_stream().cuda_stream)
+        return self.probs.cpu().numpy().reshape(self.out_shape)
+
+    def logits(self):
+        v = self.logits_view
+        return v.buf.t.cpu().numpy().reshape(self.B, v.buf.H, v.buf.W, v.C)
+
+    def argmax(self):
+        v = self.logits_view
+        out = torch.empty(v.buf.M, dtype=torch.int32, device=self.device)
+        capi.call("dl3_argmax", ptr(v.buf.t), out.data_ptr(), v.buf.M, v.C, torch.cuda.current_stream().cuda_stream)
+        return out.cpu().numpy().reshape(self.B, v.buf.H, v.buf.W)
+
+    def set_targets(self, y, sw=None):
+        M = self.logits_view.buf.M
+        yt = torch.from_numpy(np.ascontiguousarray(np.asarray(y, np.float32).reshape(-1)))
+        assert yt.numel() == M, (yt.numel(), M)
+        self.labels.copy_(yt.to(self.device))
+        if sw is None:
+            sw = (np.asarray(y).reshape(-1) != self.logits_view.C).astype(np.float32)
+        self.sweights.copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(sw, np.float32).reshape(-1))).to(self.device))
+
+    def fwd_bwd(self):
+        """forward + loss + backward on the resident batch (the benchmarked hot path)"""
+        self._prep()
+        if self.use_graph and self._calls >= 1:
+            if self.graph is None:
+                # the first call ran eagerly (module loading, allocator warm-up); capture one replayable hipGraph now
+                torch.cuda.synchronize()
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self.run_ops(self.ops_fwd)
+                        self.run_ops(self.ops_bwd)
+                    self.graph = g
+                except Exception as e:  # pragma: no cover - depends on the runtime
+                    print("dl3: hipGraph capture failed (%s); running eagerly" % e)
+                    self.use_graph = False
+                    torch.cuda.synchronize()
+                    return self.fwd_bwd()
+            self.graph.replay()
+        else:
+            self.run_ops(self.ops_fwd)
+            self.run_ops(self.ops_bwd)
+        self._calls += 1
+
+    def adam(self, opt=None, grad_scale=1.0):
+        """Keras Adam with decay (notebook cell 2): lr_t = lr/(1+decay*it) * sqrt(1-b2^t)/(1-b1^t)"""
+        o = dict(lr=7e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-8, decay=1e-6)
+        o.update(opt or {})
+        it = self.iteration
+        t = it + 1
+        lr = o["lr"] / (1.0 + o["decay"] * it)
+        lr_t = lr * math.sqrt(1.0 - o["beta_2"] ** t) / (1.0 - o["beta_1"] ** t)
+        capi.call("dl3_adam_step", ptr(self.params), ptr(self.grads), ptr(self.adam_m), ptr(self.adam_v),
+                  self.n_param, lr_t, o["beta_1"], o["beta_2"], o["epsilon"], grad_scale,
+                  torch.cuda.current_stream().cuda_stream)
+        self.iteration += 1
+        self.dirty = True
+
+    def train_step(self, x, y, sw=None, opt=None, comm=None):
+        self.set_input(x)
+        self.set_targets(y, sw)
+        self.fwd_bwd()
+        scale = 1.0
+        if comm is not None:
+            scale = comm.allreduce_grads(self.grads)
+        self.adam(opt, scale)
+        return float(self.loss[0].item())
+
+    def grad_of(self, name):
+        kind, off, n, shp, _ = self.slots[name]
+        assert kind == "p"
+        return self.grads[off:off + n].cpu().numpy().reshape(shp)
+
+
+# ======================================================================================
+# units
+# ======================================================================================
+
+
+class _ConvBase:
+    def __init__(self, eng, layer, inv, outv, want_stat):
+        self.eng, self.layer, self.inv, self.outv = eng, layer, inv, outv
+        self.bn = None
+        self.stat, self.P = None, 0
+        self.want_stat = want_stat
+        eng._consume(inv)
+
+    def wname(self):
+        return self.layer.name + "/kernel:0"
+
+
+class PwUnit(_ConvBase):
+    """Conv2D 1x1 (+bias): dl3_pwconv_fwd / _bwd_weight / _bwd_data"""
+
+    def __init__(self, eng, layer, inv, outv, want_stat):
+        super().__init__(eng, layer, inv, outv, want_stat)
+        self.M, self.K, self.N = inv.buf.M, inv.C, outv.C
+        self.bias = layer.name + "/bias:0" if layer.cfg["use_bias"] else None
+        if want_stat:
+            self.P = eng.lib.dl3_pwconv_partials(self.M, self.K, self.N)
+            self.stat = eng.empty(self.P * self.N * 2)
+        s, t, a = inv.xform()
+        eng.op(eng.ops_fwd, "dl3_pwconv_fwd", inv.p(), inv.ld, s, t, a, eng.wptr(self.wname()),
+               eng.wptr(self.bias) if self.bias else None, outv.p(), outv.ld, self.M, self.K, self.N, ptr(self.stat))
+
+    def bwd(self):
+        eng, inv, outv = self.eng, self.inv, self.outv
+        M, K, N = self.M, self.K, self.N
+        g, ldg, y, ldy, cA, cB, cC = eng.grad_operand(outv)
+        s, t, a = inv.xform()
+        if eng.trainable(self.wname()) or (self.bias and eng.trainable(self.bias)):
+            ws = eng.lib.dl3_pwconv_bwd_weight_workspace(M, K, N)
+            eng.op_ws(eng.ops_bwd, "dl3_pwconv_bwd_weight", ws, 17, inv.p(), inv.ld, s, t, a, g, ldg, y, ldy, cA, cB, cC,
+                      eng.gptr(self.wname()), eng.gptr(self.bias) if self.bias else None, M, K, N, 0, ws)
+        ibuf = inv.buf
+        if not ibuf.requires_grad:
+            return
+        wT = eng.empty(K * N)
+        eng.op(eng.ops_bwd, "dl3_transpose", eng.wptr(self.wname()), ptr(wT), K, N)
+        gout, add, last = eng.contrib_kernel(ibuf)
+        need_stat = last and bool(ibuf.bns)
+        P = eng.lib.dl3_pwconv_partials(M, N, K)
+        dpart = eng.empty(P * ibuf.ld * 2) if need_stat else None
+        if need_stat and (inv.off != 0 or inv.C != ibuf.ld):
+            raise NotImplementedError("BN-backward statistics through a channel slice")
+        need_x = a != ACT_NONE or need_stat
+        eng.op(eng.ops_bwd, "dl3_pwconv_bwd_data", g, ldg, y, ldy, cA, cB, cC, ptr(wT),
+               gout.data_ptr() + 4 * inv.off, ibuf.ld, inv.p() if need_x else None, inv.ld,
+               s if a != ACT_NONE else None, t if a != ACT_NONE else None, a,
+               (add.data_ptr() + 4 * inv.off) if add is not None else None, ibuf.ld, 1, 1.0,
+               ibuf.vptr(V_MEAN, inv.off) if need_stat else None, ibuf.vptr(V_INVSTD, inv.off) if need_stat else None,
+               ptr(dpart), M, K, N)
+        if need_stat:
+            eng.finish_bn_bwd(ibuf, dpart, P, ibuf.ld)
+
+
+class DwUnit(_ConvBase):
+    """DepthwiseConv2D 3x3: dl3_dwconv3x3_fwd / dl3_dwconv3x3_bwd (fused data+weight gradient)"""
+
+    def __init__(self, eng, layer, inv, outv, stride, rate, pt, pl, want_stat):
+        super().__init__(eng, layer, inv, outv, want_stat)
+        N, H, W, C = inv.shape
+        Ho, Wo = outv.buf.H, outv.buf.W
+        self.geom = (eng.B, H, W, C, stride, rate, pt, pl, Ho, Wo)
+        self.P = eng.lib.dl3_dwconv3x3_partials(eng.B, H, W, C, stride, rate, Ho, Wo, eng.dw_impl)
+        if want_stat:
+            self.stat = eng.empty(self.P * C * 2)
+        s, t, a = inv.xform()
+        eng.op(eng.ops_fwd, "dl3_dwconv3x3_fwd", inv.p(), s, t, a, eng.wptr(self.wname()), outv.p(), *self.geom,
+               ptr(self.stat), eng.dw_impl)
+
+    def wname(self):
+        return self.layer.name + "/depthwise_kernel:0"
+
+    def bwd(self):
+        eng, inv, outv = self.eng, self.inv, self.outv
+        C = inv.C
+        g, ldg, y, ldy, cA, cB, cC = eng.grad_operand(outv)
+        assert ldg == C
+        s, t, a = inv.xform()
+        ibuf = inv.buf
+        wpart = eng.empty(self.P * 9 * C)
+        gout = add = dpart = None
+        need_stat = False
+        if ibuf.requires_grad:
+            gout, add, last = eng.contrib_kernel(ibuf)
+            need_stat = last and bool(ibuf.bns)
+            dpart = eng.empty(self.P * C * 2) if need_stat else None
+        eng.op(eng.ops_bwd, "dl3_dwconv3x3_bwd", g, y, cA, cB, cC, inv.p(), s, t, a, eng.wptr(self.wname()),
+               ptr(gout), ptr(add), ibuf.vptr(V_MEAN) if need_stat else None,
+               ibuf.vptr(V_INVSTD) if need_stat else None, ptr(dpart), ptr(wpart), *self.geom, eng.dw_impl)
+        eng.op(eng.ops_bwd, "dl3_reduce_partials", ptr(wpart), self.P, 9 * C, eng.gptr(self.wname()))
+        if need_stat:
+            eng.finish_bn_bwd(ibuf, dpart, self.P, C)
+
+
+class Conv3Unit(_ConvBase):
+    """dense Conv2D 3x3 (stem)"""
+
+    def __init__(self, eng, layer, inv, outv, stride, pt, pl, want_stat):
+        super().__init__(eng, layer, inv, outv, want_stat)
+        N, H, W, Cin = inv.shape
+        Ho, Wo, Cout = outv.buf.H, outv.buf.W, outv.C
+        if inv.off != 0 or inv.ld != Cin or outv.off != 0 or outv.ld != Cout:
+            raise NotImplementedError("dense 3x3 conv on channel slices")
+        self.geom = (eng.B, H, W, Cin, Cout, stride, pt, pl, Ho, Wo)
+        self.P = eng.lib.dl3_conv3x3_partials(eng.B, Ho, Wo, Cout)
+        if want_stat:
+            self.stat = eng.empty(self.P * Cout * 2)
+        s, t, a = inv.xform()
+        eng.op(eng.ops_fwd, "dl3_conv3x3_fwd", inv.p(), s, t, a, eng.wptr(self.wname()), outv.p(), *self.geom,
+               ptr(self.stat))
+
+    def bwd(self):
+        eng, inv, outv = self.eng, self.inv, self.outv
+        B, H, W, Cin, Cout, stride, pt, pl, Ho, Wo = self.geom
+        g, ldg, y, ldy, cA, cB, cC = eng.grad_operand(outv)
+        s, t, a = inv.xform()
+        if eng.trainable(self.wname()):
+            wpart = eng.empty(self.P * 9 * Cin * Cout)
+            eng.op(eng.ops_bwd, "dl3_conv3x3_bwd_weight", inv.p(), s, t, a, g, y, cA, cB, cC, ptr(wpart), *self.geom)
+            eng.op(eng.ops_bwd, "dl3_reduce_partials", ptr(wpart), self.P, 9 * Cin * Cout, eng.gptr(self.wname()))
+        ibuf = inv.buf
+        if not ibuf.requires_grad:
+            return
+        gout, add, last = eng.contrib_kernel(ibuf)
+        need_stat = last and bool(ibuf.bns)
+        P = eng.lib.dl3_conv3x3_partials(B, H, W, Cin)
+        dpart = eng.empty(P * Cin * 2) if need_stat else None
+        need_x = a != ACT_NONE or need_stat
+        eng.op(eng.ops_bwd, "dl3_conv3x3_bwd_data", g, y, cA, cB, cC, eng.wptr(self.wname()), ptr(gout),
+               inv.p() if need_x else None, s if a != ACT_NONE else None, t if a != ACT_NONE else None, a, ptr(add),
+               ibuf.vptr(V_MEAN) if need_stat else None, ibuf.vptr(V_INVSTD) if need_stat else None, ptr(dpart),
+               *self.geom)
+        if need_stat:
+            eng.finish_bn_bwd(ibuf, dpart, P, Cin)
+
+
+class AddUnit:
+    """Add (deeplabv3p.py:147-149,:201): out = T(a) + T(b); backward = gradient aliases"""
+
+    def __init__(self, eng, a, b, outv):
+        self.eng, self.a, self.b, self.outv = eng, a, b, outv
+        eng._consume(a)
+        eng._consume(b)
+        sa, ta, aa = a.xform()
+        sb, tb, ab = b.xform()
+        eng.op(eng.ops_fwd, "dl3_affine_add", a.p(), a.ld, sa, ta, aa, b.p(), b.ld, sb, tb, ab, outv.p(), outv.ld,
+               outv.buf.M, outv.C, 0.0, 0)
+
+    def bwd(self):
+        g = self.outv.buf.grad
+        for v in (self.a, self.b):
+            self.eng.contrib_passthrough(v.buf, v, g)
+
+
+class MaterializeUnit:
+    """Dropout(0.1) in training mode (deeplabv3p.py:410): out = T(x) * keepmask/(1-rate)"""
+
+    def __init__(self, eng, inv, outv, rate, seed):
+        self.eng, self.inv, self.outv, self.rate, self.seed = eng, inv, outv, rate, seed
+        eng._consume(inv)
+        s, t, a = inv.xform()
+        eng.op(eng.ops_fwd, "dl3_affine_add", inv.p(), inv.ld, s, t, a, None, 0, None, None, ACT_NONE, outv.p(),
+               outv.ld, outv.buf.M, outv.C, rate, seed)
+
+    def bwd(self):
+        g = self.outv.buf.grad
+        self.eng.contrib_elementwise(self.inv.buf, self.inv, ptr(g), self.outv.ld, drop=(self.rate, self.seed))
+
+
+class GapUnit:
+    """global AveragePooling2D (deeplabv3p.py:375)"""
+
+    def __init__(self, eng, inv, outv):
+        self.eng, self.inv, self.outv = eng, inv, outv
+        eng._consume(inv)
+        s, t, a = inv.xform()
+        self.HW = inv.buf.H * inv.buf.W
+        eng.op(eng.ops_fwd, "dl3_gap_fwd", inv.p(), inv.ld, s, t, a, outv.p(), eng.B, self.HW, inv.C, 1.0 / self.HW)
+
+    def bwd(self):
+        g = self.outv.buf.grad
+        if not self.inv.buf.requires_grad:
+            return
+        self.eng.contrib_elementwise(self.inv.buf, self.inv, ptr(g), self.outv.ld, gin_div=self.HW,
+                                     gin_scale=1.0 / self.HW)
+
+
+class ResizeUnit:
+    """Lambda(tf.image.resize_bilinear) (deeplabv3p.py:382,:418,:439; utils.py:190)"""
+
+    def __init__(self, eng, inv, outv, Ho, Wo):
+        self.eng, self.inv, self.outv = eng, inv, outv
+        eng._consume(inv)
+        s, t, a = inv.xform()
+        self.dims = (eng.B, inv.buf.H, inv.buf.W, Ho, Wo, inv.C)
+        eng.op(eng.ops_fwd, "dl3_resize_bilinear_fwd", inv.p(), inv.ld, s, t, a, outv.p(), outv.ld, *self.dims)
+
+    def bwd(self):
+        eng, inv, outv = self.eng, self.inv, self.outv
+        ibuf = inv.buf
+        if not ibuf.requires_grad:
+            return
+        B, Hi, Wi, Ho, Wo, C = self.dims
+        g = outv.buf.grad.data_ptr() + 4 * outv.off
+        plain = inv.act == ACT_NONE and not ibuf.bns and inv.off == 0 and inv.C == ibuf.ld
+        if Hi == 1 and Wi == 1:
+            # a 1x1 source is a broadcast: its transpose is the per-image column sum
+            tmp = eng.empty(B * C)
+            eng.op(eng.ops_bwd, "dl3_gap_fwd", g, outv.ld, None, None, ACT_NONE, ptr(tmp), B, Ho * Wo, C, 1.0)
+            eng.contrib_elementwise(ibuf, inv, ptr(tmp), C)
+        elif plain:
+            gout, add, last = eng.contrib_kernel(ibuf)
+            eng.op(eng.ops_bwd, "dl3_resize_bilinear_bwd", g, outv.ld, ptr(gout), ibuf.ld, B, Hi, Wi, Ho, Wo, C,
+                   1 if add is not None else 0)
+            if add is not None and add is not gout:
+                raise NotImplementedError("resize backward with a foreign addend")
+        else:
+            tmp = eng.empty(ibuf.M * C)
+            eng.op(eng.ops_bwd, "dl3_resize_bilinear_bwd", g, outv.ld, ptr(tmp), C, B, Hi, Wi, Ho, Wo, C, 0)
+            eng.contrib_elementwise(ibuf, inv, ptr(tmp), C)
+
+
+class ShuffleUnit:
+    """Subpixel._phase_shift (subpixel.py:77-88)"""
+
+    def __init__(self, eng, inv, outv, r, co):
+        self.eng, self.inv, self.outv, self.r, self.co = eng, inv, outv, r, co
+        eng._consume(inv)
+        eng.op(eng.ops_fwd, "dl3_phase_shift", inv.p(), outv.p(), eng.B, inv.buf.H, inv.buf.W, co, r, 0)
+
+    def bwd(self):
+        eng, inv = self.eng, self.inv
+        gout, add, last = eng.contrib_kernel(inv.buf)
+        assert add is None and not inv.buf.bns
+        eng.op(eng.ops_bwd, "dl3_phase_shift", ptr(self.outv.buf.grad), ptr(gout), eng.B, inv.buf.H, inv.buf.W,
+               self.co, self.r, 1)

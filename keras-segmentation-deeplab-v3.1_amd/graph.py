@@ -1,0 +1,516 @@
+"""Host-side mirror of the small slice of the Keras functional API that the reference's hot path
+touches (deeplabv3p.py:29-40 imports; used at :47-206, :260-452; utils.py:181-198).
+
+Pure Python + numpy: layers only DECLARE the graph (names, hyper-parameters, weight shapes and
+host master copies of the weights).  All arithmetic happens in libdl3.so through engine.py.
+What callers of the reference touch is reproduced: `Model.input/.output/.layers/.name`,
+`layer.name/.output/.trainable/.get_weights()/.set_weights()`, `Model(inputs, outputs)` re-wiring
+(utils.py:181,:193,:198), Keras 2.2.4 layer ordering (`layers[-5]`) and auto-naming.
+"""
+import collections
+import math
+
+import numpy as np
+
+_uids = collections.defaultdict(int)
+_rng = np.random.default_rng(0)
+
+
+def clear_session(seed=0):
+    """keras.backend.clear_session(): reset auto-naming counters (and the weight-init RNG)."""
+    global _rng
+    _uids.clear()
+    _rng = np.random.default_rng(seed)
+
+
+def set_seed(seed):
+    global _rng
+    _rng = np.random.default_rng(seed)
+
+
+def _auto_name(prefix):
+    _uids[prefix] += 1
+    return "%s_%d" % (prefix, _uids[prefix])
+
+
+def glorot_uniform(shape, fan_in, fan_out):
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    return _rng.uniform(-lim, lim, shape).astype(np.float32)
+
+
+def glorot_normal(shape, fan_in, fan_out):
+    """tf.glorot_normal_initializer (default of icnr_weights, subpixel.py:9): truncated normal,
+    stddev = sqrt(2/(fan_in+fan_out))/.87962566 [TF-semantics]; the RNG stream itself is not
+    reproducible against TF, only the distribution."""
+    std = math.sqrt(2.0 / (fan_in + fan_out)) / 0.87962566103423978
+    v = _rng.normal(0.0, std, shape)
+    bad = np.abs(v) > 2 * std
+    while bad.any():
+        v[bad] = _rng.normal(0.0, std, int(bad.sum()))
+        bad = np.abs(v) > 2 * std
+    return v.astype(np.float32)
+
+
+class KTensor:
+    """Symbolic tensor: static shape without the batch axis, and the layer that produced it."""
+
+    def __init__(self, shape, layer):
+        self.shape = tuple(shape)
+        self.layer = layer
+        self._keras_shape = (None,) + self.shape  # read by the reference at deeplabv3p.py:168
+
+    def __repr__(self):
+        return "<KTensor %s from %s>" % (self.shape, self.layer.name)
+
+
+class Layer:
+    kind = "Layer"
+    prefix = "layer"
+
+    def __init__(self, name=None, **cfg):
+        self.name = name or _auto_name(self.prefix)
+        self.cfg = cfg
+        self.trainable = True
+        self.inbound = []
+        self.output = None
+        self.weights = collections.OrderedDict()  # "<layer>/<var>:0" -> np.ndarray (host master copy)
+        self._engine = None
+
+    # Keras: layer(x) / layer([a, b])
+    def __call__(self, x):
+        ins = list(x) if isinstance(x, (list, tuple)) else [x]
+        assert self.output is None, "layer %s called twice (shared layers are not on the path)" % self.name
+        self.inbound = ins
+        self.output = KTensor(self.compute_output_shape([t.shape for t in ins]), self)
+        self.build([t.shape for t in ins])
+        return self.output
+
+    @property
+    def input(self):
+        return self.inbound[0] if len(self.inbound) == 1 else self.inbound
+
+    def build(self, in_shapes):
+        pass
+
+    def compute_output_shape(self, in_shapes):
+        return in_shapes[0]
+
+    def weight_names(self):
+        return list(self.weights.keys())
+
+    def get_weights(self):
+        if self._engine is not None:
+            self._engine.sync_layer_to_host(self)
+        return [w.copy() for w in self.weights.values()]
+
+    def set_weights(self, ws):
+        names = list(self.weights.keys())
+        if len(ws) != len(names):
+            raise ValueError("layer %s expects %d weight arrays, got %d" % (self.name, len(names), len(ws)))
+        for n, w in zip(names, ws):
+            w = np.asarray(w, np.float32)
+            if w.shape != self.weights[n].shape:
+                raise ValueError("layer %s weight %s: shape %s != %s" % (self.name, n, w.shape, self.weights[n].shape))
+            self.weights[n] = w.copy()
+        if self._engine is not None:
+            self._engine.sync_layer_to_device(self)
+
+    def count_params(self):
+        return int(sum(w.size for w in self.weights.values()))
+
+
+class InputLayer(Layer):
+    kind = "InputLayer"
+    prefix = "input"
+
+
+def Input(shape=None, tensor=None, name=None):
+    """keras.layers.Input (deeplabv3p.py:261,:264).  `tensor` may be a numpy/torch array whose
+    trailing dims give the shape; it is remembered as the model's default feed."""
+    lyr = InputLayer(name=name)
+    if shape is None and tensor is not None:
+        shape = tuple(tensor.shape[1:])
+    lyr.output = KTensor(shape, lyr)
+    lyr.cfg["tensor"] = tensor
+    return lyr.output
+
+
+def _same_out(size, stride):
+    return -(-size // stride)
+
+
+class Conv2D(Layer):
+    """keras.layers.Conv2D restricted to what the path uses: k in {1,3}, dilation 1, groups 1."""
+    kind = "Conv2D"
+    prefix = "conv2d"
+
+    def __init__(self, filters, kernel_size, strides=(1, 1), padding="valid", use_bias=True, dilation_rate=(1, 1),
+                 activation=None, name=None, kernel_initializer="glorot_uniform", **kw):
+        super().__init__(name=name)
+        k = kernel_size[0] if isinstance(kernel_size, (tuple, list)) else kernel_size
+        s = strides[0] if isinstance(strides, (tuple, list)) else strides
+        r = dilation_rate[0] if isinstance(dilation_rate, (tuple, list)) else dilation_rate
+        assert activation is None and r == 1
+        self.cfg.update(filters=int(filters), k=int(k), stride=int(s), padding=padding, use_bias=bool(use_bias), rate=1)
+
+    def compute_output_shape(self, in_shapes):
+        H, W, _ = in_shapes[0]
+        c = self.cfg
+        if c["padding"] == "same":
+            return (_same_out(H, c["stride"]), _same_out(W, c["stride"]), c["filters"])
+        return ((H - c["k"]) // c["stride"] + 1, (W - c["k"]) // c["stride"] + 1, c["filters"])
+
+    def build(self, in_shapes):
+        cin, c = in_shapes[0][2], self.cfg
+        k, f = c["k"], c["filters"]
+        self.weights[self.name + "/kernel:0"] = glorot_uniform((k, k, cin, f), k * k * cin, k * k * f)
+        if c["use_bias"]:
+            self.weights[self.name + "/bias:0"] = np.zeros((f,), np.float32)
+
+
+class DepthwiseConv2D(Layer):
+    kind = "DepthwiseConv2D"
+    prefix = "depthwise_conv2d"
+
+    def __init__(self, kernel_size, strides=(1, 1), padding="valid", use_bias=True, dilation_rate=(1, 1),
+                 activation=None, name=None, **kw):
+        super().__init__(name=name)
+        k = kernel_size[0] if isinstance(kernel_size, (tuple, list)) else kernel_size
+        s = strides[0] if isinstance(strides, (tuple, list)) else strides
+        r = dilation_rate[0] if isinstance(dilation_rate, (tuple, list)) else dilation_rate
+        assert k == 3 and not use_bias and activation is None
+        self.cfg.update(k=3, stride=int(s), padding=padding, rate=int(r))
+
+    def compute_output_shape(self, in_shapes):
+        H, W, C = in_shapes[0]
+        c = self.cfg
+        if c["padding"] == "same":
+            return (_same_out(H, c["stride"]), _same_out(W, c["stride"]), C)
+        keff = (c["k"] - 1) * c["rate"] + 1
+        return ((H - keff) // c["stride"] + 1, (W - keff) // c["stride"] + 1, C)
+
+    def build(self, in_shapes):
+        C = in_shapes[0][2]
+        # Keras DepthwiseConv2D glorot fans: fan_in = kh*kw*C, fan_out = kh*kw*depth_multiplier
+        self.weights[self.name + "/depthwise_kernel:0"] = glorot_uniform((3, 3, C, 1), 9 * C, 9)
+
+
+class BatchNormalization(Layer):
+    kind = "BatchNormalization"
+    prefix = "batch_normalization"
+
+    def __init__(self, epsilon=1e-3, momentum=0.99, name=None, **kw):
+        super().__init__(name=name)
+        self.cfg.update(eps=float(epsilon), momentum=float(momentum))
+
+    def build(self, in_shapes):
+        C = in_shapes[0][-1]
+        n = self.name
+        self.weights[n + "/gamma:0"] = np.ones((C,), np.float32)
+        self.weights[n + "/beta:0"] = np.zeros((C,), np.float32)
+        self.weights[n + "/moving_mean:0"] = np.zeros((C,), np.float32)
+        self.weights[n + "/moving_variance:0"] = np.ones((C,), np.float32)
+
+
+class Activation(Layer):
+    """'relu', 'relu6' (the reference's Lambda(relu(x, max_value=6.)), deeplabv3p.py:181) or 'softmax'."""
+    kind = "Activation"
+    prefix = "activation"
+
+    def __init__(self, fn, name=None):
+        super().__init__(name=name)
+        assert fn in ("relu", "relu6", "softmax")
+        self.cfg["fn"] = fn
+
+
+class ReLU6(Activation):
+    """Lambda(lambda x: relu(x, max_value=6.)) — a Lambda layer in the reference, hence lambda_N auto-names."""
+    prefix = "lambda"
+
+    def __init__(self, name=None):
+        super().__init__("relu6", name=name)
+
+
+class Prescale(Layer):
+    """Lambda(lambda x: x/127.5 - 1) (deeplabv3p.py:270)"""
+    kind = "Prescale"
+    prefix = "lambda"
+
+
+class ResizeBilinear(Layer):
+    """Lambda(K.tf.image.resize_bilinear(x, size)) (deeplabv3p.py:382,:418,:439; utils.py:190)"""
+    kind = "ResizeBilinear"
+    prefix = "lambda"
+
+    def __init__(self, size, name=None):
+        super().__init__(name=name)
+        self.cfg["size"] = (int(size[0]), int(size[1]))
+
+    def compute_output_shape(self, in_shapes):
+        return self.cfg["size"] + (in_shapes[0][2],)
+
+
+class Add(Layer):
+    kind = "Add"
+    prefix = "add"
+
+    def compute_output_shape(self, in_shapes):
+        assert in_shapes[0] == in_shapes[1], in_shapes
+        return in_shapes[0]
+
+
+class Concatenate(Layer):
+    kind = "Concatenate"
+    prefix = "concatenate"
+
+    def compute_output_shape(self, in_shapes):
+        assert all(s[:2] == in_shapes[0][:2] for s in in_shapes), in_shapes
+        return in_shapes[0][:2] + (sum(s[2] for s in in_shapes),)
+
+
+class AveragePooling2D(Layer):
+    kind = "AveragePooling2D"
+    prefix = "average_pooling2d"
+
+    def __init__(self, pool_size, name=None):
+        super().__init__(name=name)
+        self.cfg["pool"] = (int(pool_size[0]), int(pool_size[1]))
+
+    def compute_output_shape(self, in_shapes):
+        H, W, C = in_shapes[0]
+        ph, pw = self.cfg["pool"]
+        if (H // ph, W // pw) != (1, 1):
+            raise NotImplementedError("only the global pooling of deeplabv3p.py:375 is on the path")
+        return (1, 1, C)
+
+
+class ZeroPadding2D(Layer):
+    kind = "ZeroPadding2D"
+    prefix = "zero_padding2d"
+
+    def __init__(self, padding, name=None):
+        super().__init__(name=name)
+        # Keras reads a 2-tuple of ints as symmetric (height, width) padding (deeplabv3p.py:68,:110)
+        ph, pw = padding
+        self.cfg["pad"] = ((int(ph), int(ph)), (int(pw), int(pw)))
+
+    def compute_output_shape(self, in_shapes):
+        H, W, C = in_shapes[0]
+        (pt, pb), (pl, pr) = self.cfg["pad"]
+        return (H + pt + pb, W + pl + pr, C)
+
+
+class Dropout(Layer):
+    kind = "Dropout"
+    prefix = "dropout"
+
+    def __init__(self, rate, name=None):
+        super().__init__(name=name)
+        self.cfg["rate"] = float(rate)
+
+
+class Reshape(Layer):
+    kind = "Reshape"
+    prefix = "reshape"
+
+    def __init__(self, target_shape, name=None):
+        super().__init__(name=name)
+        self.cfg["target"] = tuple(target_shape)
+
+    def compute_output_shape(self, in_shapes):
+        n = int(np.prod(in_shapes[0]))
+        tgt = list(self.cfg["target"])
+        if -1 in tgt:
+            known = int(np.prod([t for t in tgt if t != -1]))
+            tgt[tgt.index(-1)] = n // known
+        assert int(np.prod(tgt)) == n, (tgt, in_shapes)
+        return tuple(tgt)
+
+
+# --------------------------------------------------------------------------------------
+
+
+class Model:
+    """keras.models.Model(inputs, outputs, name): the sub-graph between `inputs` and `outputs`."""
+
+    def __init__(self, inputs, outputs, name=None):
+        self.name = name or _auto_name("model")
+        self.input = inputs
+        self.output = outputs
+        self._collect()
+        self._engines = {}
+        self._compiled = None
+
+    # -- graph -----------------------------------------------------------------------
+    def _collect(self):
+        """Keras 2.2.4 Network._init_graph_network ordering: DFS from the output
+        assigns visit indices (pre-order, inputs in call order), depth = longest path to the
+        output, layers sorted by decreasing depth then increasing visit index."""
+        out_layer = self.output.layer
+        in_layer = self.input.layer
+        index, depth = {}, {}
+        finished = set()
+
+        def visit(start):
+            # iterative form of Keras' recursive build_map: a layer gets its index when it is first
+            # ENTERED (pre-order); inbound layers are entered in call order; finished layers are skipped
+            stack = [(start, 0)]
+            while stack:
+                lyr, i = stack.pop()
+                if i == 0:
+                    if lyr in finished:
+                        continue
+                    if lyr not in index:
+                        index[lyr] = len(index)
+                ins = [] if lyr is in_layer else lyr.inbound
+                if i < len(ins):
+                    stack.append((lyr, i + 1))
+                    stack.append((ins[i].layer, 0))
+                else:
+                    finished.add(lyr)
+
+        visit(out_layer)
+        if in_layer not in index:
+            raise ValueError("graph disconnected: the input is not an ancestor of the output")
+        # topological (creation) order: every layer's inputs precede it
+        topo = []
+        seen = set()
+
+        def topo_visit(layer):
+            stack = [(layer, 0)]
+            while stack:
+                lyr, i = stack.pop()
+                if lyr in seen:
+                    continue
+                ins = lyr.inbound if lyr is not in_layer else []
+                if i < len(ins):
+                    stack.append((lyr, i + 1))
+                    if ins[i].layer not in seen:
+                        stack.append((ins[i].layer, 0))
+                else:
+                    seen.add(lyr)
+                    topo.append(lyr)
+
+        topo_visit(out_layer)
+        self._topo = topo
+        # depth = longest path to the output, relaxed in reverse topological order
+        for lyr in topo:
+            depth[lyr] = 0
+        for lyr in reversed(topo):
+            ins = lyr.inbound if lyr is not in_layer else []
+            for t in ins:
+                depth[t.layer] = max(depth[t.layer], depth[lyr] + 1)
+        self.layers = sorted(topo, key=lambda l: (-depth[l], index[l]))
+        self._by_name = {l.name: l for l in self.layers}
+
+    def get_layer(self, name=None, index=None):
+        if index is not None:
+            return self.layers[index]
+        return self._by_name[name]
+
+    @property
+    def weights(self):
+        return [n for l in self.layers for n in l.weights]
+
+    def count_params(self):
+        return sum(l.count_params() for l in self.layers)
+
+    def trainable_count(self):
+        n = 0
+        for l in self.layers:
+            if not l.trainable:
+                continue
+            for k, w in l.weights.items():
+                if "/moving_" not in k:
+                    n += w.size
+        return int(n)
+
+    def summary(self, print_fn=print):
+        print_fn('Model: "%s"' % self.name)
+        for l in self.layers:
+            print_fn("%-48s %-22s %-18s %9d" % (l.name, l.kind, l.output.shape, l.count_params()))
+        print_fn("Total params: %d   Trainable params: %d" % (self.count_params(), self.trainable_count()))
+
+    # -- weights -----------------------------------------------------------------------
+    def get_weights(self):
+        return [w for l in self.layers for w in l.get_weights()]
+
+    def set_weights(self, ws):
+        i = 0
+        for l in self.layers:
+            n = len(l.weights)
+            if n:
+                l.set_weights(ws[i:i + n])
+                i += n
+
+    def save_weights(self, path):
+        from . import h5io
+        h5io.save_weights(self, path)
+
+    def load_weights(self, path, by_name=False):
+        from . import h5io
+        h5io.load_weights(self, path, by_name=by_name)
+
+    # -- execution (delegated to the HIP engine) ----------------------------------------
+    def compile(self, optimizer=None, loss=None, metrics=None, sample_weight_mode=None, **kw):
+        """keras Model.compile as used by the notebook (cell 2): remembers the optimizer
+        hyper-parameters; the loss on the path is always sparse_crossentropy_ignoring_last_label
+        with temporal sample weights (utils.py:127-130)."""
+        self._compiled = dict(optimizer=optimizer, loss=loss, metrics=metrics, sample_weight_mode=sample_weight_mode)
+
+    def _engine(self, batch, training, **kw):
+        """engine for (batch, mode); weights travel through the host master copies when the active engine changes"""
+        from .engine import Engine
+        key = (int(batch), bool(training), tuple(sorted(kw.items())))
+        eng = self._engines.get(key)
+        active = getattr(self, "_active", None)
+        if eng is not active and active is not None:
+            active.sync_all_to_host()
+        if eng is None:
+            eng = Engine(self, batch=int(batch), training=training, **kw)
+            self._engines[key] = eng
+        elif eng is not active:
+            eng.sync_all_to_device()
+        self._active = eng
+        eng.activate()
+        return eng
+
+    def predict(self, x, batch_size=32, verbose=0):
+        x = np.asarray(x, np.float32) if not hasattr(x, "data_ptr") else x
+        n = x.shape[0]
+        bs = min(int(batch_size), n)
+        outs = []
+        for i in range(0, n, bs):
+            xb = x[i:i + bs]
+            eng = self._engine(xb.shape[0], False)
+            outs.append(eng.predict(xb))
+        return np.concatenate(outs, axis=0)
+
+    def train_on_batch(self, x, y, sample_weight=None, **engine_kw):
+        eng = self._engine(x.shape[0], True, **engine_kw)
+        opt = (self._compiled or {}).get("optimizer") or {}
+        return eng.train_step(x, y, sample_weight, opt)
+
+    def fit(self, x, y, batch_size=16, epochs=1, sample_weight=None, verbose=0, **kw):
+        """Minimal Model.fit (utils.py:244): plain epochs over (x, y) without shuffling or callbacks."""
+        hist = []
+        n = x.shape[0]
+        for _ in range(epochs):
+            for i in range(0, n - batch_size + 1, batch_size):
+                sw = None if sample_weight is None else sample_weight[i:i + batch_size]
+                hist.append(self.train_on_batch(x[i:i + batch_size], y[i:i + batch_size], sw))
+        return hist
+
+    def fit_generator(self, generator, steps_per_epoch=None, epochs=1, verbose=0, **kw):
+        """Minimal Model.fit_generator (utils.py:233): generator yields (X, Y, {'pred_mask': SW}) or (X, Y, SW)."""
+        hist = []
+        steps = steps_per_epoch or len(generator)
+        for _ in range(epochs):
+            for i in range(steps):
+                item = generator[i] if hasattr(generator, "__getitem__") else next(generator)
+                X, Y = item[0], item[1]
+                SW = item[2] if len(item) > 2 else None
+                if isinstance(SW, dict):
+                    SW = list(SW.values())[0]
+                hist.append(self.train_on_batch(X, Y, SW))
+        return hist

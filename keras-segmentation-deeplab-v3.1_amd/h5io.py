@@ -1,0 +1,91 @@
+"""Keras weight-file I/O for the model mirror (reference: model.load_weights(path, by_name=True)
+deeplabv3p.py:465; positional load utils.py:207,:229; ModelCheckpoint(save_weights_only=True) notebook cell 5).
+
+Layout [TF-semantics: Keras 2.2.x save_weights] — root attrs `layer_names`, `backend`, `keras_version`;
+one group per layer with attr `weight_names`; datasets `/<layer>/<layer>/<var>:0`, float32, HWIO.
+`.h5` files need h5py (absent from this image's main interpreter — probed at call time); the same
+content is always readable/writable as `.npz` with keys "<layer>/<var>:0" plus "__layer_names__".
+"""
+import numpy as np
+
+
+def _h5py():
+    try:
+        import h5py
+        return h5py
+    except ImportError:
+        return None
+
+
+def _is_npz(path):
+    return str(path).endswith(".npz")
+
+
+def save_weights(model, path):
+    layers = model.layers
+    if _is_npz(path):
+        d = {"__layer_names__": np.array([l.name for l in layers], dtype="S")}
+        for l in layers:
+            for n, w in zip(l.weights.keys(), l.get_weights()):
+                d[n] = w
+        np.savez(path, **d)
+        return
+    h5py = _h5py()
+    if h5py is None:
+        raise ImportError("saving Keras .h5 weights needs h5py; use a .npz path (same keys) on this machine")
+    with h5py.File(path, "w", libver="earliest") as f:
+        f.attrs["layer_names"] = np.array([l.name.encode() for l in layers], dtype="S")
+        f.attrs["backend"] = b"tensorflow"
+        f.attrs["keras_version"] = b"2.2.4"
+        for l in layers:
+            g = f.create_group(l.name)
+            names = list(l.weights.keys())
+            g.attrs["weight_names"] = np.array([n.encode() for n in names], dtype="S") if names else np.zeros((0,), "S1")
+            for n, w in zip(names, l.get_weights()):
+                g.create_dataset(n, data=np.asarray(w, np.float32))
+
+
+def _read_file(path):
+    """-> (layer_names, {layer: [(weight_name, array), ...]})"""
+    if _is_npz(path):
+        z = np.load(path)
+        names = [n.decode() for n in z["__layer_names__"]]
+        per = {n: [] for n in names}
+        for k in z.files:
+            if k == "__layer_names__":
+                continue
+            per.setdefault(k.split("/")[0], []).append((k, z[k]))
+        return names, per
+    h5py = _h5py()
+    if h5py is None:
+        raise ImportError("reading Keras .h5 weights needs h5py, which this interpreter lacks; convert the file to "
+                          ".npz (keys '<layer>/<var>:0') on a machine that has it")
+    with h5py.File(path, "r") as f:
+        root = f["model_weights"] if "model_weights" in f else f
+        dec = lambda s: s.decode() if isinstance(s, bytes) else str(s)
+        names = [dec(n) for n in root.attrs["layer_names"]]
+        per = {}
+        for n in names:
+            g = root[n]
+            per[n] = [(dec(w), np.asarray(g[dec(w)])) for w in g.attrs["weight_names"]]
+        return names, per
+
+
+def load_weights(model, path, by_name=False):
+    names, per = _read_file(path)
+    if by_name:
+        # Keras load_weights_from_hdf5_group_by_name: layers matched by name, others left untouched
+        for l in model.layers:
+            if l.weights and l.name in per and per[l.name]:
+                arrs = [a for _, a in per[l.name]]
+                if len(arrs) != len(l.weights):
+                    raise ValueError("layer %s: file has %d arrays, model expects %d" % (l.name, len(arrs), len(l.weights)))
+                l.set_weights(arrs)
+        return
+    # positional: weight-bearing layers zipped in order (utils.py:207)
+    file_layers = [n for n in names if per.get(n)]
+    model_layers = [l for l in model.layers if l.weights]
+    if len(file_layers) != len(model_layers):
+        raise ValueError("file holds %d weight-bearing layers, model has %d" % (len(file_layers), len(model_layers)))
+    for n, l in zip(file_layers, model_layers):
+        l.set_weights([a for _, a in per[n]])

@@ -1,0 +1,62 @@
+"""Per-image data parallelism: one process per GPU, RCCL all-reduce of the flat gradient arena.
+
+Replaces the reference's single-process in-graph `keras.utils.multi_gpu_model` (utils.py:209-211), which
+splits the batch across towers and merges on the CPU with no collectives.  Here every rank owns B images
+(BatchNorm statistics stay per replica, exactly like the reference's towers), runs the same plan, and ONE
+all-reduce(sum) of the flat fp32 gradient arena (8.45 MB for MobileNetV2) crosses xGMI per step; the 1/world
+factor is folded into the Adam kernel (dl3_adam_step grad_scale).  torch.distributed backend "nccl" IS RCCL on
+ROCm; "gloo" is used by the CPU tests.  The path has no other exchange step, so there is no other collective.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class DataParallel:
+    def __init__(self, backend=None, device=None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = device
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        self.backend = backend
+        if self.world > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            if backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+
+    def shard(self, n_global):
+        """contiguous image shard [lo, hi) of this rank (global batch = B * world)"""
+        per = n_global // self.world
+        return self.rank * per, (self.rank + 1) * per
+
+    def allreduce_grads(self, flat):
+        """sum the flat gradient arena over ranks in place; returns the scale the optimizer must apply"""
+        if self.world > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        return 1.0 / self.world
+
+    def broadcast(self, flat, src=0):
+        """identical initial weights / Adam state on every rank"""
+        if self.world > 1:
+            dist.broadcast(flat, src=src)
+
+    def max_over_ranks(self, value):
+        if self.world == 1:
+            return float(value)
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier()
+
+    def close(self):
+        if self.world > 1 and dist.is_initialized():
+            dist.destroy_process_group()

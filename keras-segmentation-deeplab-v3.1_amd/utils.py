@@ -1,0 +1,111 @@
+"""Host-side mirror of the parts of the reference's utils.py that sit on the hot path:
+`SegModel.create_seg_model` head surgery (utils.py:169-214), the loss
+`sparse_crossentropy_ignoring_last_label` (utils.py:127-130) — executed on the GPU by
+dl3_softmax_xent — and host restatements of the metrics that the north star leaves on the host
+(`Jaccard` utils.py:139-157, `sparse_accuracy_ignoring_last_label` utils.py:132-138).
+Out of scope by the SURVEY §8 contract: SegmentationGenerator, do_crf, plotting.
+"""
+import numpy as np
+
+from . import graph as G
+from .deeplabv3p import Deeplabv3
+from .graph import Activation, Conv2D, Model, Reshape, ResizeBilinear
+from .subpixel import Subpixel, icnr_weights
+
+
+def sparse_crossentropy_ignoring_last_label(y_true, y_pred):
+    """Marker for Model.compile(loss=...): the engine's training step always evaluates this loss
+    (utils.py:127-130) on the GPU; calling it on host arrays evaluates the same formula in numpy."""
+    y_true = np.asarray(y_true)
+    p = np.asarray(y_pred, np.float64)
+    C = p.shape[-1]
+    t = y_true[:, :, 0].astype(np.int64)
+    q = np.clip(p / p.sum(-1, keepdims=True), 1e-7, 1 - 1e-7)
+    valid = t < C
+    out = np.zeros(t.shape)
+    b, i = np.nonzero(valid)
+    out[b, i] = -np.log(q[b, i, t[b, i]])
+    return out
+
+
+def sparse_accuracy_ignoring_last_label(y_true, y_pred):
+    """utils.py:132-138 on host."""
+    C = y_pred.shape[-1]
+    t = np.asarray(y_true).reshape(-1).astype(np.int64)
+    pred = np.asarray(y_pred).reshape(-1, C).argmax(-1)
+    legal = t != C
+    return float((legal & (t == pred)).sum() / max(legal.sum(), 1))
+
+
+def Jaccard(y_true, y_pred):
+    """utils.py:139-157 on host: per class, IoU per image averaged over images containing the class;
+    classes that occur nowhere (NaN) are dropped; mean over the remaining classes."""
+    y_true = np.asarray(y_true)
+    C = y_pred.shape[-1]
+    pred = np.asarray(y_pred).argmax(-1)
+    t = y_true[:, :, 0]
+    ious = []
+    for i in range(C):
+        tl, pl = t == i, pred == i
+        legal = tl.sum(axis=1) > 0
+        if legal.any():
+            inter = (tl & pl).sum(axis=1)[legal]
+            union = (tl | pl).sum(axis=1)[legal]
+            ious.append(float(np.mean(inter / union)))
+    return float(np.mean(ious)) if ious else float("nan")
+
+
+class SegModel:
+    """utils.py:160-254 — only model construction is on the path."""
+    epochs = 20
+    batch_size = 16
+
+    def __init__(self, dataset="VOCdevkit/VOC2012", image_size=(320, 320)):
+        self.sz = tuple(image_size)
+        self.mainpath = dataset
+        self.crop = False
+
+    def create_seg_model(self, net, n=21, backbone="mobilenetv2", load_weights=False, multi_gpu=False):
+        """net='original': DeepLabV3+ body + conv_upsample 1x1 + bilinear (utils.py:188-193);
+        net='subpixel': body + Subpixel(n, 1, scale) with ICNR init (utils.py:194-204).
+        The body is Deeplabv3(weights=None, classes=21, OS=16) cut at model.layers[-5] (utils.py:177-181).
+        multi_gpu: the reference's in-graph keras.utils.multi_gpu_model (utils.py:209-211) is replaced by
+        one process per GPU + RCCL gradient all-reduce (parallel.py); the flag is accepted and ignored here."""
+        model = Deeplabv3(weights=None, input_tensor=None, infer=False, input_shape=self.sz + (3,), classes=21,
+                          backbone=backbone, OS=16, alpha=1)
+        base_model = Model(model.input, model.layers[-5].output)
+        self.net = net
+        self.modelpath = "weights/{}_{}.h5".format(backbone, net)
+        scale = 4 if backbone == "xception" else 8
+        if net == "original":
+            x = Conv2D(n, (1, 1), padding="same", name="conv_upsample")(base_model.output)
+            x = ResizeBilinear((self.sz[0], self.sz[1]))(x)
+            x = Reshape((self.sz[0] * self.sz[1], -1))(x)
+            x = Activation("softmax", name="pred_mask")(x)
+            model = Model(base_model.input, x, name="deeplabv3p")
+        elif net == "subpixel":
+            x = Subpixel(n, 1, scale, padding="same")(base_model.output)
+            x = Reshape((self.sz[0] * self.sz[1], -1))(x)
+            x = Activation("softmax", name="pred_mask")(x)
+            model = Model(base_model.input, x, name="deeplabv3p_subpixel")
+        else:
+            raise ValueError("net must be 'original' or 'subpixel'")
+        for layer in model.layers:  # ICNR re-initialisation (utils.py:200-204)
+            if type(layer) == Subpixel:
+                c, b = layer.get_weights()
+                layer.set_weights([icnr_weights(scale=scale, shape=c.shape), b])
+        if load_weights:
+            model.load_weights(self.modelpath)
+        self.model = model
+        return model
+
+    def load_weights(self, model):
+        model.load_weights(self.modelpath)
+
+    @classmethod
+    def set_num_epochs(cls, new_epochs):
+        cls.epochs = new_epochs
+
+    @classmethod
+    def set_batch_size(cls, new_batch_size):
+        cls.batch_size = new_batch_size

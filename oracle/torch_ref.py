@@ -1,0 +1,213 @@
+"""Second, independent CPU restatement (torch autograd) — TEST INFRASTRUCTURE ONLY.
+
+Written against the same reference lines as oracle/dl3_oracle.py but with different machinery
+(NCHW torch.nn.functional convolutions with explicit F.pad, F.batch_norm, autograd for every
+gradient), so that an error in the hand-written numpy forward/backward formulas shows up as a
+disagreement (tests/test_oracle.py).  It also serves as the labelled "framework CPU path" proxy
+(torch/oneDNN on the host cores) in bench.py's cpu_baseline leg, because the reference's own
+Keras/TensorFlow CPU path cannot be installed here.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import dl3_oracle as O
+
+
+def _same(size, k, s, r):
+    out, beg, end = O.same_pads(size, k, s, r)
+    return beg, end
+
+
+def _explicit(size, k, s, r):
+    out, beg, end = O.explicit_pads(size, k, s, r)
+    return beg, end
+
+
+class Ref:
+    def __init__(self, params, training, dropout_mask=None, bn_frozen=False, dtype=torch.float32):
+        self.np_params = params
+        self.t = {}
+        for k, v in params.items():
+            t = torch.tensor(np.asarray(v), dtype=dtype)
+            if not k.split("/")[-1].startswith("moving"):
+                t.requires_grad_(True)
+            self.t[k] = t
+        self.training = training
+        self.dropout_mask = dropout_mask
+        self.bn_frozen = bn_frozen
+        self.dtype = dtype
+
+    # x is NCHW throughout
+    def conv(self, x, name, k=1, stride=1, same=True, bias=False):
+        w = self.t[name + "/kernel:0"].permute(3, 2, 0, 1)  # HWIO -> OIHW
+        H, W = x.shape[2], x.shape[3]
+        if k == 1 and stride > 1:
+            pads = (0, 0, 0, 0)
+        else:
+            fn = _same if same else _explicit
+            pt, pb = fn(H, k, stride, 1)
+            pl, pr = fn(W, k, stride, 1)
+            pads = (pl, pr, pt, pb)
+        x = F.pad(x, pads)
+        b = self.t[name + "/bias:0"] if bias else None
+        return F.conv2d(x, w, b, stride=stride)
+
+    def dw(self, x, name, stride=1, rate=1, same=True):
+        w = self.t[name + "/depthwise_kernel:0"].permute(2, 3, 0, 1)  # (3,3,C,1) -> (C,1,3,3)
+        H, W = x.shape[2], x.shape[3]
+        fn = _same if same else _explicit
+        pt, pb = fn(H, 3, stride, rate)
+        pl, pr = fn(W, 3, stride, rate)
+        x = F.pad(x, (pl, pr, pt, pb))
+        return F.conv2d(x, w, None, stride=stride, dilation=rate, groups=x.shape[1])
+
+    def bn(self, x, name, eps=1e-3):
+        g, b = self.t[name + "/gamma:0"], self.t[name + "/beta:0"]
+        mm, mv = self.t[name + "/moving_mean:0"], self.t[name + "/moving_variance:0"]
+        if self.training and not self.bn_frozen:
+            return F.batch_norm(x, None, None, g, b, True, 0.0, eps)
+        return F.batch_norm(x, mm, mv, g, b, False, 0.0, eps)
+
+    def resize(self, x, Ho, Wo):
+        Hi, Wi = x.shape[2], x.shape[3]
+        ylo, yhi, wy = O._tf1_lerp(Ho, Hi)
+        xlo, xhi, wx = O._tf1_lerp(Wo, Wi)
+        ylo, yhi, xlo, xhi = [torch.as_tensor(a) for a in (ylo, yhi, xlo, xhi)]
+        wy = torch.tensor(wy, dtype=x.dtype)[None, None, :, None]
+        wx = torch.tensor(wx, dtype=x.dtype)[None, None, None, :]
+        top_rows, bot_rows = x.index_select(2, ylo), x.index_select(2, yhi)
+        tl, tr = top_rows.index_select(3, xlo), top_rows.index_select(3, xhi)
+        bl, br = bot_rows.index_select(3, xlo), bot_rows.index_select(3, xhi)
+        top = tl + (tr - tl) * wx
+        bot = bl + (br - bl) * wx
+        return top + (bot - top) * wy
+
+    def sepconv(self, x, prefix, stride=1, rate=1, depth_activation=False, eps=1e-3):
+        if not depth_activation:
+            x = F.relu(x)
+        x = self.bn(self.dw(x, prefix + "_depthwise", stride, rate, same=(stride == 1)), prefix + "_depthwise_BN", eps)
+        if depth_activation:
+            x = F.relu(x)
+        x = self.bn(self.conv(x, prefix + "_pointwise"), prefix + "_pointwise_BN", eps)
+        if depth_activation:
+            x = F.relu(x)
+        return x
+
+    def xblock(self, x, prefix, skip_type, stride, rate=1, depth_activation=False, return_skip=False):
+        res, skip = x, None
+        for i in range(3):
+            res = self.sepconv(res, prefix + "_separable_conv%d" % (i + 1), stride if i == 2 else 1, rate,
+                               depth_activation)
+            if i == 1:
+                skip = res
+        if skip_type == "conv":
+            sc = self.bn(self.conv(x, prefix + "_shortcut", 1, stride), prefix + "_shortcut_BN")
+            out = res + sc
+        elif skip_type == "sum":
+            out = res + x
+        else:
+            out = res
+        return (out, skip) if return_skip else out
+
+    def features(self, x, backbone, input_shape, OS):
+        H, W = input_shape[0], input_shape[1]
+        x = x / 127.5 - 1.0
+        skip1 = None
+        if backbone == "xception":
+            if OS == 8:
+                e3, mr, er, atrous = 1, 2, (2, 4), (12, 24, 36)
+            else:
+                e3, mr, er, atrous = 2, 1, (1, 2), (6, 12, 18)
+            x = F.relu(self.bn(self.conv(x, "entry_flow_conv1_1", 3, 2), "entry_flow_conv1_1_BN"))
+            x = F.relu(self.bn(self.conv(x, "entry_flow_conv1_2", 3, 1), "entry_flow_conv1_2_BN"))
+            x = self.xblock(x, "entry_flow_block1", "conv", 2)
+            x, skip1 = self.xblock(x, "entry_flow_block2", "conv", 2, return_skip=True)
+            x = self.xblock(x, "entry_flow_block3", "conv", e3)
+            for i in range(16):
+                x = self.xblock(x, "middle_flow_unit_%d" % (i + 1), "sum", 1, mr)
+            x = self.xblock(x, "exit_flow_block1", "conv", 1, er[0])
+            x = self.xblock(x, "exit_flow_block2", "none", 1, er[1], depth_activation=True)
+        else:
+            OS = 8
+            x = F.relu6(self.bn(self.conv(x, "Conv", 3, 2), "Conv_BN"))
+            for bid, filters, stride, expansion, skip, rate in O.MNV2_BLOCKS:
+                inp = x
+                prefix = "expanded_conv_%d_" % bid if bid else "expanded_conv_"
+                if bid:
+                    x = F.relu6(self.bn(self.conv(x, prefix + "expand"), prefix + "expand_BN"))
+                x = F.relu6(self.bn(self.dw(x, prefix + "depthwise", stride, rate), prefix + "depthwise_BN"))
+                x = self.bn(self.conv(x, prefix + "project"), prefix + "project_BN")
+                if skip:
+                    x = inp + x
+        fh, fw = math.ceil(H / OS), math.ceil(W / OS)
+        b4 = x.mean(dim=(2, 3), keepdim=True)
+        b4 = F.relu(self.bn(self.conv(b4, "image_pooling"), "image_pooling_BN", 1e-5))
+        b4 = self.resize(b4, fh, fw)
+        b0 = F.relu(self.bn(self.conv(x, "aspp0"), "aspp0_BN", 1e-5))
+        if backbone == "xception":
+            bs = [self.sepconv(x, "aspp%d" % (i + 1), 1, atrous[i], True, 1e-5) for i in range(3)]
+            x = torch.cat([b4, b0] + bs, dim=1)
+        else:
+            x = torch.cat([b4, b0], dim=1)
+        x = F.relu(self.bn(self.conv(x, "concat_projection"), "concat_projection_BN", 1e-5))
+        if self.training and self.dropout_mask is not None:
+            m = torch.tensor(self.dropout_mask, dtype=x.dtype).permute(0, 3, 1, 2)
+            x = x * m * (1.0 / 0.9)
+        if backbone == "xception":
+            x = self.resize(x, math.ceil(H / 4), math.ceil(W / 4))
+            d = F.relu(self.bn(self.conv(skip1, "feature_projection0"), "feature_projection0_BN", 1e-5))
+            x = torch.cat([x, d], dim=1)
+            x = self.sepconv(x, "decoder_conv0", 1, 1, True, 1e-5)
+            x = self.sepconv(x, "decoder_conv1", 1, 1, True, 1e-5)
+        return x
+
+    def logits(self, x_nhwc, backbone="mobilenetv2", input_shape=(512, 512, 3), classes=21, OS=16, head="deeplab",
+               subpixel_name="subpixel_1"):
+        x = torch.tensor(np.asarray(x_nhwc), dtype=self.dtype).permute(0, 3, 1, 2)
+        f = self.features(x, backbone, input_shape, OS)
+        H, W = input_shape[0], input_shape[1]
+        if head == "subpixel":
+            r = 4 if backbone == "xception" else 8
+            y = self.conv(f, subpixel_name, bias=True)  # [N, C*r*r, a, b]
+            N, c, a, b = y.shape
+            co = c // (r * r)
+            # out[n, ia*r+q, ib*r+p, ch] = I[n, ia, ib, ch*r*r + p*r + q]  (subpixel.py:77-88)
+            y = y.reshape(N, co, r, r, a, b)           # [n, ch, p, q, ia, ib]
+            y = y.permute(0, 1, 4, 3, 5, 2)            # [n, ch, ia, q, ib, p]
+            y = y.reshape(N, co, a * r, b * r)
+        else:
+            name = "conv_upsample" if head == "original" else (
+                "logits_semantic" if classes == 21 else "custom_logits_semantic")
+            y = self.resize(self.conv(f, name, bias=True), H, W)
+        return y.permute(0, 2, 3, 1)  # NHWC
+
+    def loss(self, logits, labels, weights):
+        B, H, W, C = logits.shape
+        lg = logits.reshape(B, H * W, C)
+        t = torch.tensor(np.asarray(labels).reshape(B, H * W)).long()
+        w = torch.tensor(np.asarray(weights).reshape(B, H * W), dtype=self.dtype)
+        onehot = F.one_hot(t, C + 1)[..., :C].to(self.dtype)  # utils.py:129
+        p = torch.softmax(lg, dim=-1)
+        q = p / p.sum(dim=-1, keepdim=True)
+        # the clip is applied to the VALUE only, so that (like the oracle) its gradient is (p-y)w/nnz
+        q = q + (q.clamp(1e-7, 1 - 1e-7) - q).detach()
+        l = -(onehot * torch.log(q)).sum(dim=-1)
+        nnz = max(float((w != 0).sum()), 1.0)
+        return (l * w).sum() / nnz
+
+
+def train_grads(params, x, labels, weights, dropout_mask=None, bn_frozen=False, dtype=torch.float32, **kw):
+    ref = Ref(params, True, dropout_mask, bn_frozen, dtype)
+    logits = ref.logits(x, **kw)
+    loss = ref.loss(logits, labels, weights)
+    loss.backward()
+    grads = {k: (None if t.grad is None else t.grad.numpy()) for k, t in ref.t.items() if t.requires_grad}
+    return float(loss.detach()), grads, logits.detach().numpy()
+
+
+def infer_logits(params, x, dtype=torch.float32, **kw):
+    with torch.no_grad():
+        return Ref(params, False, dtype=dtype).logits(x, **kw).numpy()

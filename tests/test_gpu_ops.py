@@ -1,0 +1,508 @@
+"""-m gpu parity tests: every libdl3.so operator, called through the C ABI, against the numpy oracle
+(oracle/dl3_oracle.py) on the same seeded inputs.  fp32 tolerance: max|a-b| <= TOL * max|b|."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dl3_oracle as O
+from tests.gpu_util import (call, dev, empty, fold_partials, host, np_act, np_mask, ptr, relerr, stream)
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def L():
+    import dl3_amd  # noqa: F401
+    from dl3_amd import capi
+    return capi.lib()
+
+
+def _xform(rng, C, act):
+    if act is None:
+        return None, None, 0
+    s = rng.uniform(0.5, 1.5, C).astype(np.float32)
+    t = rng.normal(0, 0.5, C).astype(np.float32)
+    return s, t, act
+
+
+DW_CASES = [
+    # N, H, W, C, stride, rate, (pad_t, pad_l) or None=SAME, impl, act
+    (2, 16, 16, 32, 1, 1, None, 0, None),
+    (2, 16, 16, 96, 1, 2, None, 0, 2),
+    (1, 32, 32, 64, 1, 4, None, 0, 2),
+    (2, 17, 19, 40, 1, 3, None, 0, 1),
+    (2, 16, 16, 32, 1, 2, None, 1, 2),   # gather impl on a march-able shape
+    (2, 16, 16, 32, 2, 1, None, 0, 2),   # SAME stride 2, even size: pad (0,0)
+    (2, 15, 15, 24, 2, 1, None, 0, 2),   # SAME stride 2, odd size: pad (1,1)
+    (2, 16, 16, 32, 2, 1, (1, 1), 0, 1),  # explicit ZeroPadding2D + VALID (Xception)
+    (1, 8, 8, 16, 1, 12, None, 0, 1),    # rate > size
+    (3, 64, 64, 144, 1, 1, None, 0, 2),  # C not a multiple of 32, several row chunks
+]
+
+
+def _dw_geom(H, W, stride, rate, pads):
+    if pads is None:
+        Ho, pt, _ = O.same_pads(H, 3, stride, rate)
+        Wo, pl, _ = O.same_pads(W, 3, stride, rate)
+    else:
+        pt, pl = pads
+        Ho = (H + 2 * pt - ((3 - 1) * rate + 1)) // stride + 1
+        Wo = (W + 2 * pl - ((3 - 1) * rate + 1)) // stride + 1
+    return Ho, Wo, pt, pl
+
+
+@pytest.mark.parametrize("case", DW_CASES)
+def test_dwconv_fwd(L, case):
+    N, H, W, C, stride, rate, pads, impl, act = case
+    rng = np.random.default_rng(0)
+    Ho, Wo, pt, pl = _dw_geom(H, W, stride, rate, pads)
+    x = rng.normal(0, 1, (N, H, W, C)).astype(np.float32)
+    w = rng.normal(0, 0.3, (3, 3, C)).astype(np.float32)
+    s, t, a = _xform(rng, C, act)
+    xin = x if s is None else np_act(s * x + t, a)
+    ref = O.depthwise3x3(xin.astype(np.float64), w.astype(np.float64), stride, rate, pt, pl, Ho, Wo)
+    P = L.dl3_dwconv3x3_partials(N, H, W, C, stride, rate, Ho, Wo, impl)
+    y, part = empty(N, Ho, Wo, C), empty(P, C, 2)
+    call("dl3_dwconv3x3_fwd", ptr(dev(x)), ptr(dev(s)) if s is not None else None,
+         ptr(dev(t)) if t is not None else None, a, ptr(dev(w)), ptr(y), N, H, W, C, stride, rate, pt, pl, Ho, Wo,
+         ptr(part), impl)
+    assert relerr(host(y), ref) < TOL
+    s1, s2 = fold_partials(part, P, C)
+    assert relerr(s1, ref.sum((0, 1, 2))) < 1e-3
+    assert relerr(s2, (ref ** 2).sum((0, 1, 2))) < 1e-3
+
+
+@pytest.mark.parametrize("case", DW_CASES)
+def test_dwconv_bwd(L, case):
+    N, H, W, C, stride, rate, pads, impl, act = case
+    rng = np.random.default_rng(1)
+    Ho, Wo, pt, pl = _dw_geom(H, W, stride, rate, pads)
+    x = rng.normal(0, 1, (N, H, W, C)).astype(np.float32)
+    w = rng.normal(0, 0.3, (3, 3, C)).astype(np.float32)
+    g = rng.normal(0, 1, (N, Ho, Wo, C)).astype(np.float32)
+    yraw = rng.normal(0, 1, (N, Ho, Wo, C)).astype(np.float32)
+    cA, cB, cC = [rng.normal(0, 1, C).astype(np.float32) for _ in range(3)]
+    add = rng.normal(0, 1, (N, H, W, C)).astype(np.float32)
+    mean = rng.normal(0, 1, C).astype(np.float32)
+    invstd = rng.uniform(0.5, 2, C).astype(np.float32)
+    s, t, a = _xform(rng, C, act)
+    z = x.astype(np.float64) if s is None else (s * x.astype(np.float64) + t)
+    xin = np_act(z, a)
+    dY = cA * g.astype(np.float64) + cB * yraw + cC
+    tape = O.Tape()
+    wv = w.astype(np.float64)
+    yref = O.depthwise3x3(xin, wv, stride, rate, pt, pl, Ho, Wo, tape=tape)
+    grads = tape.backward(yref, dY)
+    dx_ref = grads[id(xin)] * np_mask(z, a) + add
+    dw_ref = grads[id(wv)]
+    P = L.dl3_dwconv3x3_partials(N, H, W, C, stride, rate, Ho, Wo, impl)
+    dx, dpart, wpart = empty(N, H, W, C), empty(P, C, 2), empty(P, 9, C)
+    call("dl3_dwconv3x3_bwd", ptr(dev(g)), ptr(dev(yraw)), ptr(dev(cA)), ptr(dev(cB)), ptr(dev(cC)), ptr(dev(x)),
+         ptr(dev(s)) if s is not None else None, ptr(dev(t)) if t is not None else None, a, ptr(dev(w)), ptr(dx),
+         ptr(dev(add)), ptr(dev(mean)), ptr(dev(invstd)), ptr(dpart), ptr(wpart), N, H, W, C, stride, rate, pt, pl,
+         Ho, Wo, impl)
+    assert relerr(host(dx), dx_ref) < TOL
+    dwg = host(wpart).reshape(P, 3, 3, C).astype(np.float64).sum(0)
+    assert relerr(dwg, dw_ref) < 1e-3
+    s1, s2 = fold_partials(dpart, P, C)
+    assert relerr(s1, dx_ref.sum((0, 1, 2))) < 1e-3
+    assert relerr(s2, (dx_ref * (x - mean) * invstd).sum((0, 1, 2))) < 1e-3
+
+
+def test_dwconv_bwd_plain_operand(L):
+    """cA == NULL (dY = g), no add, no stats, no dx"""
+    N, H, W, C = 2, 16, 16, 32
+    rng = np.random.default_rng(2)
+    x = rng.normal(0, 1, (N, H, W, C)).astype(np.float32)
+    w = rng.normal(0, 0.3, (3, 3, C)).astype(np.float32)
+    g = rng.normal(0, 1, (N, H, W, C)).astype(np.float32)
+    tape = O.Tape()
+    xv, wv = x.astype(np.float64), w.astype(np.float64)
+    yref = O.depthwise3x3(xv, wv, 1, 2, 2, 2, H, W, tape=tape)
+    grads = tape.backward(yref, g.astype(np.float64))
+    P = L.dl3_dwconv3x3_partials(N, H, W, C, 1, 2, H, W, 0)
+    dx, wpart = empty(N, H, W, C), empty(P, 9, C)
+    call("dl3_dwconv3x3_bwd", ptr(dev(g)), None, None, None, None, ptr(dev(x)), None, None, 0, ptr(dev(w)), ptr(dx),
+         None, None, None, None, ptr(wpart), N, H, W, C, 1, 2, 2, 2, H, W, 0)
+    assert relerr(host(dx), grads[id(xv)]) < TOL
+    assert relerr(host(wpart).reshape(P, 3, 3, C).sum(0), grads[id(wv)]) < 1e-3
+
+
+PW_CASES = [
+    # M, K, N, ldx_extra, ldy_extra, bias, act
+    (256, 16, 96, 0, 0, False, 2),
+    (512, 96, 24, 0, 0, False, 2),
+    (300, 32, 21, 0, 0, True, None),     # N not a multiple of 4 -> scalar path, M tail
+    (1024, 160, 960, 0, 0, False, None),
+    (384, 960, 160, 0, 0, False, 2),
+    (130, 24, 144, 0, 0, False, 2),
+    (64, 320, 256, 0, 256, False, None),  # writes a channel slice of a concat buffer
+    (200, 512, 256, 0, 0, False, 1),
+    (4, 320, 256, 0, 0, False, None),    # image-pooling branch: M = batch
+    (256, 256, 1344, 0, 0, True, None),  # Subpixel head
+    (256, 64, 384, 64, 0, False, 2),     # reads a channel slice
+]
+
+
+@pytest.mark.parametrize("case", PW_CASES)
+def test_pwconv_fwd(L, case):
+    M, K, N, lxe, lye, bias, act = case
+    rng = np.random.default_rng(3)
+    ldx, ldy = K + lxe, N + lye
+    xfull = rng.normal(0, 1, (M, ldx)).astype(np.float32)
+    w = rng.normal(0, 0.2, (K, N)).astype(np.float32)
+    b = rng.normal(0, 1, N).astype(np.float32) if bias else None
+    s, t, a = _xform(rng, K, act)
+    xoff = lxe
+    x = xfull[:, xoff:xoff + K].astype(np.float64)
+    xin = x if s is None else np_act(s * x + t, a)
+    ref = xin @ w.astype(np.float64) + (b if bias else 0)
+    P = L.dl3_pwconv_partials(M, K, N)
+    yfull = torch.zeros(M, ldy, dtype=torch.float32, device="cuda")
+    part = empty(P, N, 2)
+    xd = dev(xfull)
+    call("dl3_pwconv_fwd", ptr(xd, xoff), ldx, ptr(dev(s)) if s is not None else None,
+         ptr(dev(t)) if t is not None else None, a, ptr(dev(w)), ptr(dev(b)) if bias else None, ptr(yfull, lye), ldy,
+         M, K, N, ptr(part))
+    y = host(yfull)
+    assert relerr(y[:, lye:], ref) < TOL
+    if lye:
+        assert np.all(y[:, :lye] == 0)
+    s1, s2 = fold_partials(part, P, N)
+    assert relerr(s1, ref.sum(0)) < 1e-3
+    assert relerr(s2, (ref ** 2).sum(0)) < 1e-3
+
+
+BD_CASES = [
+    # M, K, N, act, two-tensor, add mode (0 none, 1 tensor, 2 broadcast), stats
+    (256, 16, 96, 2, True, 1, True),
+    (300, 256, 21, None, False, 0, False),   # logits conv: plain dY, K of the GEMM = 21
+    (384, 160, 960, None, True, 1, True),
+    (512, 960, 160, 2, True, 0, True),
+    (256, 320, 256, None, True, 2, True),    # + broadcast per-image addend (global-pool branch)
+    (130, 144, 24, 2, True, 0, True),
+    (256, 512, 256, 1, True, 0, True),
+]
+
+
+@pytest.mark.parametrize("case", BD_CASES)
+def test_pwconv_bwd_data(L, case):
+    M, K, N, act, two, addmode, stats = case
+    rng = np.random.default_rng(4)
+    g = rng.normal(0, 1, (M, N)).astype(np.float32)
+    yraw = rng.normal(0, 1, (M, N)).astype(np.float32)
+    cA, cB, cC = [rng.normal(0, 1, N).astype(np.float32) for _ in range(3)]
+    w = rng.normal(0, 0.2, (K, N)).astype(np.float32)
+    x = rng.normal(0, 1, (M, K)).astype(np.float32)
+    s, t, a = _xform(rng, K, act)
+    mean = rng.normal(0, 1, K).astype(np.float32)
+    invstd = rng.uniform(0.5, 2, K).astype(np.float32)
+    dY = (cA * g.astype(np.float64) + cB * yraw + cC) if two else g.astype(np.float64)
+    ref = dY @ w.astype(np.float64).T
+    if s is not None:
+        ref = ref * np_mask(s * x.astype(np.float64) + t, a)
+    add_div, add_scale, add = 1, 1.0, None
+    if addmode == 1:
+        add = rng.normal(0, 1, (M, K)).astype(np.float32)
+        ref = ref + add
+    elif addmode == 2:
+        add_div, add_scale = 64, 0.25
+        add = rng.normal(0, 1, (M // add_div, K)).astype(np.float32)
+        ref = ref + add_scale * np.repeat(add, add_div, axis=0)
+    wT = empty(N, K)
+    call("dl3_transpose", ptr(dev(w)), ptr(wT), K, N)
+    assert np.array_equal(host(wT), w.T)
+    P = L.dl3_pwconv_partials(M, N, K)
+    dx, dpart = empty(M, K), empty(P, K, 2)
+    need_x = s is not None or stats
+    call("dl3_pwconv_bwd_data", ptr(dev(g)), N, ptr(dev(yraw)) if two else None, N, ptr(dev(cA)) if two else None,
+         ptr(dev(cB)) if two else None, ptr(dev(cC)) if two else None, ptr(wT), ptr(dx), K,
+         ptr(dev(x)) if need_x else None, K, ptr(dev(s)) if s is not None else None,
+         ptr(dev(t)) if t is not None else None, a, ptr(dev(add)) if add is not None else None, K, add_div, add_scale,
+         ptr(dev(mean)) if stats else None, ptr(dev(invstd)) if stats else None, ptr(dpart) if stats else None, M, K, N)
+    assert relerr(host(dx), ref) < TOL
+    if stats:
+        s1, s2 = fold_partials(dpart, P, K)
+        assert relerr(s1, ref.sum(0)) < 1e-3
+        assert relerr(s2, (ref * (x - mean) * invstd).sum(0)) < 1e-3
+
+
+BW_CASES = [
+    # M, K, N, act, two-tensor, dbias
+    (1024, 16, 96, 2, True, False),
+    (2048, 160, 960, None, True, False),
+    (2048, 960, 160, 2, True, False),
+    (1000, 256, 21, 1, False, True),
+    (4, 320, 256, None, True, False),
+    (4096, 96, 576, 2, True, False),
+    (512, 512, 256, 1, True, False),
+    (700, 24, 144, None, True, False),
+]
+
+
+@pytest.mark.parametrize("case", BW_CASES)
+def test_pwconv_bwd_weight(L, case):
+    M, K, N, act, two, dbias = case
+    rng = np.random.default_rng(5)
+    g = rng.normal(0, 1, (M, N)).astype(np.float32)
+    yraw = rng.normal(0, 1, (M, N)).astype(np.float32)
+    cA, cB, cC = [rng.normal(0, 1, N).astype(np.float32) for _ in range(3)]
+    x = rng.normal(0, 1, (M, K)).astype(np.float32)
+    s, t, a = _xform(rng, K, act)
+    xin = x.astype(np.float64) if s is None else np_act(s * x.astype(np.float64) + t, a)
+    dY = (cA * g.astype(np.float64) + cB * yraw + cC) if two else g.astype(np.float64)
+    ref = xin.T @ dY
+    nbytes = L.dl3_pwconv_bwd_weight_workspace(M, K, N)
+    ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device="cuda")
+    dw, db = empty(K, N), empty(N)
+    call("dl3_pwconv_bwd_weight", ptr(dev(x)), K, ptr(dev(s)) if s is not None else None,
+         ptr(dev(t)) if t is not None else None, a, ptr(dev(g)), N, ptr(dev(yraw)) if two else None, N,
+         ptr(dev(cA)) if two else None, ptr(dev(cB)) if two else None, ptr(dev(cC)) if two else None, ptr(dw),
+         ptr(db) if dbias else None, M, K, N, ptr(ws), nbytes)
+    assert relerr(host(dw), ref) < TOL
+    if dbias:
+        assert relerr(host(db), dY.sum(0)) < TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32, 3, 32, 2), (1, 17, 19, 3, 32, 2), (1, 16, 16, 32, 64, 1)])
+def test_conv3x3(L, shape):
+    N, H, W, Cin, Cout, stride = shape
+    rng = np.random.default_rng(6)
+    Ho, pt, _ = O.same_pads(H, 3, stride, 1)
+    Wo, pl, _ = O.same_pads(W, 3, stride, 1)
+    x = rng.uniform(0, 255, (N, H, W, Cin)).astype(np.float32)
+    w = rng.normal(0, 0.2, (3, 3, Cin, Cout)).astype(np.float32)
+    s = np.full(Cin, 1 / 127.5, np.float32)
+    t = np.full(Cin, -1.0, np.float32)
+    xin = s * x.astype(np.float64) + t
+    tape = O.Tape()
+    wv = w.astype(np.float64)
+    ref = O.conv2d(xin, wv, stride, pt, pl, Ho, Wo, tape=tape)
+    P = L.dl3_conv3x3_partials(N, Ho, Wo, Cout)
+    y, part = empty(N, Ho, Wo, Cout), empty(P, Cout, 2)
+    xd, sd, td, wd = dev(x), dev(s), dev(t), dev(w)
+    call("dl3_conv3x3_fwd", ptr(xd), ptr(sd), ptr(td), 0, ptr(wd), ptr(y), N, H, W, Cin, Cout, stride, pt, pl, Ho, Wo,
+         ptr(part))
+    assert relerr(host(y), ref) < TOL
+    s1, s2 = fold_partials(part, P, Cout)
+    assert relerr(s1, ref.sum((0, 1, 2))) < 1e-3 and relerr(s2, (ref ** 2).sum((0, 1, 2))) < 1e-3
+    # weight gradient with a BN-backward operand
+    g = rng.normal(0, 1, ref.shape).astype(np.float32)
+    cA, cB, cC = [rng.normal(0, 1, Cout).astype(np.float32) for _ in range(3)]
+    yraw = host(y)
+    dY = cA * g.astype(np.float64) + cB * yraw + cC
+    grads = tape.backward(ref, dY)
+    wpart = empty(P, 9 * Cin * Cout)
+    call("dl3_conv3x3_bwd_weight", ptr(xd), ptr(sd), ptr(td), 0, ptr(dev(g)), ptr(y), ptr(dev(cA)), ptr(dev(cB)),
+         ptr(dev(cC)), ptr(wpart), N, H, W, Cin, Cout, stride, pt, pl, Ho, Wo)
+    assert relerr(host(wpart).astype(np.float64).sum(0).reshape(3, 3, Cin, Cout), grads[id(wv)]) < 1e-3
+    if Cin % 4 == 0:
+        P2 = L.dl3_conv3x3_partials(N, H, W, Cin)
+        dx, dpart = empty(N, H, W, Cin), empty(P2, Cin, 2)
+        mean = rng.normal(0, 1, Cin).astype(np.float32)
+        invstd = rng.uniform(0.5, 2, Cin).astype(np.float32)
+        call("dl3_conv3x3_bwd_data", ptr(dev(g)), ptr(y), ptr(dev(cA)), ptr(dev(cB)), ptr(dev(cC)), ptr(wd), ptr(dx),
+             ptr(xd), ptr(sd), ptr(td), 1, None, ptr(dev(mean)), ptr(dev(invstd)), ptr(dpart), N, H, W, Cin, Cout,
+             stride, pt, pl, Ho, Wo)
+        dx_ref = grads[id(xin)] * (xin > 0)
+        assert relerr(host(dx), dx_ref) < TOL
+        s1, s2 = fold_partials(dpart, P2, Cin)
+        assert relerr(s1, dx_ref.sum((0, 1, 2))) < 1e-3
+        assert relerr(s2, (dx_ref * (x - mean) * invstd).sum((0, 1, 2))) < 1e-3
+
+
+def test_bn_finalize_and_bwd(L):
+    rng = np.random.default_rng(7)
+    P, ldc, C, c0, count = 37, 48, 24, 16, 1000.0
+    part = rng.normal(0, 1, (P, ldc, 2)).astype(np.float32)
+    part[:, :, 1] = np.abs(part[:, :, 1]) * 40 + 30  # sum of squares: keep the variance positive
+    gamma, beta = rng.uniform(0.5, 1.5, C).astype(np.float32), rng.normal(0, 1, C).astype(np.float32)
+    mm, mv = rng.normal(0, 1, C).astype(np.float32), rng.uniform(0.5, 2, C).astype(np.float32)
+    eps, mom = 1e-3, 0.99
+    s1 = part[:, c0:c0 + C, 0].astype(np.float64).sum(0)
+    s2 = part[:, c0:c0 + C, 1].astype(np.float64).sum(0)
+    mean = s1 / count
+    var = s2 / count - mean ** 2
+    invstd = 1 / np.sqrt(var + eps)
+    outs = [empty(C) for _ in range(4)]
+    mmd, mvd = dev(mm), dev(mv)
+    pd = dev(part)
+    call("dl3_bn_finalize", ptr(pd, 2 * c0), P, ldc, C, count, ptr(dev(gamma)), ptr(dev(beta)), eps, mom,
+         *[ptr(o) for o in outs], ptr(mmd), ptr(mvd))
+    sc, sh, me, isd = [host(o) for o in outs]
+    assert relerr(sc, gamma * invstd) < 1e-5 and relerr(sh, beta - mean * gamma * invstd) < 1e-5
+    assert relerr(me, mean) < 1e-5 and relerr(isd, invstd) < 1e-5
+    assert relerr(host(mmd), mom * mm + (1 - mom) * mean) < 1e-5
+    assert relerr(host(mvd), mom * mv + (1 - mom) * var * count / (count - 1)) < 1e-5
+    # frozen
+    outs2 = [empty(C) for _ in range(4)]
+    call("dl3_bn_frozen", ptr(dev(gamma)), ptr(dev(beta)), ptr(dev(mm)), ptr(dev(mv)), eps, C, *[ptr(o) for o in outs2])
+    assert relerr(host(outs2[0]), gamma / np.sqrt(mv + eps)) < 1e-5
+    assert relerr(host(outs2[1]), beta - mm * gamma / np.sqrt(mv + eps)) < 1e-5
+    # backward coefficients: dy = gamma*invstd*(g - sum(g)/M - xhat*sum(g*xhat)/M)
+    dpart = rng.normal(0, 1, (P, ldc, 2)).astype(np.float32)
+    d1 = dpart[:, c0:c0 + C, 0].astype(np.float64).sum(0)
+    d2 = dpart[:, c0:c0 + C, 1].astype(np.float64).sum(0)
+    co = [empty(C) for _ in range(5)]
+    call("dl3_bn_bwd_finalize", ptr(dev(dpart), 2 * c0), P, ldc, C, count, ptr(dev(gamma)), ptr(dev(mean)),
+         ptr(dev(invstd)), 1, *[ptr(o) for o in co])
+    cA, cB, cC, dg, db = [host(o).astype(np.float64) for o in co]
+    assert relerr(dg, d2) < 1e-5 and relerr(db, d1) < 1e-5
+    g = rng.normal(0, 1, (50, C))
+    y = rng.normal(0, 1, (50, C))
+    xhat = (y - mean) * invstd
+    want = gamma * invstd * (g - d1 / count - xhat * d2 / count)
+    assert relerr(cA * g + cB * y + cC, want) < 1e-4
+    call("dl3_bn_bwd_finalize", ptr(dev(dpart), 2 * c0), P, ldc, C, count, ptr(dev(gamma)), ptr(dev(mean)),
+         ptr(dev(invstd)), 0, *[ptr(o) for o in co])
+    assert relerr(host(co[0]), gamma * invstd) < 1e-5 and np.all(host(co[1]) == 0) and np.all(host(co[2]) == 0)
+
+
+@pytest.mark.parametrize("P,n", [(5, 100), (64, 333), (700, 77), (119, 4096)])
+def test_reduce_partials(L, P, n):
+    rng = np.random.default_rng(8)
+    part = rng.normal(0, 1, (P, n)).astype(np.float32)
+    out = empty(n)
+    call("dl3_reduce_partials", ptr(dev(part)), P, n, ptr(out))
+    assert relerr(host(out), part.astype(np.float64).sum(0)) < 1e-5
+
+
+def test_affine_add_and_dropout(L):
+    rng = np.random.default_rng(9)
+    M, C = 300, 40
+    a, b = rng.normal(0, 1, (M, C)).astype(np.float32), rng.normal(0, 1, (M, C)).astype(np.float32)
+    sa, ta = rng.uniform(0.5, 1.5, C).astype(np.float32), rng.normal(0, 1, C).astype(np.float32)
+    out = empty(M, C)
+    call("dl3_affine_add", ptr(dev(a)), C, ptr(dev(sa)), ptr(dev(ta)), 2, ptr(dev(b)), C, None, None, 0, ptr(out), C, M,
+         C, 0.0, 0)
+    assert relerr(host(out), np_act(sa * a + ta, 2) + b) < 1e-6
+    # dropout: deterministic mask of the right density, identical between forward and gradient kernels
+    M2, C2 = 4096, 256
+    ones = np.ones((M2, C2), np.float32)
+    o1, o2 = empty(M2, C2), empty(M2, C2)
+    call("dl3_affine_add", ptr(dev(ones)), C2, None, None, 0, None, 0, None, None, 0, ptr(o1), C2, M2, C2, 0.1, 1234)
+    call("dl3_grad_finish", ptr(dev(ones)), C2, 1, 1.0, ptr(o2), C2, None, 0, None, 0, None, None, 0, None, None, None,
+         M2, C2, 0.1, 1234)
+    h1, h2 = host(o1), host(o2)
+    assert np.array_equal(h1, h2)
+    keep = (h1 != 0).mean()
+    assert abs(keep - 0.9) < 5e-3
+    assert np.allclose(h1[h1 != 0], 1 / 0.9)
+
+
+def test_grad_finish_and_gap(L):
+    rng = np.random.default_rng(10)
+    M, C, HW = 512, 48, 128
+    g = rng.normal(0, 1, (M, C)).astype(np.float32)
+    x = rng.normal(0, 1, (M, C)).astype(np.float32)
+    add = rng.normal(0, 1, (M, C)).astype(np.float32)
+    s, t = rng.uniform(0.5, 1.5, C).astype(np.float32), rng.normal(0, 1, C).astype(np.float32)
+    mean, invstd = rng.normal(0, 1, C).astype(np.float32), rng.uniform(0.5, 2, C).astype(np.float32)
+    P = L.dl3_rows_partials(M)
+    out, part = empty(M, C), empty(P, C, 2)
+    call("dl3_grad_finish", ptr(dev(g)), C, 1, 1.0, ptr(out), C, ptr(dev(add)), C, ptr(dev(x)), C, ptr(dev(s)),
+         ptr(dev(t)), 1, ptr(dev(mean)), ptr(dev(invstd)), ptr(part), M, C, 0.0, 0)
+    ref = g * np_mask(s * x + t, 1) + add
+    assert relerr(host(out), ref) < 1e-6
+    s1, s2 = fold_partials(part, P, C)
+    assert relerr(s1, ref.astype(np.float64).sum(0)) < 1e-4
+    assert relerr(s2, (ref.astype(np.float64) * (x - mean) * invstd).sum(0)) < 1e-4
+    # broadcast form (backward of the global average pool) accumulating in place
+    gv = rng.normal(0, 1, (M // HW, C)).astype(np.float32)
+    acc = dev(add)
+    call("dl3_grad_finish", ptr(dev(gv)), C, HW, 1.0 / HW, ptr(acc), C, ptr(acc), C, None, 0, None, None, 0, None, None,
+         None, M, C, 0.0, 0)
+    assert relerr(host(acc), add + np.repeat(gv, HW, axis=0) / HW) < 1e-6
+    # global average pool with transform, reading a channel slice
+    N = M // HW
+    xf = rng.normal(0, 1, (M, C + 16)).astype(np.float32)
+    o = empty(N, C)
+    call("dl3_gap_fwd", ptr(dev(xf), 16), C + 16, ptr(dev(s)), ptr(dev(t)), 1, ptr(o), N, HW, C, 1.0 / HW)
+    ref = np_act(s * xf[:, 16:].astype(np.float64) + t, 1).reshape(N, HW, C).mean(1)
+    assert relerr(host(o), ref) < 1e-5
+
+
+@pytest.mark.parametrize("dims", [(2, 8, 8, 64, 64, 21), (2, 1, 1, 16, 16, 32), (1, 16, 16, 32, 32, 8),
+                                  (1, 10, 7, 33, 20, 5)])
+def test_resize_bilinear(L, dims):
+    N, Hi, Wi, Ho, Wo, C = dims
+    rng = np.random.default_rng(11)
+    x = rng.normal(0, 1, (N, Hi, Wi, C)).astype(np.float32)
+    tape = O.Tape()
+    ref = O.resize_bilinear_tf1(x, Ho, Wo, tape=tape)
+    y = empty(N, Ho, Wo, C)
+    call("dl3_resize_bilinear_fwd", ptr(dev(x)), C, None, None, 0, ptr(y), C, N, Hi, Wi, Ho, Wo, C)
+    assert relerr(host(y), ref) < 1e-5
+    g = rng.normal(0, 1, ref.shape).astype(np.float32)
+    dx_ref = tape.backward(ref, g)[id(x)]
+    dx = empty(N, Hi, Wi, C)
+    call("dl3_resize_bilinear_bwd", ptr(dev(g)), C, ptr(dx), C, N, Hi, Wi, Ho, Wo, C, 0)
+    assert relerr(host(dx), dx_ref) < 1e-4
+    call("dl3_resize_bilinear_bwd", ptr(dev(g)), C, ptr(dx), C, N, Hi, Wi, Ho, Wo, C, 1)
+    assert relerr(host(dx), 2 * dx_ref) < 1e-4
+
+
+def test_phase_shift(L):
+    rng = np.random.default_rng(12)
+    N, H, W, co, r = 2, 5, 6, 3, 4
+    x = rng.normal(0, 1, (N, H, W, co * r * r)).astype(np.float32)
+    ref = O.phase_shift(x, r)
+    y = empty(*ref.shape)
+    call("dl3_phase_shift", ptr(dev(x)), ptr(y), N, H, W, co, r, 0)
+    assert np.array_equal(host(y), ref)
+    back = empty(*x.shape)
+    call("dl3_phase_shift", ptr(y), ptr(back), N, H, W, co, r, 1)
+    assert np.array_equal(host(back), x)
+
+
+def test_softmax_argmax_xent(L):
+    rng = np.random.default_rng(13)
+    M, C = 5000, 21
+    x = rng.normal(0, 3, (M, C)).astype(np.float32)
+    labels = rng.integers(0, C + 1, M).astype(np.float32)
+    w = ((labels < C) * rng.uniform(0.5, 2, M)).astype(np.float32)
+    p = empty(M, C)
+    call("dl3_softmax_fwd", ptr(dev(x)), ptr(p), M, C)
+    assert relerr(host(p), O.softmax(x.astype(np.float64))) < 1e-5
+    am = torch.empty(M, dtype=torch.int32, device="cuda")
+    call("dl3_argmax", ptr(dev(x)), am.data_ptr(), M, C)
+    assert np.array_equal(host(am), x.argmax(-1))
+    nnz = empty(1)
+    call("dl3_count_nonzero", ptr(dev(w)), M, ptr(nnz))
+    assert host(nnz)[0] == float((w != 0).sum())
+    loss_ref, dl_ref, p_ref = O.loss_sparse_xent_ignoring_last_label(x.astype(np.float64)[None], labels[None],
+                                                                     w.astype(np.float64)[None])
+    P = L.dl3_rows_partials(M)
+    dl, lp, probs = empty(M, C), empty(P), empty(M, C)
+    call("dl3_softmax_xent", ptr(dev(x)), ptr(dev(labels)), ptr(dev(w)), ptr(nnz), ptr(probs), ptr(dl), ptr(lp), M, C)
+    assert relerr(host(dl), dl_ref[0]) < 1e-5
+    assert abs(host(lp).astype(np.float64).sum() / (w != 0).sum() - loss_ref) < 1e-5 * abs(loss_ref)
+    assert relerr(host(probs), p_ref[0]) < 1e-5
+
+
+def test_adam_fill(L):
+    rng = np.random.default_rng(14)
+    n = 10001
+    p, g = rng.normal(0, 1, n).astype(np.float32), rng.normal(0, 1, n).astype(np.float32)
+    m, v = rng.normal(0, 0.1, n).astype(np.float32), rng.uniform(0, 0.1, n).astype(np.float32)
+    pd, md, vd = dev(p), dev(m), dev(v)
+    lr, b1, b2, eps, gs = 1e-3, 0.9, 0.999, 1e-8, 0.5
+    call("dl3_adam_step", ptr(pd), ptr(dev(g)), ptr(md), ptr(vd), n, lr, b1, b2, eps, gs)
+    gg = g * gs
+    m2 = b1 * m + (1 - b1) * gg
+    v2 = b2 * v + (1 - b2) * gg * gg
+    assert relerr(host(md), m2) < 1e-6 and relerr(host(vd), v2) < 1e-6
+    assert relerr(host(pd), p - lr * m2 / (np.sqrt(v2) + eps)) < 1e-6
+    f = empty(1000)
+    call("dl3_fill", ptr(f), 2.5, 1000)
+    assert np.all(host(f) == 2.5)
+
+
+def test_error_reporting(L):
+    """bad arguments come back as a status + message, not a crash (include/dl3.h conventions)"""
+    rc = L.dl3_pwconv_fwd(None, 4, None, None, 0, None, None, None, 4, 4, 4, 4, None, stream())
+    assert rc == -1 and b"null" in L.dl3_last_error()
+    x = empty(16, 6)
+    rc = L.dl3_dwconv3x3_fwd(ptr(x), None, None, 0, ptr(x), ptr(x), 1, 4, 4, 6, 1, 1, 1, 1, 4, 4, None, 0, stream())
+    assert rc == -4

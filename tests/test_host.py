@@ -1,0 +1,161 @@
+"""CPU tests of the host layer: the Deeplabv3()/SegModel/Subpixel drop-in surface, Keras layer ordering and
+naming, weight I/O, and the C-ABI library (loads, exports every symbol of include/dl3.h; no compute calls)."""
+import numpy as np
+import pytest
+
+import dl3_amd  # noqa: F401
+from dl3_amd import capi, graph as G
+from dl3_amd.deeplabv3p import Deeplabv3, _make_divisible
+from dl3_amd.subpixel import ICNR, Subpixel, icnr_weights
+from dl3_amd.utils import Jaccard, SegModel, sparse_accuracy_ignoring_last_label
+from oracle import dl3_oracle as O
+
+
+def test_library_exports_every_header_symbol():
+    L = capi.lib()
+    protos = capi.protos()
+    assert len(protos) >= 30
+    for name in protos:
+        assert hasattr(L, name), name
+    assert L.dl3_version() >= 100
+    assert L.dl3_pwconv_partials(65536, 160, 960) > 0
+    assert L.dl3_pwconv_bwd_weight_workspace(65536, 160, 960) > 0
+    assert L.dl3_dwconv3x3_partials(16, 64, 64, 960, 1, 4, 64, 64, 0) > 0
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    G.clear_session()
+    m = Deeplabv3(weights=None, input_shape=(64, 64, 3), classes=2)
+    with pytest.raises(capi.DL3Error):
+        m.predict(np.zeros((1, 64, 64, 3), np.float32))
+
+
+def test_constructor_contract():
+    with pytest.raises(ValueError):
+        Deeplabv3(weights="imagenet")
+    with pytest.raises(ValueError):
+        Deeplabv3(weights=None, backbone="resnet")
+    with pytest.raises(FileNotFoundError):
+        Deeplabv3(weights="pascal_voc", input_shape=(64, 64, 3))
+    G.clear_session()
+    m = Deeplabv3(weights=None, infer=True, input_shape=(64, 64, 3), classes=5)
+    assert m.output.shape == (64, 64, 5) and m.name == "deeplabv3p"
+    G.clear_session()
+    m = Deeplabv3(weights=None, input_shape=(64, 64, 3), classes=5)
+    assert m.output.shape == (64 * 64, 5)
+
+
+def test_mobilenetv2_structure_goldens():
+    G.clear_session()
+    m = Deeplabv3(weights=None, input_shape=(128, 128, 3), classes=2)
+    assert m.count_params() == 2141762
+    G.clear_session()
+    m = Deeplabv3(weights=None, classes=21)
+    assert m.count_params() == 2146645 and m.trainable_count() == 2113557
+    wl = [l.name for l in m.layers if l.weights]
+    assert len(wl) == 109
+    assert wl[:4] == ["Conv", "Conv_BN", "expanded_conv_depthwise", "expanded_conv_depthwise_BN"]
+    # Keras depth ordering of the ASPP branches
+    assert wl[-7:] == ["image_pooling", "image_pooling_BN", "aspp0", "aspp0_BN", "concat_projection",
+                       "concat_projection_BN", "logits_semantic"]
+    # the linear tail that utils.py:181 cuts at layers[-5]
+    assert [l.kind for l in m.layers[-5:]] == ["Dropout", "Conv2D", "ResizeBilinear", "Reshape", "Activation"]
+    # OS is silently 8 for mobilenetv2 (deeplabv3p.py:316): 64x64 features at 512x512
+    assert m.get_layer("expanded_conv_16_project").output.shape == (64, 64, 320)
+    assert m.get_layer("expanded_conv_14_depthwise").cfg["rate"] == 4
+    assert m.get_layer("expanded_conv_7_depthwise").cfg["rate"] == 2
+    assert m.get_layer("expanded_conv_6_depthwise").cfg["rate"] == 1
+    assert m.get_layer("Conv_BN").cfg["momentum"] == 0.999 and m.get_layer("aspp0_BN").cfg["eps"] == 1e-5
+    names = set(n for l in m.layers for n in l.weights)
+    assert names == set(O.param_shapes("mobilenetv2", 21))
+    for l in m.layers:
+        for n, w in l.weights.items():
+            assert tuple(w.shape) == tuple(O.param_shapes("mobilenetv2", 21)[n]), n
+
+
+def test_xception_structure_goldens():
+    G.clear_session()
+    m = Deeplabv3(weights=None, classes=21, backbone="xception", OS=8)
+    assert m.count_params() == 41258213 and m.trainable_count() == 41055413
+    wl = [l.name for l in m.layers if l.weights]
+    assert len(wl) == 293
+    i = wl.index("aspp1_depthwise")
+    assert wl[i:i + 16] == ["aspp1_depthwise", "aspp2_depthwise", "aspp3_depthwise", "aspp1_depthwise_BN",
+                            "aspp2_depthwise_BN", "aspp3_depthwise_BN", "image_pooling", "image_pooling_BN", "aspp0",
+                            "aspp1_pointwise", "aspp2_pointwise", "aspp3_pointwise", "aspp0_BN", "aspp1_pointwise_BN",
+                            "aspp2_pointwise_BN", "aspp3_pointwise_BN"]
+    assert m.get_layer("aspp3_depthwise").cfg["rate"] == 36
+    assert m.get_layer("exit_flow_block2_separable_conv3_pointwise").output.shape == (64, 64, 2048)
+    assert m.layers[-5].kind == "Activation"  # last decoder ReLU (utils.py:181)
+    assert set(n for l in m.layers for n in l.weights) == set(O.param_shapes("xception", 21))
+    G.clear_session()
+    m16 = Deeplabv3(weights=None, classes=21, backbone="xception", OS=16)
+    assert m16.get_layer("aspp3_depthwise").cfg["rate"] == 18
+    assert m16.get_layer("exit_flow_block2_separable_conv3_pointwise").output.shape == (32, 32, 2048)
+
+
+def test_segmodel_heads():
+    G.clear_session()
+    sm = SegModel(image_size=(512, 512)).create_seg_model("subpixel", n=21)
+    assert sm.name == "deeplabv3p_subpixel" and sm.trainable_count() == 2453568
+    assert [l.name for l in sm.layers[-3:]] == ["subpixel_1", "reshape_2", "pred_mask"]
+    sp = sm.get_layer("subpixel_1")
+    k, b = sp.get_weights()
+    assert k.shape == (1, 1, 256, 21 * 64) and np.all(b == 0) and sp.output.shape == (512, 512, 21)
+    for j in range(21 * 64):  # ICNR mapping survives create_seg_model (utils.py:200-204)
+        assert np.array_equal(k[0, 0, :, j], k[0, 0, :, j % 21])
+    G.clear_session()
+    om = SegModel(image_size=(320, 320)).create_seg_model("original", n=7)
+    assert om.name == "deeplabv3p" and om.get_layer("conv_upsample").get_weights()[0].shape == (1, 1, 256, 7)
+    assert om.output.shape == (320 * 320, 7)
+    G.clear_session()
+    xm = SegModel(image_size=(256, 256)).create_seg_model("subpixel", n=21, backbone="xception")
+    assert xm.get_layer("subpixel_1").cfg["r"] == 4
+
+
+def test_icnr_and_make_divisible():
+    w = icnr_weights(scale=2, shape=(3, 3, 8, 12))
+    assert w.shape == (3, 3, 8, 12)
+    X = np.random.default_rng(0).normal(size=(1, 1, 5, 3)).astype(np.float32)
+    W = ICNR(lambda shape: X, scale=4)(shape=(1, 1, 5, 48))
+    assert np.array_equal(W, O.icnr_from_subkernel(X, 4))
+    X3 = np.random.default_rng(1).normal(size=(3, 3, 5, 3)).astype(np.float32)
+    assert np.array_equal(ICNR(lambda shape: X3, scale=2)(shape=(3, 3, 5, 12)), O.icnr_from_subkernel(X3, 2))
+    for v in (8, 16, 24, 32, 11.2, 33.6, 100):
+        assert _make_divisible(v, 8) == O._make_divisible(v, 8)
+    assert Subpixel(21, 1, 8).cfg["filters"] == 21 * 64
+
+
+def test_weight_io_roundtrip(tmp_path):
+    G.clear_session()
+    m = Deeplabv3(weights=None, input_shape=(64, 64, 3), classes=4)
+    path = str(tmp_path / "w.npz")
+    m.save_weights(path)
+    G.clear_session(seed=5)
+    m2 = Deeplabv3(weights=None, input_shape=(64, 64, 3), classes=4)
+    assert not np.array_equal(m.get_layer("Conv").get_weights()[0], m2.get_layer("Conv").get_weights()[0])
+    m2.load_weights(path)  # positional
+    for a, b in zip(m.get_weights(), m2.get_weights()):
+        assert np.array_equal(a, b)
+    G.clear_session(seed=6)
+    m3 = Deeplabv3(weights=None, input_shape=(64, 64, 3), classes=21)  # logits_semantic != custom_*: skipped by_name
+    m3.load_weights(path, by_name=True)
+    assert np.array_equal(m.get_layer("aspp0").get_weights()[0], m3.get_layer("aspp0").get_weights()[0])
+    with pytest.raises(ValueError):
+        m3.get_layer("Conv").set_weights([np.zeros((1, 1, 3, 32), np.float32)])
+
+
+def test_host_metrics():
+    y_true = np.array([[[0], [1], [1], [2]], [[0], [0], [3], [3]]], np.float32)  # 3 = void for C = 3
+    probs = np.zeros((2, 4, 3), np.float32)
+    for b, row in enumerate([[0, 1, 0, 2], [0, 1, 0, 0]]):
+        for i, c in enumerate(row):
+            probs[b, i, c] = 1
+    assert abs(sparse_accuracy_ignoring_last_label(y_true, probs) - 4 / 6) < 1e-6
+    # class 0: img0 1/2, img1 1/4 (predictions on void pixels count in the union) -> 3/8; class 1: 1/2 (img0 only);
+    # class 2: 1
+    assert abs(Jaccard(y_true, probs) - np.mean([np.mean([1 / 2, 1 / 4]), 1 / 2, 1.0])) < 1e-6
+    assert abs(Jaccard(y_true, probs) - O.jaccard(y_true[:, :, 0], probs)) < 1e-12

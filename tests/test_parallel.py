@@ -1,0 +1,68 @@
+"""world_size-2 gloo test of the data-parallel step logic (parallel.py): image shards per rank, one all-reduce
+(sum) of the flat gradient arena, 1/world folded into the optimizer — checked against the single-process mean of
+the per-shard gradients computed by the CPU oracle."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from oracle import dl3_oracle as O
+
+KW = dict(backbone="mobilenetv2", input_shape=(32, 32, 3), classes=3)
+
+
+def _data():
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (4, 32, 32, 3)).astype(np.float32)
+    labels = rng.integers(0, 4, (4, 32, 32)).astype(np.float32)
+    return x, labels, (labels < 3).astype(np.float32)
+
+
+def _flat(grads, names):
+    return np.concatenate([grads[n].reshape(-1) for n in names]).astype(np.float32)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import dl3_amd  # noqa: F401
+    from dl3_amd.parallel import DataParallel
+    dp = DataParallel(backend="gloo")
+    x, labels, w = _data()
+    lo, hi = dp.shard(x.shape[0])
+    params = O.init_params(O.param_shapes("mobilenetv2", 3), seed=1 + rank)  # deliberately different per rank
+    names = sorted(n for n in params if "/moving_" not in n)
+    flat_p = torch.from_numpy(_flat(params, names))
+    dp.broadcast(flat_p, src=0)  # identical initial weights on every rank
+    off = 0
+    for n in names:
+        params[n] = flat_p[off:off + params[n].size].numpy().reshape(params[n].shape).copy()
+        off += params[n].size
+    _, grads, _, _ = O.train_grads(params, x[lo:hi], labels[lo:hi], w[lo:hi], **KW)
+    flat_g = torch.from_numpy(_flat(grads, names))
+    scale = dp.allreduce_grads(flat_g)
+    t = dp.max_over_ranks(1.0 + rank)
+    dp.barrier()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), g=flat_g.numpy() * scale, lo=lo, hi=hi, tmax=t,
+             p0=flat_p.numpy()[:64])
+    dp.close()
+
+
+def test_two_rank_gradient_allreduce(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in (0, 1)]
+    assert (int(r0["lo"]), int(r0["hi"]), int(r1["lo"]), int(r1["hi"])) == (0, 2, 2, 4)
+    assert np.array_equal(r0["g"], r1["g"]) and np.array_equal(r0["p0"], r1["p0"])
+    assert float(r0["tmax"]) == 2.0 and float(r1["tmax"]) == 2.0
+    x, labels, w = _data()
+    params = O.init_params(O.param_shapes("mobilenetv2", 3), seed=1)
+    names = sorted(n for n in params if "/moving_" not in n)
+    gs = [_flat(O.train_grads(params, x[a:b], labels[a:b], w[a:b], **KW)[1], names) for a, b in ((0, 2), (2, 4))]
+    want = (gs[0] + gs[1]) / 2
+    assert np.allclose(r0["g"], want, rtol=1e-5, atol=1e-6 * np.abs(want).max())
