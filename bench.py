@@ -28,6 +28,14 @@ from dl3_amd.deeplabv3p import Deeplabv3  # noqa: E402
 from dl3_amd.parallel import DataParallel  # noqa: E402
 from dl3_amd.utils import SegModel  # noqa: E402
 
+T0 = time.perf_counter()
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %7.1fs] %s" % (time.perf_counter() - T0, msg), file=sys.stderr, flush=True)
+
+
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3  # fp32 MFMA = fp32 vector peak
 
@@ -113,8 +121,12 @@ def cpu_baseline_leg(args):
     sample.  kind='port': the reference's own Keras/TensorFlow CPU path cannot be installed here."""
     from oracle import dl3_oracle as O
     from oracle import torch_ref as T
-    cores = os.cpu_count() or 1
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # oneDNN on a 2-image batch stops scaling (and collapses from oversubscription) far below a 256-thread host:
+    # use at most 32 threads and report that count
+    cores = min(avail, args.cpu_threads)
     torch.set_num_threads(cores)
+    log("cpu baseline on %d of %d host cores" % (cores, avail))
     B = 2
     kw = dict(backbone=args.backbone, input_shape=(args.size, args.size, 3), classes=21, OS=16)
     params = O.init_params(O.param_shapes(args.backbone, 21), seed=1)
@@ -146,6 +158,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=32)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -154,7 +167,10 @@ def main():
     dp = DataParallel(backend="nccl")
     assert dp.world == args.gpus or (args.gpus == 1 and dp.world == 1), "launch with torch.distributed.run for --gpus > 1"
 
+    log("building engine (batch %d per GPU, %d GPU)" % (args.batch, dp.world))
     model, eng = build_engine(args)
+    log("engine built: %d fwd ops, %d bwd ops, %.2f GB device memory" % (
+        len(eng.ops_fwd), len(eng.ops_bwd), torch.cuda.memory_allocated() / 1e9))
     dp.broadcast(eng.params)
     dp.broadcast(eng.state)
 
@@ -163,8 +179,10 @@ def main():
         scale = dp.allreduce_grads(eng.grads)
         eng.adam(None, scale)
 
-    for _ in range(max(args.warmup, 2)):  # >= 2: the first call runs eagerly, the second captures the hipGraph
+    for i in range(max(args.warmup, 2)):  # >= 2: the first call runs eagerly, the second captures the hipGraph
         step()
+        torch.cuda.synchronize()
+        log("warm-up step %d done" % i)
     dp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -174,6 +192,7 @@ def main():
     dp.barrier()
     dt = dp.max_over_ranks(time.perf_counter() - t0)
     loss = float(eng.loss[0].item())
+    log("timed %d steps: %.1f ms/step" % (args.steps, 1e3 * dt / args.steps))
 
     if dp.rank == 0:
         imgs = args.batch * dp.world * args.steps
@@ -190,6 +209,7 @@ def main():
         }
         if not args.no_roofline:
             r = roofline_leg(args.batch)
+            log("roofline leg done: " + ", ".join("%s %.3f ms" % (k, v["ms"]) for k, v in r.items()))
             k = r["dw_r4_fwd"]
             rec["roofline"] = {"bound": "hbm", "kernel": "dw_march_fwd (DepthwiseConv2D 3x3 rate 4, %dx64x64x960)" % args.batch,
                                "achieved": k["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["gbs"] / HBM_PEAK_GBS,
@@ -197,6 +217,7 @@ def main():
             rec["kernels"] = r
         if dp.world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline_leg(args)
+            log("cpu baseline done")
         print(json.dumps(rec))
     dp.close()
 

@@ -164,7 +164,8 @@ int dl3_argmax(const float *x, int *out, int M, int C, void *stream);
 /* count of non-zero sample weights -> *out (float) ; sparse_crossentropy_ignoring_last_label
  * (utils.py:127-130) with Keras temporal sample weights:
  *   loss = sum_m w[m]*(-log clip(p[m,label]))/nnz ; dlogits = (p - onehot)*w/nnz ; label==C (void): onehot=0.
- * loss_partial [P] (P = dl3_rows_partials(M)); probs nullable. */
+ * loss_partial [P] (P = dl3_rows_partials(M)) holds per-block shares of the loss (already divided by nnz);
+ * probs nullable. */
 int dl3_count_nonzero(const float *w, int M, float *out, void *stream);
 int dl3_softmax_xent(const float *logits, const float *labels, const float *weights, const float *nnz,
                      float *probs, float *dlogits, float *loss_partial, int M, int C, void *stream);

@@ -72,6 +72,11 @@ def lib():
     global _lib, _protos
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so); it must be loaded first so that libdl3.so
+    # binds to the SAME runtime instance whose streams and device pointers it is handed
+    import torch  # noqa: F401
+    if torch.cuda.is_available():
+        torch.cuda.init()
     if not os.path.exists(LIBPATH):
         raise DL3Error(
             "libdl3.so not found at %s — build it with `python __graft_entry__.py` "

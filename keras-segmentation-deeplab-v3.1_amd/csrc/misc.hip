@@ -144,7 +144,7 @@ __global__ void count_to_float_kernel(unsigned int *cnt) {
   *reinterpret_cast<float *>(cnt) = (float)v;
 }
 
-// loss_partial[blockIdx.x] = sum over the block's rows of w*(-log clip(p_label));
+// loss_partial[blockIdx.x] = sum over the block's rows of w*(-log clip(p_label))/nnz;
 // dlogits = (p - onehot) * w / nnz ; label == C (void) -> onehot = 0 and, by the generator's
 // contract (utils.py:388-399), w = 0.
 __global__ __launch_bounds__(256) void softmax_xent_kernel(const float *__restrict__ x,
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float *__restri
       // Keras categorical_crossentropy on probabilities: renormalise, clip to [1e-7, 1-1e-7], -log
       float q = pt / psum;
       q = fminf(fmaxf(q, 1e-7f), 1.f - 1e-7f);
-      lsum += -logf(q) * w;
+      lsum += -logf(q) * w * inv_nnz;
     }
   }
   lsum = wave_sum(lsum);
