@@ -37,21 +37,31 @@ struct GemmArgs {
 
 constexpr int BK = 16;
 
-template <int TM, int TN, int WM, int WN, bool AVEC, bool BVEC>
-__global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs P) {
+// Main loop structure (both kernels): global -> registers -> LDS, double-buffered LDS (ONE barrier per
+// K-tile), MFMA operand fragments prefetched one k-step ahead.  Out-of-range rows / columns are handled by
+// clamping the ADDRESS (always in bounds, so loads are unconditional and branch-free) and zeroing the VALUE
+// when it is written to LDS.
+template <int TM, int TN, int WM, int WN, bool VEC>
+__global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmArgs P) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr int LDA = BM + 2;  // 4*LDA == 8 (mod 32): transposed 4-float stores hit distinct banks
   constexpr int LDB = BN + 4;
-  constexpr int NA = BM / 64;                   // float4 A loads per thread per K-tile
-  constexpr int NB = (4 * BN + 255) / 256;      // float4 B loads per thread per K-tile
-  __shared__ float lds[BK * LDA + BK * LDB];
-  float *As = lds, *Bs = lds + BK * LDA;
+  constexpr int NA = BM / 64;               // float4 A loads per thread per K-tile
+  constexpr int NB = (4 * BN + 255) / 256;  // float4 B loads per thread per K-tile
+  constexpr int STAGE = BK * LDA + BK * LDB;
+  __shared__ float lds[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int n0 = blockIdx.x * BN;
+  // XCD-aware remap (workgroup b runs on XCD b % 8): give each XCD a contiguous run of logical ids so that the
+  // column tiles of one row tile — which re-read the same A rows — share one XCD's L2.  Speed only.
+  const int nwg = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = b & 7;
+  const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (b >> 3);
+  const int bx = lid % gridDim.x, by = lid / gridDim.x;
+  const int n0 = bx * BN;
   const int akq = tid & 3, amr = tid >> 2;
   const int ktiles = (P.K + BK - 1) / BK;
   const bool xform = (P.ka != nullptr);
@@ -61,7 +71,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs P) {
 #pragma unroll
   for (int i = 0; i < TN; i++) st1[i] = st2[i] = 0.f;
 
-  for (int mt = blockIdx.y; mt < P.mtiles; mt += gridDim.y) {
+  for (int mt = by; mt < P.mtiles; mt += gridDim.y) {
     const int m0 = mt * BM;
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -75,65 +85,62 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs P) {
 
     auto load_tiles = [&](int kt) {
       const int k = kt * BK + akq * 4;
+      if (VEC) {
+        const int kc = min(k, P.K - 4);
 #pragma unroll
-      for (int i = 0; i < NA; i++) {
-        const int row = m0 + amr + 64 * i;
-        ra[i] = splat4(0.f);
-        ra2[i] = splat4(0.f);
-        if (row < P.M) {
-          if (AVEC) {
-            if (k < P.K) {
-              ra[i] = ld4(P.a + (size_t)row * P.lda + k);
-              if (two) ra2[i] = ld4(P.a2 + (size_t)row * P.lda2 + k);
-            }
-          } else {
+        for (int i = 0; i < NA; i++) {
+          const int row = min(m0 + amr + 64 * i, P.M - 1);
+          ra[i] = ld4(P.a + (size_t)row * P.lda + kc);
+          if (two) ra2[i] = ld4(P.a2 + (size_t)row * P.lda2 + kc);
+        }
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-              if (k + j < P.K) {
-                ra[i][j] = P.a[(size_t)row * P.lda + k + j];
-                if (two) ra2[i][j] = P.a2[(size_t)row * P.lda2 + k + j];
-              }
+        for (int i = 0; i < NB; i++) {
+          const int idx = tid + 256 * i;
+          if (NB * 256 == 4 * BN || idx < 4 * BN) {
+            const int kk = idx / (BN / 4), nq = idx % (BN / 4);
+            const int krow = min(kt * BK + kk, P.K - 1), col = min(n0 + nq * 4, P.N - 4);
+            rb[i] = ld4(P.b + (size_t)krow * P.ldb + col);
           }
         }
-      }
+      } else {
 #pragma unroll
-      for (int i = 0; i < NB; i++) {
-        const int idx = tid + 256 * i;
-        rb[i] = splat4(0.f);
-        if (idx < 4 * BN) {
-          const int kk = idx / (BN / 4), nq = idx % (BN / 4);
-          const int krow = kt * BK + kk, col = n0 + nq * 4;
-          if (krow < P.K) {
-            if (BVEC) {
-              if (col < P.N) rb[i] = ld4(P.b + (size_t)krow * P.ldb + col);
-            } else {
+        for (int i = 0; i < NA; i++) {
+          const int row = min(m0 + amr + 64 * i, P.M - 1);
 #pragma unroll
-              for (int j = 0; j < 4; j++)
-                if (col + j < P.N) rb[i][j] = P.b[(size_t)krow * P.ldb + col + j];
-            }
+          for (int j = 0; j < 4; j++) {
+            const int kc = min(k + j, P.K - 1);
+            ra[i][j] = P.a[(size_t)row * P.lda + kc];
+            if (two) ra2[i][j] = P.a2[(size_t)row * P.lda2 + kc];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+          const int idx = tid + 256 * i;
+          if (NB * 256 == 4 * BN || idx < 4 * BN) {
+            const int kk = idx / (BN / 4), nq = idx % (BN / 4);
+            const int krow = min(kt * BK + kk, P.K - 1);
+#pragma unroll
+            for (int j = 0; j < 4; j++) rb[i][j] = P.b[(size_t)krow * P.ldb + min(n0 + nq * 4 + j, P.N - 1)];
           }
         }
       }
     };
 
-    auto store_tiles = [&](int kt) {
+    auto store_tiles = [&](int kt, float *As, float *Bs) {
       const int k = kt * BK + akq * 4;
       f32x4 fa = splat4(1.f), fb = splat4(0.f), fc = splat4(0.f);
-      bool kok[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) kok[j] = (k + j < P.K);
       if (xform) {
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (kok[j]) {
-            fa[j] = P.ka[k + j];
-            fc[j] = P.kc[k + j];
-            if (two) fb[j] = P.kb[k + j];
-          }
+        for (int j = 0; j < 4; j++) {
+          const int kc = min(k + j, P.K - 1);
+          fa[j] = P.ka[kc];
+          fc[j] = P.kc[kc];
+          if (two) fb[j] = P.kb[kc];
+        }
       }
 #pragma unroll
       for (int i = 0; i < NA; i++) {
-        const int row = m0 + amr + 64 * i;
+        const bool rok = (m0 + amr + 64 * i) < P.M;
         f32x4 v = ra[i];
         if (xform) {
           v = fa * v + fc;
@@ -141,64 +148,76 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs P) {
         }
         v = dl3_act4(v, P.a_act);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const float o = (row < P.M && kok[j]) ? v[j] : 0.f;
-          As[(akq * 4 + j) * LDA + amr + 64 * i] = o;
-        }
+        for (int j = 0; j < 4; j++) As[(akq * 4 + j) * LDA + amr + 64 * i] = (rok && (k + j < P.K)) ? v[j] : 0.f;
       }
 #pragma unroll
       for (int i = 0; i < NB; i++) {
         const int idx = tid + 256 * i;
-        if (idx < 4 * BN) {
+        if (NB * 256 == 4 * BN || idx < 4 * BN) {
           const int kk = idx / (BN / 4), nq = idx % (BN / 4);
-          st4(&Bs[kk * LDB + nq * 4], rb[i]);
+          const bool kok = (kt * BK + kk) < P.K;
+          f32x4 v = rb[i];
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (!(kok && (n0 + nq * 4 + j < P.N))) v[j] = 0.f;
+          st4(&Bs[kk * LDB + nq * 4], v);
         }
       }
     };
 
     load_tiles(0);
-    __syncthreads();  // previous tile's (or previous m-tile's) LDS reads are done
-    store_tiles(0);
+    __syncthreads();  // the previous m-tile's LDS reads (and the stat fold) are done
+    store_tiles(0, lds, lds + BK * LDA);
     __syncthreads();
     for (int kt = 0; kt < ktiles; ++kt) {
-      if (kt + 1 < ktiles) load_tiles(kt + 1);
+      const float *As = lds + (kt & 1) * STAGE;
+      const float *Bs = As + BK * LDA;
+      const bool more = kt + 1 < ktiles;
+      if (more) load_tiles(kt + 1);
+      float af[2][TM], bf[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) af[0][i] = As[lhi * LDA + (wm * TM + i) * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TN; j++) bf[0][j] = Bs[lhi * LDB + (wn * TN + j) * 32 + l31];
 #pragma unroll
       for (int ks = 0; ks < BK / 2; ++ks) {
-        float af[TM], bf[TN];
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks + 1 < BK / 2) {
 #pragma unroll
-        for (int i = 0; i < TM; i++) af[i] = As[(2 * ks + lhi) * LDA + (wm * TM + i) * 32 + l31];
+          for (int i = 0; i < TM; i++) af[nxt][i] = As[(2 * ks + 2 + lhi) * LDA + (wm * TM + i) * 32 + l31];
 #pragma unroll
-        for (int j = 0; j < TN; j++) bf[j] = Bs[(2 * ks + lhi) * LDB + (wn * TN + j) * 32 + l31];
+          for (int j = 0; j < TN; j++) bf[nxt][j] = Bs[(2 * ks + 2 + lhi) * LDB + (wn * TN + j) * 32 + l31];
+        }
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
           for (int j = 0; j < TN; j++)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
       }
-      if (kt + 1 < ktiles) {
-        __syncthreads();
-        store_tiles(kt + 1);
-        __syncthreads();
+      if (more) {
+        float *An = lds + ((kt + 1) & 1) * STAGE;
+        store_tiles(kt + 1, An, An + BK * LDA);
       }
+      __syncthreads();
     }
 
     // ---------------- epilogue
+    const bool full = (m0 + BM <= P.M) && (n0 + BN <= P.N);
 #pragma unroll
     for (int j = 0; j < TN; j++) {
       const int col = n0 + (wn * TN + j) * 32 + l31;
       const bool cok = col < P.N;
+      const int colc = min(col, P.N - 1);
       float bias = 0.f, es = 1.f, et = 0.f, mu = 0.f, is = 0.f;
-      if (cok) {
-        if (P.bias) bias = P.bias[col];
-        if (P.ep_scale) { es = P.ep_scale[col]; et = P.ep_shift[col]; }
-        if (P.stat_mode == 2) { mu = P.ep_mean[col]; is = P.ep_invstd[col]; }
-      }
+      if (P.bias) bias = P.bias[colc];
+      if (P.ep_scale) { es = P.ep_scale[colc]; et = P.ep_shift[colc]; }
+      if (P.stat_mode == 2) { mu = P.ep_mean[colc]; is = P.ep_invstd[colc]; }
 #pragma unroll
       for (int i = 0; i < TM; i++) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          if (cok && row < P.M) {
+          if (full || (cok && row < P.M)) {
             float v = acc[i][j][r] + bias;
             float xr = 0.f;
             if (P.ep_x) {
@@ -247,8 +266,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(GemmArgs P) {
           a1 += sred[(w * BN + cl) * 2 + 0];
           a2 += sred[(w * BN + cl) * 2 + 1];
         }
-        P.part[((size_t)blockIdx.y * P.N + col) * 2 + 0] = a1;
-        P.part[((size_t)blockIdx.y * P.N + col) * 2 + 1] = a2;
+        P.part[((size_t)by * P.N + col) * 2 + 0] = a1;
+        P.part[((size_t)by * P.N + col) * 2 + 1] = a2;
       }
     }
   }
@@ -267,14 +286,14 @@ struct WgradArgs {
   int M, K, N, Mper;
 };
 
-template <int TA, int TB, int WA, int WB, bool XVEC, bool DVEC>
-__global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs P) {
+template <int TA, int TB, int WA, int WB, bool VEC>
+__global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
   static_assert(WA * WB == 4, "4 waves per workgroup");
   constexpr int BKT = 32 * TA * WA, BNT = 32 * TB * WB, MS = 16;
   constexpr int LDX = BKT + 4, LDD = BNT + 4;
   constexpr int NX = (4 * BKT + 255) / 256, ND = (4 * BNT + 255) / 256;
-  __shared__ float lds[MS * LDX + MS * LDD];
-  float *Xs = lds, *Ds = lds + MS * LDX;
+  constexpr int STAGE = MS * LDX + MS * LDD;
+  __shared__ float lds[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wa = wave / WB, wb = wave % WB;
@@ -293,89 +312,99 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs P) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
+  // per-thread column positions are the same for every M stage: hoist coefficients and validity
+  f32x4 xs4[NX], xt4[NX], kA4[ND], kB4[ND], kC4[ND];
+  bool xok[NX][4], dok[ND][4];
+#pragma unroll
+  for (int i = 0; i < NX; i++) {
+    const int idx = tid + 256 * i;
+    const int k = kbase + (idx % (BKT / 4)) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      xok[i][j] = (k + j) < P.K;
+      const int kc = min(k + j, P.K - 1);
+      xs4[i][j] = xform ? P.xs[kc] : 1.f;
+      xt4[i][j] = xform ? P.xt[kc] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < ND; i++) {
+    const int idx = tid + 256 * i;
+    const int col = nbase + (idx % (BNT / 4)) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      dok[i][j] = (col + j) < P.N;
+      const int cc = min(col + j, P.N - 1);
+      kA4[i][j] = two ? P.cA[cc] : 1.f;
+      kB4[i][j] = two ? P.cB[cc] : 0.f;
+      kC4[i][j] = two ? P.cC[cc] : 0.f;
+    }
+  }
+
   f32x4 rx[NX], rg[ND], ry[ND];
 
   auto load_tiles = [&](int m0) {
 #pragma unroll
     for (int i = 0; i < NX; i++) {
       const int idx = tid + 256 * i;
-      rx[i] = splat4(0.f);
-      if (idx < 4 * BKT) {
+      if (NX * 256 == 4 * BKT || idx < 4 * BKT) {
         const int mr = idx / (BKT / 4), kq = idx % (BKT / 4);
-        const int row = m0 + mr, k = kbase + kq * 4;
-        if (row < mend) {
-          if (XVEC) {
-            if (k < P.K) rx[i] = ld4(P.x + (size_t)row * P.ldx + k);
-          } else {
+        const int row = min(m0 + mr, P.M - 1), k = kbase + kq * 4;
+        if (VEC) {
+          rx[i] = ld4(P.x + (size_t)row * P.ldx + min(k, P.K - 4));
+        } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-              if (k + j < P.K) rx[i][j] = P.x[(size_t)row * P.ldx + k + j];
-          }
+          for (int j = 0; j < 4; j++) rx[i][j] = P.x[(size_t)row * P.ldx + min(k + j, P.K - 1)];
         }
       }
     }
 #pragma unroll
     for (int i = 0; i < ND; i++) {
       const int idx = tid + 256 * i;
-      rg[i] = splat4(0.f);
-      ry[i] = splat4(0.f);
-      if (idx < 4 * BNT) {
+      if (ND * 256 == 4 * BNT || idx < 4 * BNT) {
         const int mr = idx / (BNT / 4), nq = idx % (BNT / 4);
-        const int row = m0 + mr, col = nbase + nq * 4;
-        if (row < mend) {
-          if (DVEC) {
-            if (col < P.N) {
-              rg[i] = ld4(P.g + (size_t)row * P.ldg + col);
-              if (two) ry[i] = ld4(P.y + (size_t)row * P.ldy + col);
-            }
-          } else {
+        const int row = min(m0 + mr, P.M - 1), col = nbase + nq * 4;
+        if (VEC) {
+          const int cc = min(col, P.N - 4);
+          rg[i] = ld4(P.g + (size_t)row * P.ldg + cc);
+          if (two) ry[i] = ld4(P.y + (size_t)row * P.ldy + cc);
+        } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-              if (col + j < P.N) {
-                rg[i][j] = P.g[(size_t)row * P.ldg + col + j];
-                if (two) ry[i][j] = P.y[(size_t)row * P.ldy + col + j];
-              }
+          for (int j = 0; j < 4; j++) {
+            const int cc = min(col + j, P.N - 1);
+            rg[i][j] = P.g[(size_t)row * P.ldg + cc];
+            if (two) ry[i][j] = P.y[(size_t)row * P.ldy + cc];
           }
         }
       }
     }
   };
 
-  auto store_tiles = [&](int m0) {
+  auto store_tiles = [&](int m0, float *Xs, float *Ds) {
 #pragma unroll
     for (int i = 0; i < NX; i++) {
       const int idx = tid + 256 * i;
-      if (idx < 4 * BKT) {
+      if (NX * 256 == 4 * BKT || idx < 4 * BKT) {
         const int mr = idx / (BKT / 4), kq = idx % (BKT / 4);
-        const int row = m0 + mr, k = kbase + kq * 4;
-        f32x4 v = rx[i];
-        if (xform) {
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-            if (k + j < P.K) v[j] = P.xs[k + j] * v[j] + P.xt[k + j];
-        }
-        v = dl3_act4(v, P.x_act);
+        const bool rok = (m0 + mr) < mend;
+        f32x4 v = dl3_act4(xs4[i] * rx[i] + xt4[i], P.x_act);
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          if (!(row < mend && k + j < P.K)) v[j] = 0.f;
+          if (!(rok && xok[i][j])) v[j] = 0.f;
         st4(&Xs[mr * LDX + kq * 4], v);
       }
     }
 #pragma unroll
     for (int i = 0; i < ND; i++) {
       const int idx = tid + 256 * i;
-      if (idx < 4 * BNT) {
+      if (ND * 256 == 4 * BNT || idx < 4 * BNT) {
         const int mr = idx / (BNT / 4), nq = idx % (BNT / 4);
-        const int row = m0 + mr, col = nbase + nq * 4;
-        f32x4 v = rg[i];
-        if (two) {
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-            if (col + j < P.N) v[j] = P.cA[col + j] * v[j] + P.cB[col + j] * ry[i][j] + P.cC[col + j];
-        }
+        const bool rok = (m0 + mr) < mend;
+        f32x4 v = kA4[i] * rg[i] + kC4[i];
+        if (two) v += kB4[i] * ry[i];
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          if (!(row < mend && col + j < P.N)) v[j] = 0.f;
+          if (!(rok && dok[i][j])) v[j] = 0.f;
         st4(&Ds[mr * LDD + nq * 4], v);
       }
     }
@@ -383,29 +412,39 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs P) {
 
   if (mbeg < mend) {
     load_tiles(mbeg);
-    store_tiles(mbeg);
+    store_tiles(mbeg, lds, lds + MS * LDX);
     __syncthreads();
-    for (int m0 = mbeg; m0 < mend; m0 += MS) {
+    int stage = 0;
+    for (int m0 = mbeg; m0 < mend; m0 += MS, stage ^= 1) {
+      const float *Xs = lds + stage * STAGE;
+      const float *Ds = Xs + MS * LDX;
       const bool more = (m0 + MS < mend);
       if (more) load_tiles(m0 + MS);
+      float af[2][TA], bf[2][TB];
+#pragma unroll
+      for (int i = 0; i < TA; i++) af[0][i] = Xs[lhi * LDX + (wa * TA + i) * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TB; j++) bf[0][j] = Ds[lhi * LDD + (wb * TB + j) * 32 + l31];
 #pragma unroll
       for (int ks = 0; ks < MS / 2; ++ks) {
-        float af[TA], bf[TB];
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks + 1 < MS / 2) {
 #pragma unroll
-        for (int i = 0; i < TA; i++) af[i] = Xs[(2 * ks + lhi) * LDX + (wa * TA + i) * 32 + l31];
+          for (int i = 0; i < TA; i++) af[nxt][i] = Xs[(2 * ks + 2 + lhi) * LDX + (wa * TA + i) * 32 + l31];
 #pragma unroll
-        for (int j = 0; j < TB; j++) bf[j] = Ds[(2 * ks + lhi) * LDD + (wb * TB + j) * 32 + l31];
+          for (int j = 0; j < TB; j++) bf[nxt][j] = Ds[(2 * ks + 2 + lhi) * LDD + (wb * TB + j) * 32 + l31];
+        }
 #pragma unroll
         for (int i = 0; i < TA; i++)
 #pragma unroll
           for (int j = 0; j < TB; j++)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
       }
       if (more) {
-        __syncthreads();
-        store_tiles(m0 + MS);
-        __syncthreads();
+        float *Xn = lds + (stage ^ 1) * STAGE;
+        store_tiles(m0 + MS, Xn, Xn + MS * LDX);
       }
+      __syncthreads();
     }
   }
   float *out = P.ws + (size_t)blockIdx.z * P.K * P.N;
@@ -470,15 +509,17 @@ int gemm_grid_y(int M, int N, const GemmCfg &c) {
   const int mtiles = dl3_cdiv(M, c.BM), ntn = dl3_cdiv(N, c.BN);
   int py = 2048 / ntn;
   if (py < 32) py = 32;
-  return mtiles < py ? mtiles : py;
+  if (mtiles <= py) return mtiles;
+  const int iters = dl3_cdiv(mtiles, py);  // every workgroup loops over the same number of row tiles
+  return dl3_cdiv(mtiles, iters);
 }
 
 template <int TM, int TN, int WM, int WN>
 void launch_gemm(const GemmArgs &A, dim3 grid, hipStream_t st, bool vec) {
   // two instantiations only: 16-byte loads on both operands, or scalar loads on both (tiny GEMMs
   // with N or K = number of classes)
-  if (vec) hipLaunchKernelGGL((pw_gemm_kernel<TM, TN, WM, WN, true, true>), grid, dim3(256), 0, st, A);
-  else hipLaunchKernelGGL((pw_gemm_kernel<TM, TN, WM, WN, false, false>), grid, dim3(256), 0, st, A);
+  if (vec) hipLaunchKernelGGL((pw_gemm_kernel<TM, TN, WM, WN, true>), grid, dim3(256), 0, st, A);
+  else hipLaunchKernelGGL((pw_gemm_kernel<TM, TN, WM, WN, false>), grid, dim3(256), 0, st, A);
 }
 
 inline bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
@@ -538,8 +579,8 @@ int colsum_rows(int M) {
 
 template <int TA, int TB, int WA, int WB>
 void launch_wgrad(const WgradArgs &A, dim3 grid, hipStream_t st, bool vec) {
-  if (vec) hipLaunchKernelGGL((pw_wgrad_kernel<TA, TB, WA, WB, true, true>), grid, dim3(256), 0, st, A);
-  else hipLaunchKernelGGL((pw_wgrad_kernel<TA, TB, WA, WB, false, false>), grid, dim3(256), 0, st, A);
+  if (vec) hipLaunchKernelGGL((pw_wgrad_kernel<TA, TB, WA, WB, true>), grid, dim3(256), 0, st, A);
+  else hipLaunchKernelGGL((pw_wgrad_kernel<TA, TB, WA, WB, false>), grid, dim3(256), 0, st, A);
 }
 
 }  // namespace
