@@ -145,6 +145,12 @@ int dl3_grad_finish(const float *gin, int ldgin, int gin_div, float gin_scale, f
                     const float *add, int ldadd, const float *xraw, int ldx, const float *scale,
                     const float *shift, int act, const float *mean, const float *invstd, float *dstat_partial,
                     int M, int C, float drop_rate, unsigned long long drop_seed, void *stream);
+/* strided 1x1 convolutions (Xception shortcuts, _conv2d_same(kernel_size=1, stride=2), deeplabv3p.py:143-145) sample
+ * rows/cols 0, s, 2s, ...: y[n,oy,ox,c] = T(x)[n, oy*s, ox*s, c] compacts the sampled pixels for the GEMM;
+ * the backward scatters the compact gradient back (zeros elsewhere). */
+int dl3_subsample_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act, float *y,
+                      int N, int H, int W, int C, int stride, int Ho, int Wo, void *stream);
+int dl3_subsample_bwd(const float *g, float *dx, int N, int H, int W, int C, int stride, int Ho, int Wo, void *stream);
 /* AveragePooling2D over the whole map (deeplabv3p.py:375): out[n][c] = out_scale * sum_hw T(x)[n,hw,c] */
 int dl3_gap_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act, float *out,
                 int N, int HW, int C, float out_scale, void *stream);

@@ -235,6 +235,34 @@ __global__ __launch_bounds__(256) void gap_kernel(const float *__restrict__ x, i
   }
 }
 
+// y[n,oy,ox,c] = T(x)[n, oy*s, ox*s, c]; grid (ceil(Wo*C/256), N*Ho)
+__global__ __launch_bounds__(256) void subsample_fwd_kernel(const float *__restrict__ x, int ldx,
+                                                            const float *__restrict__ sc,
+                                                            const float *__restrict__ sh, int act,
+                                                            float *__restrict__ y, int H, int W, int C, int stride,
+                                                            int Ho, int Wo) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Wo * C) return;
+  const int ox = i / C, c = i - ox * C;
+  const int n = blockIdx.y / Ho, oy = blockIdx.y - n * Ho;
+  float v = x[(((size_t)n * H + (size_t)oy * stride) * W + (size_t)ox * stride) * ldx + c];
+  if (sc) v = sc[c] * v + sh[c];
+  y[((size_t)blockIdx.y * Wo) * C + i] = dl3_act(v, act);
+}
+
+// dx[n,iy,ix,c] = g[n,iy/s,ix/s,c] if iy%s==0 && ix%s==0 else 0; grid (ceil(W*C/256), N*H)
+__global__ __launch_bounds__(256) void subsample_bwd_kernel(const float *__restrict__ g, float *__restrict__ dx,
+                                                            int H, int W, int C, int stride, int Ho, int Wo) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= W * C) return;
+  const int ix = i / C, c = i - ix * C;
+  const int n = blockIdx.y / H, iy = blockIdx.y - n * H;
+  float v = 0.f;
+  if (iy % stride == 0 && ix % stride == 0 && iy / stride < Ho && ix / stride < Wo)
+    v = g[(((size_t)n * Ho + iy / stride) * Wo + ix / stride) * C + c];
+  dx[((size_t)blockIdx.y * W) * C + i] = v;
+}
+
 __global__ __launch_bounds__(256) void fill_kernel(float *p, float v, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
 }
@@ -371,5 +399,26 @@ extern "C" int dl3_adam_step(float *p, const float *g, float *m, float *v, size_
   hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, beta1,
                      beta2, eps, grad_scale);
   DL3_LAUNCH_CHECK("adam_step");
+  return DL3_OK;
+}
+
+extern "C" int dl3_subsample_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
+                                 float *y, int N, int H, int W, int C, int stride, int Ho, int Wo, void *stream) {
+  DL3_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && stride >= 1 && Ho > 0 && Wo > 0, "subsample_fwd: bad argument");
+  DL3_CHECK_ARG((Ho - 1) * stride < H && (Wo - 1) * stride < W && ldx >= C, "subsample_fwd: geometry out of range");
+  DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "subsample_fwd: scale/shift must come together");
+  DL3_UNSUPPORTED((long)N * Ho > 65535L * 32768L, "subsample_fwd: too many rows");
+  hipLaunchKernelGGL(subsample_fwd_kernel, dim3(dl3_cdiv(Wo * C, 256), N * Ho), dim3(256), 0, (hipStream_t)stream, x,
+                     ldx, in_scale, in_shift, in_act, y, H, W, C, stride, Ho, Wo);
+  DL3_LAUNCH_CHECK("subsample_fwd");
+  return DL3_OK;
+}
+
+extern "C" int dl3_subsample_bwd(const float *g, float *dx, int N, int H, int W, int C, int stride, int Ho, int Wo,
+                                 void *stream) {
+  DL3_CHECK_ARG(g && dx && N > 0 && H > 0 && W > 0 && C > 0 && stride >= 1 && Ho > 0 && Wo > 0, "subsample_bwd: bad argument");
+  hipLaunchKernelGGL(subsample_bwd_kernel, dim3(dl3_cdiv(W * C, 256), N * H), dim3(256), 0, (hipStream_t)stream, g, dx,
+                     H, W, C, stride, Ho, Wo);
+  DL3_LAUNCH_CHECK("subsample_bwd");
   return DL3_OK;
 }

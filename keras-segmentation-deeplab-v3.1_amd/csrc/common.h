@@ -39,17 +39,19 @@ void dl3_set_error(const char *fmt, ...);
 static inline int dl3_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---------------------------------------------------------------- device helpers
+// Branch-free activation: act is wave-uniform, so the clamp bounds are scalar selects and the activation is
+// one v_max + one v_min — no control flow that would make hipcc serialise neighbouring loads behind s_waitcnt.
+//   DL3_ACT_NONE: [-inf, +inf]   DL3_ACT_RELU: [0, +inf] (deeplabv3p.py:72)   DL3_ACT_RELU6: [0, 6] (deeplabv3p.py:181)
 __device__ __forceinline__ float dl3_act(float v, int act) {
-  // DL3_ACT_RELU: max(v,0); DL3_ACT_RELU6: min(max(v,0),6)   (deeplabv3p.py:72,:181)
-  if (act == DL3_ACT_RELU) return fmaxf(v, 0.f);
-  if (act == DL3_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
-  return v;
+  const float lo = (act != DL3_ACT_NONE) ? 0.f : -__builtin_inff();
+  const float hi = (act == DL3_ACT_RELU6) ? 6.f : __builtin_inff();
+  return fminf(fmaxf(v, lo), hi);
 }
-// derivative mask of the activation at pre-activation z
+// derivative mask of the activation at pre-activation z: 1 inside the open interval (lo, hi)
 __device__ __forceinline__ float dl3_act_mask(float z, int act) {
-  if (act == DL3_ACT_RELU) return z > 0.f ? 1.f : 0.f;
-  if (act == DL3_ACT_RELU6) return (z > 0.f && z < 6.f) ? 1.f : 0.f;
-  return 1.f;
+  const float lo = (act != DL3_ACT_NONE) ? 0.f : -__builtin_inff();
+  const float hi = (act == DL3_ACT_RELU6) ? 6.f : __builtin_inff();
+  return (z > lo && z < hi) ? 1.f : 0.f;
 }
 __device__ __forceinline__ f32x4 dl3_act4(f32x4 v, int act) {
   f32x4 r;

@@ -78,39 +78,45 @@ __global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x,
   const int k1 = min(k0 + TK, Ka);
 
   f32x4 wv[9], s = splat4(1.f), t = splat4(0.f);
-  if (active) {
 #pragma unroll
-    for (int i = 0; i < 9; i++) wv[i] = ld4(w + (size_t)i * C + c);
-    if (sc) { s = ld4(sc + c); t = ld4(sh + c); }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 9; i++) wv[i] = splat4(0.f);
-  }
+  for (int i = 0; i < 9; i++) wv[i] = ld4(w + (size_t)i * C + min(c, C - 4));
+  if (sc) { s = ld4(sc + min(c, C - 4)); t = ld4(sh + min(c, C - 4)); }
   const bool xl_ok = (xx - r >= 0), xr_ok = (xx + r < W);
-  const float *xbase = x + ((size_t)n * H * W) * C + c;
+  // clamped coordinates: every lane always issues in-bounds loads (no branches -> the loads of a row group are
+  // all in flight together); out-of-image taps and idle lanes are zeroed by a select afterwards
+  const int cc = min(c, C - 4), xc = min(xx, W - 1), xlc = min(max(xx - r, 0), W - 1), xrc = min(xx + r, W - 1);
+  const float *xbase = x + ((size_t)n * H * W) * C + cc;
   float *ybase = y + ((size_t)n * H * W) * C + c;
+  const int Kc = max(Ka - 1, 0);
 
   auto ldrow = [&](int k, f32x4 &l, f32x4 &m, f32x4 &rr) {
-    l = m = rr = splat4(0.f);
-    if (active && k >= 0 && k < Ka) {
-      const float *row = xbase + (size_t)(a + k * r) * W * C;
-      m = dl3_act4(s * ld4(row + (size_t)xx * C) + t, act);
-      if (xl_ok) l = dl3_act4(s * ld4(row + (size_t)(xx - r) * C) + t, act);
-      if (xr_ok) rr = dl3_act4(s * ld4(row + (size_t)(xx + r) * C) + t, act);
-    }
+    const bool rok = active && k >= 0 && k < Ka;
+    const float *row = xbase + (size_t)(a + min(max(k, 0), Kc) * r) * W * C;
+    const f32x4 vm = dl3_act4(s * ld4(row + (size_t)xc * C) + t, act);
+    const f32x4 vl = dl3_act4(s * ld4(row + (size_t)xlc * C) + t, act);
+    const f32x4 vr = dl3_act4(s * ld4(row + (size_t)xrc * C) + t, act);
+    // multiply by 0/1 instead of selecting: a select lets the compiler sink the loads into a branch again
+    m = vm * splat4(rok ? 1.f : 0.f);
+    l = vl * splat4((rok && xl_ok) ? 1.f : 0.f);
+    rr = vr * splat4((rok && xr_ok) ? 1.f : 0.f);
   };
 
   f32x4 accA = splat4(0.f), accB = splat4(0.f), s1 = splat4(0.f), s2 = splat4(0.f);
-  f32x4 nl, nm, nr;
-  if (k0 < k1) {
-    ldrow(k0 - 1, nl, nm, nr);
-    for (int k = k0 - 1; k <= k1; ++k) {
-      f32x4 l = nl, m = nm, rr = nr;
-      if (k + 1 <= k1) ldrow(k + 1, nl, nm, nr);
+  // rows are processed in groups of R: all 3*R loads of a group are issued before the first use, so every lane
+  // keeps R cache-missing (centre-tap) loads in flight — the kernel is latency-bound otherwise
+  constexpr int R = 4;
+  for (int kg = k0 - 1; kg <= k1 && k0 < k1; kg += R) {
+    f32x4 l[R], m[R], rr[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) ldrow((kg + j <= k1) ? kg + j : -1, l[j], m[j], rr[j]);
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      const int k = kg + j;
+      if (k > k1) break;
       // input row k feeds out[k+1] (tap row 0), out[k] (tap row 1), out[k-1] (tap row 2)
-      f32x4 h0 = wv[0] * l + wv[1] * m + wv[2] * rr;
-      f32x4 h1 = wv[3] * l + wv[4] * m + wv[5] * rr;
-      f32x4 h2 = wv[6] * l + wv[7] * m + wv[8] * rr;
+      f32x4 h0 = wv[0] * l[j] + wv[1] * m[j] + wv[2] * rr[j];
+      f32x4 h1 = wv[3] * l[j] + wv[4] * m[j] + wv[5] * rr[j];
+      f32x4 h2 = wv[6] * l[j] + wv[7] * m[j] + wv[8] * rr[j];
       f32x4 out = accA + h2;
       if (active && k - 1 >= k0 && k - 1 < k1) {
         st4(ybase + ((size_t)(a + (k - 1) * r) * W + xx) * C, out);
@@ -156,42 +162,40 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
 
   f32x4 wv[9], s = splat4(1.f), t = splat4(0.f);
   f32x4 kA = splat4(1.f), kB = splat4(0.f), kC = splat4(0.f), mu = splat4(0.f), is = splat4(0.f);
-  if (active) {
+  {
+    const int c4 = min(c, C - 4);
 #pragma unroll
-    for (int i = 0; i < 9; i++) wv[i] = ld4(w + (size_t)i * C + c);
-    if (sc) { s = ld4(sc + c); t = ld4(sh + c); }
-    if (cA) { kA = ld4(cA + c); kB = ld4(cB + c); kC = ld4(cC + c); }
-    if (dpart) { mu = ld4(xmean + c); is = ld4(xinvstd + c); }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 9; i++) wv[i] = splat4(0.f);
+    for (int i = 0; i < 9; i++) wv[i] = ld4(w + (size_t)i * C + c4);
+    if (sc) { s = ld4(sc + c4); t = ld4(sh + c4); }
+    if (cA) { kA = ld4(cA + c4); kB = ld4(cB + c4); kC = ld4(cC + c4); }
+    if (dpart) { mu = ld4(xmean + c4); is = ld4(xinvstd + c4); }
   }
   const bool two = (cA != nullptr);
   const bool xl_ok = (xx - r >= 0), xr_ok = (xx + r < W);
-  const size_t img = ((size_t)n * H * W) * C + c;
+  const int cc = min(c, C - 4), xc = min(xx, W - 1), xlc = min(max(xx - r, 0), W - 1), xrc = min(xx + r, W - 1);
+  const size_t img = ((size_t)n * H * W) * C + c;    // own position (stores)
+  const size_t imgc = ((size_t)n * H * W) * C + cc;  // clamped (loads)
+  const int Kc = max(Ka - 1, 0);
+  const float *yr = two ? yraw : g;  // when dY = g the second stream aliases the first (coefficient 0)
 
-  auto ld_dd1 = [&](size_t off) -> f32x4 {
-    f32x4 gv = ld4(g + off);
-    if (two) return kA * gv + kB * ld4(yraw + off) + kC;
-    return gv;
-  };
+  auto ld_dd1 = [&](size_t off) -> f32x4 { return kA * ld4(g + off) + kB * ld4(yr + off) + kC; };
   auto ld_dd = [&](int k, f32x4 &l, f32x4 &m, f32x4 &rr) {
-    l = m = rr = splat4(0.f);
-    if (active && k >= 0 && k < Ka) {
-      const size_t row = img + (size_t)(a + k * r) * W * C;
-      m = ld_dd1(row + (size_t)xx * C);
-      if (xl_ok) l = ld_dd1(row + (size_t)(xx - r) * C);
-      if (xr_ok) rr = ld_dd1(row + (size_t)(xx + r) * C);
-    }
+    const bool rok = active && k >= 0 && k < Ka;
+    const size_t row = imgc + (size_t)(a + min(max(k, 0), Kc) * r) * W * C;
+    const f32x4 vm = ld_dd1(row + (size_t)xc * C), vl = ld_dd1(row + (size_t)xlc * C),
+                vr = ld_dd1(row + (size_t)xrc * C);
+    m = vm * splat4(rok ? 1.f : 0.f);
+    l = vl * splat4((rok && xl_ok) ? 1.f : 0.f);
+    rr = vr * splat4((rok && xr_ok) ? 1.f : 0.f);
   };
   // forward input row k at own column: raw value and validity
   auto ld_e = [&](int k, f32x4 &raw, bool &ok) {
     ok = active && k >= 0 && k < Ka;
-    raw = splat4(0.f);
-    if (ok) raw = ld4(x + img + ((size_t)(a + k * r) * W + xx) * C);
+    raw = ld4(x + imgc + ((size_t)(a + min(max(k, 0), Kc) * r) * W + xc) * C);
   };
   auto eact = [&](f32x4 raw, bool ok) -> f32x4 {
-    return ok ? dl3_act4(s * raw + t, act) : splat4(0.f);
+    const f32x4 v = dl3_act4(s * raw + t, act);
+    return v * splat4(ok ? 1.f : 0.f);
   };
 
   f32x4 dwv[9];
@@ -200,42 +204,51 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
   f32x4 accA = splat4(0.f), accB = splat4(0.f), s1 = splat4(0.f), s2 = splat4(0.f);
 
   if (k0 < k1) {
-    f32x4 nl, nm, nr, e_prev = splat4(0.f), e_cur, e_next;
+    // groups of R dY rows: the 7*R loads of a group (3 taps x {g, yraw} + the forward input row) are issued
+    // together, R x 3 of them cache-missing — twice the bytes in flight of a one-row software pipeline
+    constexpr int R = 2;
+    f32x4 e_prev = splat4(0.f), e_cur, e_next;
     bool ok_prev = false, ok_cur, ok_next;
-    ld_dd(k0 - 1, nl, nm, nr);
     ld_e(k0 - 1, e_cur, ok_cur);
     ld_e(k0, e_next, ok_next);
-    for (int k = k0 - 1; k <= k1; ++k) {
-      f32x4 l = nl, m = nm, rr = nr;
-      f32x4 e_nn;
-      bool ok_nn;
-      if (k + 1 <= k1) ld_dd(k + 1, nl, nm, nr);
-      ld_e(k + 2, e_nn, ok_nn);
-      if (k >= k0 && k < k1) {
-        // dW[i][j] += T(x)[k+i-1][x] * dY[k][x-(j-1)r] : j=0 -> right tap, j=2 -> left tap
-        f32x4 ea0 = eact(e_prev, ok_prev), ea1 = eact(e_cur, ok_cur), ea2 = eact(e_next, ok_next);
-        dwv[0] += ea0 * rr; dwv[1] += ea0 * m; dwv[2] += ea0 * l;
-        dwv[3] += ea1 * rr; dwv[4] += ea1 * m; dwv[5] += ea1 * l;
-        dwv[6] += ea2 * rr; dwv[7] += ea2 * m; dwv[8] += ea2 * l;
+    for (int kg = k0 - 1; kg <= k1; kg += R) {
+      f32x4 l[R], m[R], rr[R], e_new[R];
+      bool ok_new[R];
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+        ld_dd((kg + j <= k1) ? kg + j : -1, l[j], m[j], rr[j]);
+        ld_e(kg + j + 2, e_new[j], ok_new[j]);
       }
-      // dY row k feeds dx[k-1] (tap row 0), dx[k] (tap row 1), dx[k+1] (tap row 2)
-      f32x4 h0 = wv[0] * rr + wv[1] * m + wv[2] * l;
-      f32x4 h1 = wv[3] * rr + wv[4] * m + wv[5] * l;
-      f32x4 h2 = wv[6] * rr + wv[7] * m + wv[8] * l;
-      f32x4 out = accA + h0;
-      if (dx && active && k - 1 >= k0 && k - 1 < k1) {
-        const size_t off = img + ((size_t)(a + (k - 1) * r) * W + xx) * C;
-        out = out * dl3_mask4(s * e_prev + t, act);
-        if (dx_add) out += ld4(dx_add + off);
-        st4(dx + off, out);
-        s1 += out;
-        s2 += out * ((e_prev - mu) * is);
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+        const int k = kg + j;
+        if (k > k1) break;
+        if (k >= k0 && k < k1) {
+          // dW[i][j] += T(x)[k+i-1][x] * dY[k][x-(j-1)r] : j=0 -> right tap, j=2 -> left tap
+          f32x4 ea0 = eact(e_prev, ok_prev), ea1 = eact(e_cur, ok_cur), ea2 = eact(e_next, ok_next);
+          dwv[0] += ea0 * rr[j]; dwv[1] += ea0 * m[j]; dwv[2] += ea0 * l[j];
+          dwv[3] += ea1 * rr[j]; dwv[4] += ea1 * m[j]; dwv[5] += ea1 * l[j];
+          dwv[6] += ea2 * rr[j]; dwv[7] += ea2 * m[j]; dwv[8] += ea2 * l[j];
+        }
+        // dY row k feeds dx[k-1] (tap row 0), dx[k] (tap row 1), dx[k+1] (tap row 2)
+        f32x4 h0 = wv[0] * rr[j] + wv[1] * m[j] + wv[2] * l[j];
+        f32x4 h1 = wv[3] * rr[j] + wv[4] * m[j] + wv[5] * l[j];
+        f32x4 h2 = wv[6] * rr[j] + wv[7] * m[j] + wv[8] * l[j];
+        f32x4 out = accA + h0;
+        if (dx && active && k - 1 >= k0 && k - 1 < k1) {
+          const size_t off = img + ((size_t)(a + (k - 1) * r) * W + xx) * C;
+          out = out * dl3_mask4(s * e_prev + t, act);
+          if (dx_add) out += ld4(dx_add + off);
+          st4(dx + off, out);
+          s1 += out;
+          s2 += out * ((e_prev - mu) * is);
+        }
+        accA = accB + h1;
+        accB = h2;
+        e_prev = e_cur; ok_prev = ok_cur;
+        e_cur = e_next; ok_cur = ok_next;
+        e_next = e_new[j]; ok_next = ok_new[j];
       }
-      accA = accB + h1;
-      accB = h2;
-      e_prev = e_cur; ok_prev = ok_cur;
-      e_cur = e_next; ok_cur = ok_next;
-      e_next = e_nn; ok_next = ok_nn;
     }
   }
   const int p = (n * gridDim.y + pc) * nxseg + xs;

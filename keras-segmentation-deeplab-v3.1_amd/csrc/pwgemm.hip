@@ -201,7 +201,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmArgs P) {
       __syncthreads();
     }
 
-    // ---------------- epilogue
+    // ---------------- epilogue: all global reads of a 32x32 sub-tile are issued up front (clamped addresses,
+    // no branches) so 16-32 loads per lane are in flight; values outside the matrix are dropped at the store
     const bool full = (m0 + BM <= P.M) && (n0 + BN <= P.N);
 #pragma unroll
     for (int j = 0; j < TN; j++) {
@@ -214,28 +215,40 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmArgs P) {
       if (P.stat_mode == 2) { mu = P.ep_mean[colc]; is = P.ep_invstd[colc]; }
 #pragma unroll
       for (int i = 0; i < TM; i++) {
+        const int rbase = m0 + (wm * TM + i) * 32 + 4 * lhi;
+        float xr[16], ad[16];
+        if (P.ep_x) {
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int row = min(rbase + (r & 3) + 8 * (r >> 2), P.M - 1);
+            xr[r] = P.ep_x[(size_t)row * P.ld_epx + colc];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; r++) xr[r] = 0.f;
+        }
+        if (P.ep_add) {
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int row = min(rbase + (r & 3) + 8 * (r >> 2), P.M - 1);
+            const int arow = (P.add_div > 1) ? row / P.add_div : row;
+            ad[r] = P.add_scale * P.ep_add[(size_t)arow * P.ld_add + colc];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; r++) ad[r] = 0.f;
+        }
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-          const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          if (full || (cok && row < P.M)) {
-            float v = acc[i][j][r] + bias;
-            float xr = 0.f;
-            if (P.ep_x) {
-              xr = P.ep_x[(size_t)row * P.ld_epx + col];
-              v *= dl3_act_mask(es * xr + et, P.ep_act);
-            }
-            if (P.ep_add) {
-              const int arow = (P.add_div > 1) ? row / P.add_div : row;
-              v += P.add_scale * P.ep_add[(size_t)arow * P.ld_add + col];
-            }
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          const bool ok = full || (cok && row < P.M);
+          float v = acc[i][j][r] + bias;
+          if (P.ep_x) v *= dl3_act_mask(es * xr[r] + et, P.ep_act);
+          v += ad[r];
+          if (ok) {
             P.c[(size_t)row * P.ldc + col] = v;
-            if (P.stat_mode == 1) {
-              st1[j] += v;
-              st2[j] += v * v;
-            } else if (P.stat_mode == 2) {
-              st1[j] += v;
-              st2[j] += v * ((xr - mu) * is);
-            }
+            st1[j] += v;
+            st2[j] += (P.stat_mode == 2) ? v * ((xr[r] - mu) * is) : v * v;
           }
         }
       }

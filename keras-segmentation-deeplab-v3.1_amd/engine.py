@@ -349,7 +349,13 @@ class Engine:
         if l.cfg["k"] == 3:
             return self._lo_conv3x3(l, v)
         if l.cfg["stride"] != 1:
-            raise NotImplementedError("strided 1x1 convolution (%s: Xception shortcut) is not built yet" % l.name)
+            # Xception shortcut (deeplabv3p.py:143-145): compact the sampled pixels, then the ordinary GEMM
+            st = l.cfg["stride"]
+            Ho, Wo = l.output.shape[0], l.output.shape[1]
+            cbuf = Buf(self, self.B, Ho, Wo, v.C, l.name + "_sub")
+            self.bufs.append(cbuf)
+            self.units.append(SubsampleUnit(self, v, View(cbuf, 0, v.C), st))
+            v = View(cbuf, 0, v.C)
         Ho, Wo, N = v.shape[1], v.shape[2], l.cfg["filters"]
         buf, off = self._new_out(l, Ho, Wo, N)
         u = PwUnit(self, l, v, View(buf, off, N), want_stat=self.bn_batch and self._bn_follows(l))
@@ -914,3 +920,22 @@ class ShuffleUnit:
         assert add is None and not inv.buf.bns
         eng.op(eng.ops_bwd, "dl3_phase_shift", ptr(self.outv.buf.grad), ptr(gout), eng.B, inv.buf.H, inv.buf.W,
                self.co, self.r, 1)
+
+
+class SubsampleUnit:
+    """row/column sampling in front of a strided 1x1 convolution (Xception shortcuts, deeplabv3p.py:143-145)"""
+
+    def __init__(self, eng, inv, outv, stride):
+        self.eng, self.inv, self.outv, self.stride = eng, inv, outv, stride
+        eng._consume(inv)
+        s, t, a = inv.xform()
+        self.dims = (eng.B, inv.buf.H, inv.buf.W, inv.C, stride, outv.buf.H, outv.buf.W)
+        eng.op(eng.ops_fwd, "dl3_subsample_fwd", inv.p(), inv.ld, s, t, a, outv.p(), *self.dims)
+
+    def bwd(self):
+        eng, inv = self.eng, self.inv
+        if not inv.buf.requires_grad:
+            return
+        tmp = eng.empty(inv.buf.M * inv.C)
+        eng.op(eng.ops_bwd, "dl3_subsample_bwd", ptr(self.outv.buf.grad), ptr(tmp), *self.dims)
+        eng.contrib_elementwise(inv.buf, inv, ptr(tmp), inv.C)

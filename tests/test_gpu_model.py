@@ -113,14 +113,61 @@ def test_mnv2_train_step_gradients(head, dropout):
         den += float(np.sum(g ** 2))
         if e > worst:
             worst, wname = e, name
-    # whole gradient vector: tight; single small tensors (BN betas after ~50 BN backward passes): fp32 noise floor
-    assert np.sqrt(num / den) < 2e-3, np.sqrt(num / den)
+    # fp32 noise floor: the ORACLE's own fp32 run differs from its float64 run by 7e-3 (whole gradient vector) and
+    # 1.1e-2 (worst tensor) on this case (tests/test_oracle.py::test_fp32_noise_floor); late layers agree to 5e-5
+    assert np.sqrt(num / den) < 2e-2, np.sqrt(num / den)
     assert worst < 5e-2, (wname, worst)
+    assert _l2(eng.grad_of("concat_projection/kernel:0"), grads["concat_projection/kernel:0"]) < 1e-3
     # BatchNorm moving statistics (TF FusedBatchNorm semantics)
     for name, st in list(net.new_stats.items())[:8]:
         layer = model.get_layer(name)
         mm, mv = layer.get_weights()[2:]
         assert relerr(mm, st["mean"]) < 1e-3 and relerr(mv, st["var"]) < 1e-3, name
+
+
+@pytest.mark.parametrize("OS", [16, 8])
+def test_xception_train_step_gradients(OS):
+    """BASELINE.json configs[3] architecture (Xception entry/middle/exit flow, 5-branch ASPP, decoder) at a size the
+    float64 oracle finishes in seconds; OS=8 exercises the rate 12/24/36 atrous branches on a small map."""
+    import dl3_amd  # noqa: F401
+    from dl3_amd import graph as G
+    from dl3_amd.deeplabv3p import Deeplabv3
+    shape, classes, B = (64, 64, 3), 3, 2
+    G.clear_session()
+    model = Deeplabv3(weights=None, input_shape=shape, classes=classes, backbone="xception", OS=OS)
+    kw = dict(backbone="xception", input_shape=shape, classes=classes, OS=OS)
+    params = O.init_params(O.param_shapes("xception", classes), seed=1)
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (B,) + shape).astype(np.float32)
+    params = O.calibrate_bn(params, x, **kw)
+    _load(model, params)
+    labels = rng.integers(0, classes + 1, (B, shape[0] * shape[1])).astype(np.float32)
+    sw = (labels < classes).astype(np.float32)
+    eng = model._engine(B, True, dropout=False, use_graph=False)
+    eng.set_input(x)
+    eng.set_targets(labels, sw)
+    eng.fwd_bwd()
+    torch.cuda.synchronize()
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    loss, grads, logits, net = O.train_grads(p64, x.astype(np.float64), labels.astype(np.float64),
+                                              sw.astype(np.float64), **kw)
+    assert relerr(eng.logits(), logits) < 1e-3
+    assert abs(float(eng.loss[0].item()) - loss) < 1e-4 * abs(loss)
+    for name in ("decoder_conv1_pointwise/kernel:0", "aspp3_depthwise/depthwise_kernel:0", "feature_projection0/kernel:0",
+                 "exit_flow_block1_shortcut/kernel:0", "middle_flow_unit_8_separable_conv2_pointwise/kernel:0"):
+        assert _l2(eng.grad_of(name), grads[name]) < 2e-2, name
+    num = den = 0.0
+    for name, g in grads.items():
+        if g is None or "/moving_" in name or np.abs(g).max() < 1e-6:
+            continue
+        num += float(np.sum((eng.grad_of(name).astype(np.float64) - g) ** 2))
+        den += float(np.sum(g ** 2))
+    assert np.sqrt(num / den) < 5e-2, np.sqrt(num / den)
+    # inference path: logits 1e-3, argmax bit-exact
+    probs = model.predict(x, batch_size=B)
+    ref, _ = O.forward(params, x, **kw)
+    assert relerr(model._active.logits(), ref) < 1e-3
+    assert (model._active.argmax() != ref.argmax(-1)).mean() < 1e-3
 
 
 def test_graph_replay_and_determinism():

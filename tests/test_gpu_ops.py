@@ -38,6 +38,8 @@ DW_CASES = [
     (2, 16, 16, 32, 2, 1, (1, 1), 0, 1),  # explicit ZeroPadding2D + VALID (Xception)
     (1, 8, 8, 16, 1, 12, None, 0, 1),    # rate > size
     (3, 64, 64, 144, 1, 1, None, 0, 2),  # C not a multiple of 32, several row chunks
+    (2, 8, 8, 64, 1, 2, None, 0, 2),     # map narrower than the 32 pixel lanes (idle lanes must stay in bounds)
+    (1, 4, 4, 32, 1, 1, None, 0, 1),
 ]
 
 
@@ -441,6 +443,23 @@ def test_resize_bilinear(L, dims):
     assert relerr(host(dx), dx_ref) < 1e-4
     call("dl3_resize_bilinear_bwd", ptr(dev(g)), C, ptr(dx), C, N, Hi, Wi, Ho, Wo, C, 1)
     assert relerr(host(dx), 2 * dx_ref) < 1e-4
+
+
+def test_subsample(L):
+    rng = np.random.default_rng(15)
+    N, H, W, C, s_ = 2, 9, 10, 24, 2
+    Ho, Wo = (H - 1) // s_ + 1, (W - 1) // s_ + 1
+    x = rng.normal(0, 1, (N, H, W, C)).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, C).astype(np.float32), rng.normal(0, 1, C).astype(np.float32)
+    y = empty(N, Ho, Wo, C)
+    call("dl3_subsample_fwd", ptr(dev(x)), C, ptr(dev(sc)), ptr(dev(sh)), 1, ptr(y), N, H, W, C, s_, Ho, Wo)
+    assert relerr(host(y), np_act(sc * x[:, ::s_, ::s_] + sh, 1)) < 1e-6
+    g = rng.normal(0, 1, (N, Ho, Wo, C)).astype(np.float32)
+    dx = empty(N, H, W, C)
+    call("dl3_subsample_bwd", ptr(dev(g)), ptr(dx), N, H, W, C, s_, Ho, Wo)
+    ref = np.zeros_like(x)
+    ref[:, ::s_, ::s_] = g
+    assert np.array_equal(host(dx), ref)
 
 
 def test_phase_shift(L):
