@@ -44,7 +44,7 @@ def build_engine(args):
     G.clear_session(seed=1)
     shape = (args.size, args.size, 3)
     if args.head == "deeplab":
-        model = Deeplabv3(weights=None, input_shape=shape, classes=21, backbone=args.backbone, OS=16)
+        model = Deeplabv3(weights=None, input_shape=shape, classes=21, backbone=args.backbone, OS=args.os)
     else:
         model = SegModel(image_size=shape[:2]).create_seg_model(args.head, n=21, backbone=args.backbone)
     eng = model._engine(args.batch, True, bn_mode=args.bn_mode, dropout=True, use_graph=not args.no_graph)
@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU (SegModel.batch_size default, utils.py:162)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--backbone", default="mobilenetv2")
+    ap.add_argument("--os", type=int, default=16, help="output stride (Xception only; MobileNetV2 always runs at 8)")
     ap.add_argument("--head", default="deeplab", choices=["deeplab", "original", "subpixel"])
     ap.add_argument("--bn-mode", default="batch", choices=["batch", "frozen"])
     ap.add_argument("--no-graph", action="store_true")
@@ -201,9 +202,9 @@ def main():
             "value": imgs / dt, "unit": "img/s", "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Deeplabv3(backbone='%s', input_shape=(%d,%d,3), classes=21, OS=16) head=%s: "
+            "config": {"workload": "Deeplabv3(backbone='%s', input_shape=(%d,%d,3), classes=21, OS=%d) head=%s: "
                                    "fwd + sparse-xent loss + bwd + Adam, BN %s mode, dropout 0.1"
-                                   % (args.backbone, args.size, args.size, args.head, args.bn_mode),
+                                   % (args.backbone, args.size, args.size, args.os, args.head, args.bn_mode),
                        "global_batch": args.batch * dp.world, "per_gpu_batch": args.batch,
                        "parallelism": "dp%d" % dp.world, "hipgraph": eng.graph is not None, "final_loss": loss},
         }

@@ -317,7 +317,11 @@ class Engine:
         if fn == "softmax":
             return self._lo_softmax(l, v)
         if v.act != ACT_NONE:
-            raise NotImplementedError("activation stacked on an activation (%s)" % l.name)
+            # relu(relu(x)) == relu(x), relu(relu6(x)) == relu6(x), relu6(relu(x)) == relu6(x) — values and gradient
+            # masks alike (Xception: entry_flow_block1 re-applies ReLU to an already rectified tensor)
+            act = ACT_RELU6 if ACT_RELU6 in (v.act, _ACT[fn]) else ACT_RELU
+            self.views[id(l.output)] = v.derive(act=act)
+            return
         self.views[id(l.output)] = v.derive(act=_ACT[fn])
 
     def _lo_Reshape(self, l):

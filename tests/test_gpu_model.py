@@ -48,6 +48,19 @@ def _l2(a, b):
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
 
 
+def _assert_argmax_parity(mask, ref_logits):
+    """masks must be identical except where the ORACLE's own top-2 margin is below the fp32 agreement of the logits
+    (1e-3 relative): a different fp32 summation order may legitimately flip such near-ties.  The count is reported."""
+    ref_mask = ref_logits.argmax(-1)
+    diff = mask != ref_mask
+    if diff.any():
+        srt = np.sort(ref_logits, axis=-1)
+        margin = (srt[..., -1] - srt[..., -2])[diff]
+        assert margin.max() < 1e-3 * np.abs(ref_logits).max(), ("argmax flipped on a clear winner", int(diff.sum()), margin.max())
+        assert diff.mean() < 2e-3, int(diff.sum())
+        print("argmax near-tie flips: %d of %d pixels (max margin %.2e)" % (diff.sum(), diff.size, margin.max()))
+
+
 def test_cfg1_inference_matches_golden_and_oracle():
     """BASELINE.json configs[0]: mobilenetv2 128x128, 2 classes, single-image forward."""
     from tests.golden.make_golden import cfg1_case
@@ -141,6 +154,16 @@ def test_xception_train_step_gradients(OS):
     x = rng.integers(0, 256, (B,) + shape).astype(np.float32)
     params = O.calibrate_bn(params, x, **kw)
     _load(model, params)
+    # inference path first (the training step below updates the moving statistics): logits 1e-3, argmax exact
+    model.predict(x, batch_size=B)
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    ref, _ = O.forward(p64, x.astype(np.float64), **kw)
+    ref32, _ = O.forward(params, x, **kw)
+    # at OS=16 the deepest maps of a 64x64 input are 4x4 (32 samples per BN channel): ill-conditioned in fp32 —
+    # the fp32 ORACLE's own distance to float64 is the yardstick there
+    tol = max(1e-3, 2.0 * relerr(ref32, ref))
+    assert relerr(model._active.logits(), ref) < tol, (relerr(model._active.logits(), ref), tol)
+    _assert_argmax_parity(model._active.argmax(), ref)
     labels = rng.integers(0, classes + 1, (B, shape[0] * shape[1])).astype(np.float32)
     sw = (labels < classes).astype(np.float32)
     eng = model._engine(B, True, dropout=False, use_graph=False)
@@ -148,7 +171,6 @@ def test_xception_train_step_gradients(OS):
     eng.set_targets(labels, sw)
     eng.fwd_bwd()
     torch.cuda.synchronize()
-    p64 = {k: v.astype(np.float64) for k, v in params.items()}
     loss, grads, logits, net = O.train_grads(p64, x.astype(np.float64), labels.astype(np.float64),
                                               sw.astype(np.float64), **kw)
     assert relerr(eng.logits(), logits) < 1e-3
@@ -163,11 +185,6 @@ def test_xception_train_step_gradients(OS):
         num += float(np.sum((eng.grad_of(name).astype(np.float64) - g) ** 2))
         den += float(np.sum(g ** 2))
     assert np.sqrt(num / den) < 5e-2, np.sqrt(num / den)
-    # inference path: logits 1e-3, argmax bit-exact
-    probs = model.predict(x, batch_size=B)
-    ref, _ = O.forward(params, x, **kw)
-    assert relerr(model._active.logits(), ref) < 1e-3
-    assert (model._active.argmax() != ref.argmax(-1)).mean() < 1e-3
 
 
 def test_graph_replay_and_determinism():
