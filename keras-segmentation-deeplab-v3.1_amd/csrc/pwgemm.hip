@@ -14,6 +14,8 @@
 // B[k=l>>5][j=l&31]; C/D reg r of lane l is row (r&3)+8*(r>>2)+4*(l>>5), column l&31.
 // LDS tiles are k-major (As[k][m], Bs[k][n]) so fragment reads are 32 consecutive floats per
 // half-wave: conflict-free ds_read_b32.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -505,13 +507,22 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
 struct GemmCfg { int id, BM, BN; };
 const GemmCfg kGemmCfgs[] = {{0, 128, 128}, {1, 256, 64}, {2, 256, 32}, {3, 128, 160}, {4, 128, 96}};
 
+int env_int(const char *name) {
+  const char *e = getenv(name);
+  return e ? atoi(e) : -1;
+}
+
 GemmCfg pick_gemm(int M, int K, int N, bool two) {
+  const int forced = env_int("DL3_GEMM_CFG");  // tuning aid (tools/gemm_tune.py)
+  if (forced >= 0 && forced < 5) return kGemmCfgs[forced];
   double best = 1e30;
   GemmCfg bc = kGemmCfgs[0];
   for (const GemmCfg &c : kGemmCfgs) {
+    // measured on MI355X (tools/gemm_tune.py): ~80 TFLOP/s sustained fp32 MFMA, ~3 TB/s streaming; re-reads of A by
+    // the other column tiles of a row tile are L2 hits thanks to the XCD remap (charged at 1/4)
     const double ntn = dl3_cdiv(N, c.BN), mp = (double)dl3_cdiv(M, c.BM) * c.BM;
-    const double t_mfma = 2.0 * mp * K * ntn * c.BN / 100e12;
-    const double t_mem = 4.0 * ((double)M * K * ntn * (two ? 2 : 1) + (double)M * N) / 3e12;
+    const double t_mfma = 2.0 * mp * K * ntn * c.BN / 80e12;
+    const double t_mem = 4.0 * ((double)M * K * (1.0 + 0.25 * (ntn - 1)) * (two ? 2 : 1) + (double)M * N) / 3e12;
     const double cost = (t_mfma > t_mem ? t_mfma : t_mem) + 0.25 * (t_mfma + t_mem);
     if (cost < best) { best = cost; bc = c; }
   }
@@ -560,12 +571,15 @@ const WgCfg kWgCfgs[] = {{0, 64, 64},  {1, 128, 128}, {2, 160, 128}, {3, 128, 16
                          {5, 128, 64}, {6, 32, 128},  {7, 128, 32},  {8, 96, 128},  {9, 128, 96}};
 
 WgCfg pick_wgrad(int M, int K, int N, bool two) {
+  const int forced = env_int("DL3_WGRAD_CFG");
+  if (forced >= 0 && forced < 10) return kWgCfgs[forced];
   double best = 1e30;
   WgCfg bc = kWgCfgs[0];
   for (const WgCfg &c : kWgCfgs) {
     const double ntk = dl3_cdiv(K, c.BKT), ntn = dl3_cdiv(N, c.BNT);
-    const double t_mfma = 2.0 * M * ntk * c.BKT * ntn * c.BNT / 100e12;
-    const double t_mem = 4.0 * ((double)M * K * ntn + (double)M * N * ntk * (two ? 2 : 1)) / 3e12;
+    const double t_mfma = 2.0 * M * ntk * c.BKT * ntn * c.BNT / 80e12;
+    const double t_mem = 4.0 * ((double)M * K * (1.0 + 0.25 * (ntn - 1)) +
+                                (double)M * N * (1.0 + 0.25 * (ntk - 1)) * (two ? 2 : 1)) / 3e12;
     const double cost = (t_mfma > t_mem ? t_mfma : t_mem) + 0.25 * (t_mfma + t_mem);
     if (cost < best) { best = cost; bc = c; }
   }
