@@ -164,7 +164,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local % torch.cuda.device_count())
     dp = DataParallel(backend="nccl")
     assert dp.world == args.gpus or (args.gpus == 1 and dp.world == 1), "launch with torch.distributed.run for --gpus > 1"
 

@@ -175,6 +175,12 @@ int dl3_argmax(const float *x, int *out, int M, int C, void *stream);
 int dl3_count_nonzero(const float *w, int M, float *out, void *stream);
 int dl3_softmax_xent(const float *logits, const float *labels, const float *weights, const float *nnz,
                      float *probs, float *dlogits, float *loss_partial, int M, int C, void *stream);
+/* the same loss with the final resize_bilinear (deeplabv3p.py:439, utils.py:190) fused in: logits_lo is the
+ * [N,Hi,Wi,C] output of the logits conv, labels / weights / dlogits live at [N,Ho,Wo]; the full-resolution logits
+ * are interpolated in registers and never touch HBM.  C <= 32. */
+int dl3_upsample_softmax_xent(const float *logits_lo, const float *labels, const float *weights, const float *nnz,
+                              float *probs, float *dlogits, float *loss_partial, int N, int Hi, int Wi, int Ho, int Wo,
+                              int C, void *stream);
 /* out[i] = sum_p partial[p][i]  (fixed order) */
 int dl3_reduce_partials(const float *partial, int P, int n, float *out, void *stream);
 int dl3_fill(float *p, float value, size_t n, void *stream);

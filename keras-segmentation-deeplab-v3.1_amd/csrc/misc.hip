@@ -27,25 +27,24 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(const float *__restrict
                                                          const float *__restrict__ sh, int act,
                                                          float *__restrict__ y, int ldy, int N, int Hi, int Wi,
                                                          int Ho, int Wo, int C, float sy, float sx) {
-  const long total = (long)N * Ho * Wo * C;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int c = (int)(i % C);
-    long p = i / C;
-    const int ox = (int)(p % Wo);
-    p /= Wo;
-    const int oy = (int)(p % Ho);
-    const int n = (int)(p / Ho);
-    const Lerp ly = tf1_lerp(oy, sy, Hi), lx = tf1_lerp(ox, sx, Wi);
+  // grid.y = output row (n, oy); threads cover (ox, c) of that row: no 64-bit divisions per element
+  const int n = blockIdx.y / Ho, oy = blockIdx.y - n * Ho;
+  const Lerp ly = tf1_lerp(oy, sy, Hi);
+  const float *b = x + (size_t)n * Hi * Wi * ldx;
+  const float *r0 = b + (size_t)ly.lo * Wi * ldx, *r1 = b + (size_t)ly.hi * Wi * ldx;
+  float *yo = y + (size_t)blockIdx.y * Wo * ldy;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < Wo * C; i += gridDim.x * 256) {
+    const int ox = i / C, c = i - ox * C;
+    const Lerp lx = tf1_lerp(ox, sx, Wi);
     float es = 1.f, et = 0.f;
     if (sc) { es = sc[c]; et = sh[c]; }
-    const float *b = x + (size_t)n * Hi * Wi * ldx + c;
-    const float tl = dl3_act(es * b[((size_t)ly.lo * Wi + lx.lo) * ldx] + et, act);
-    const float tr = dl3_act(es * b[((size_t)ly.lo * Wi + lx.hi) * ldx] + et, act);
-    const float bl = dl3_act(es * b[((size_t)ly.hi * Wi + lx.lo) * ldx] + et, act);
-    const float br = dl3_act(es * b[((size_t)ly.hi * Wi + lx.hi) * ldx] + et, act);
+    const float tl = dl3_act(es * r0[(size_t)lx.lo * ldx + c] + et, act);
+    const float tr = dl3_act(es * r0[(size_t)lx.hi * ldx + c] + et, act);
+    const float bl = dl3_act(es * r1[(size_t)lx.lo * ldx + c] + et, act);
+    const float br = dl3_act(es * r1[(size_t)lx.hi * ldx + c] + et, act);
     const float top = tl + (tr - tl) * lx.w;
     const float bot = bl + (br - bl) * lx.w;
-    y[(((size_t)n * Ho + oy) * Wo + ox) * ldy + c] = top + (bot - top) * ly.w;
+    yo[(size_t)ox * ldy + c] = top + (bot - top) * ly.w;
   }
 }
 
@@ -54,33 +53,33 @@ __global__ __launch_bounds__(256) void resize_fwd_kernel(const float *__restrict
 __global__ __launch_bounds__(256) void resize_bwd_kernel(const float *__restrict__ dy, int lddy,
                                                          float *__restrict__ dx, int lddx, int N, int Hi, int Wi,
                                                          int Ho, int Wo, int C, float sy, float sx, int accumulate) {
-  const long total = (long)N * Hi * Wi * C;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int c = (int)(i % C);
-    long p = i / C;
-    const int ix = (int)(p % Wi);
-    p /= Wi;
-    const int iy = (int)(p % Hi);
-    const int n = (int)(p / Hi);
-    // candidate output rows: those with floor(oy*sy) in {iy-1, iy} (+1 slack each side for rounding)
-    int oy0 = (int)floorf((float)(iy - 1) / sy) - 1, oy1 = (int)ceilf((float)(iy + 1) / sy) + 1;
+  // grid.y = input row (n, iy); threads cover (ix, c)
+  const int n = blockIdx.y / Hi, iy = blockIdx.y - n * Hi;
+  // candidate output rows: those with floor(oy*sy) in {iy-1, iy} (+1 slack each side for rounding)
+  int oy0 = (int)floorf((float)(iy - 1) / sy) - 1, oy1 = (int)ceilf((float)(iy + 1) / sy) + 1;
+  oy0 = max(oy0, 0);
+  oy1 = min(oy1, Ho - 1);
+  const float *dyn = dy + (size_t)n * Ho * Wo * lddy;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < Wi * C; i += gridDim.x * 256) {
+    const int ix = i / C, c = i - ix * C;
     int ox0 = (int)floorf((float)(ix - 1) / sx) - 1, ox1 = (int)ceilf((float)(ix + 1) / sx) + 1;
-    oy0 = max(oy0, 0); oy1 = min(oy1, Ho - 1);
-    ox0 = max(ox0, 0); ox1 = min(ox1, Wo - 1);
+    ox0 = max(ox0, 0);
+    ox1 = min(ox1, Wo - 1);
     float acc = 0.f;
     for (int oy = oy0; oy <= oy1; ++oy) {
       const Lerp ly = tf1_lerp(oy, sy, Hi);
       const float wy = (ly.lo == iy ? 1.f - ly.w : 0.f) + (ly.hi == iy ? ly.w : 0.f);
       if (wy == 0.f) continue;
       float racc = 0.f;
+      const float *row = dyn + (size_t)oy * Wo * lddy + c;
       for (int ox = ox0; ox <= ox1; ++ox) {
         const Lerp lx = tf1_lerp(ox, sx, Wi);
         const float wx = (lx.lo == ix ? 1.f - lx.w : 0.f) + (lx.hi == ix ? lx.w : 0.f);
-        if (wx != 0.f) racc += wx * dy[(((size_t)n * Ho + oy) * Wo + ox) * lddy + c];
+        racc += wx * row[(size_t)ox * lddy];
       }
       acc += wy * racc;
     }
-    float *o = dx + (((size_t)n * Hi + iy) * Wi + ix) * lddx + c;
+    float *o = dx + ((size_t)blockIdx.y * Wi + ix) * lddx + c;
     *o = accumulate ? (*o + acc) : acc;
   }
 }
@@ -186,6 +185,100 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float *__restri
   if (threadIdx.x == 0) loss_part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
+// Loss tail, one pass over HBM.  Thread = pixel, logits held in registers (C <= 32); dlogits (and probs) leave
+// through an LDS transpose so that the 256 x C floats of a workgroup are stored as contiguous float4s.
+// UPSAMPLE: the logits are bilinearly interpolated on the fly from the low-resolution map (the resize_bilinear of
+// deeplabv3p.py:439 / utils.py:190 fused in), so the full-resolution logits are never written or re-read.
+template <bool UPSAMPLE>
+__global__ __launch_bounds__(256) void xent32_kernel(const float *__restrict__ x, const float *__restrict__ labels,
+                                                     const float *__restrict__ weights,
+                                                     const float *__restrict__ nnz, float *__restrict__ probs,
+                                                     float *__restrict__ dl, float *__restrict__ loss_part, long M,
+                                                     int C, int Hi, int Wi, int Ho, int Wo, float sy, float sx) {
+  constexpr int MAXC = 32;
+  __shared__ float tile[256 * MAXC];
+  __shared__ float red[4];
+  const float inv_nnz = 1.f / fmaxf(*nnz, 1.f);
+  float lsum = 0.f;
+  for (long base = (long)blockIdx.x * 256; base < M; base += (long)gridDim.x * 256) {
+    const long m = base + threadIdx.x;
+    const bool ok = m < M;
+    const long mc = ok ? m : M - 1;
+    float z[MAXC];
+    if (UPSAMPLE) {
+      const int ox = (int)(mc % Wo);
+      const long q = mc / Wo;
+      const int oy = (int)(q % Ho), n = (int)(q / Ho);
+      const Lerp ly = tf1_lerp(oy, sy, Hi), lx = tf1_lerp(ox, sx, Wi);
+      const float *b = x + (size_t)n * Hi * Wi * C;
+      const float *tl = b + ((size_t)ly.lo * Wi + lx.lo) * C, *tr = b + ((size_t)ly.lo * Wi + lx.hi) * C;
+      const float *bl = b + ((size_t)ly.hi * Wi + lx.lo) * C, *br = b + ((size_t)ly.hi * Wi + lx.hi) * C;
+#pragma unroll
+      for (int c = 0; c < MAXC; c++) {
+        const int cc = min(c, C - 1);
+        const float top = tl[cc] + (tr[cc] - tl[cc]) * lx.w;
+        const float bot = bl[cc] + (br[cc] - bl[cc]) * lx.w;
+        z[c] = top + (bot - top) * ly.w;
+      }
+    } else {
+      // coalesced copy of the workgroup's 256 x C logits through LDS, then one row per thread (stride C is odd for
+      // C = 21: conflict-free)
+      const long nrem = min((long)256, M - base) * C;
+      for (long i = threadIdx.x; i < nrem; i += 256) tile[i] = x[(size_t)base * C + i];
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < MAXC; c++) z[c] = tile[(ok ? threadIdx.x : 0) * C + min(c, C - 1)];
+      __syncthreads();
+    }
+    float mx = z[0];
+#pragma unroll
+    for (int c = 1; c < MAXC; c++) mx = fmaxf(mx, (c < C) ? z[c] : z[0]);
+    float ssum = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+      z[c] = (c < C) ? expf(z[c] - mx) : 0.f;
+      ssum += z[c];
+    }
+    const float inv = 1.f / ssum;
+    const int t = (int)labels[mc];
+    const float w = weights ? weights[mc] : 1.f;
+    float psum = 0.f, pt = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+      z[c] *= inv;  // probability
+      psum += z[c];
+      pt = (c == t) ? z[c] : pt;
+    }
+    if (ok && t >= 0 && t < C) {
+      float q = pt / psum;
+      q = fminf(fmaxf(q, 1e-7f), 1.f - 1e-7f);
+      lsum += -logf(q) * w * inv_nnz;
+    }
+    const long nrem = min((long)256, M - base) * C;
+    if (probs) {
+#pragma unroll
+      for (int c = 0; c < MAXC; c++)
+        if (c < C) tile[threadIdx.x * C + c] = z[c];
+      __syncthreads();
+      for (long i = threadIdx.x; i < nrem; i += 256) probs[(size_t)base * C + i] = tile[i];
+      __syncthreads();
+    }
+    if (dl) {
+      const float gs = w * inv_nnz;
+#pragma unroll
+      for (int c = 0; c < MAXC; c++)
+        if (c < C) tile[threadIdx.x * C + c] = (z[c] - (c == t ? 1.f : 0.f)) * gs;
+      __syncthreads();
+      for (long i = threadIdx.x; i < nrem; i += 256) dl[(size_t)base * C + i] = tile[i];
+      __syncthreads();
+    }
+  }
+  lsum = wave_sum(lsum);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) loss_part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
 inline int ew_blocks(size_t n) {
   size_t b = (n + 255) / 256;
   if (b > 8192) b = 8192;
@@ -202,8 +295,11 @@ extern "C" int dl3_resize_bilinear_fwd(const float *x, int ldx, const float *in_
   DL3_CHECK_ARG(ldx >= C && ldy >= C, "resize_fwd: leading dimension too small");
   DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "resize_fwd: scale/shift must come together");
   const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
-  hipLaunchKernelGGL(resize_fwd_kernel, dim3(ew_blocks((size_t)N * Ho * Wo * C)), dim3(256), 0,
-                     (hipStream_t)stream, x, ldx, in_scale, in_shift, in_act, y, ldy, N, Hi, Wi, Ho, Wo, C, sy, sx);
+  DL3_UNSUPPORTED((long)N * Ho > 2147483647L, "resize_fwd: too many rows");
+  int gx = dl3_cdiv(Wo * C, 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(resize_fwd_kernel, dim3(gx, N * Ho), dim3(256), 0, (hipStream_t)stream, x, ldx, in_scale,
+                     in_shift, in_act, y, ldy, N, Hi, Wi, Ho, Wo, C, sy, sx);
   DL3_LAUNCH_CHECK("resize_fwd");
   return DL3_OK;
 }
@@ -213,8 +309,10 @@ extern "C" int dl3_resize_bilinear_bwd(const float *dy, int lddy, float *dx, int
   DL3_CHECK_ARG(dy && dx && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "resize_bwd: bad argument");
   DL3_CHECK_ARG(lddy >= C && lddx >= C, "resize_bwd: leading dimension too small");
   const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
-  hipLaunchKernelGGL(resize_bwd_kernel, dim3(ew_blocks((size_t)N * Hi * Wi * C)), dim3(256), 0,
-                     (hipStream_t)stream, dy, lddy, dx, lddx, N, Hi, Wi, Ho, Wo, C, sy, sx, accumulate);
+  int gx = dl3_cdiv(Wi * C, 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(resize_bwd_kernel, dim3(gx, N * Hi), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx, lddx, N,
+                     Hi, Wi, Ho, Wo, C, sy, sx, accumulate);
   DL3_LAUNCH_CHECK("resize_bwd");
   return DL3_OK;
 }
@@ -259,8 +357,26 @@ extern "C" int dl3_count_nonzero(const float *w, int M, float *out, void *stream
 extern "C" int dl3_softmax_xent(const float *logits, const float *labels, const float *weights, const float *nnz,
                                 float *probs, float *dlogits, float *loss_partial, int M, int C, void *stream) {
   DL3_CHECK_ARG(logits && labels && nnz && loss_partial && M > 0 && C > 0, "softmax_xent: bad argument");
-  hipLaunchKernelGGL(softmax_xent_kernel, dim3(dl3_rows_partials(M)), dim3(256), 0, (hipStream_t)stream, logits,
-                     labels, weights, nnz, probs, dlogits, loss_partial, (long)M, C);
+  if (C <= 32)
+    hipLaunchKernelGGL((xent32_kernel<false>), dim3(dl3_rows_partials(M)), dim3(256), 0, (hipStream_t)stream, logits,
+                       labels, weights, nnz, probs, dlogits, loss_partial, (long)M, C, 0, 0, 0, 0, 0.f, 0.f);
+  else
+    hipLaunchKernelGGL(softmax_xent_kernel, dim3(dl3_rows_partials(M)), dim3(256), 0, (hipStream_t)stream, logits,
+                       labels, weights, nnz, probs, dlogits, loss_partial, (long)M, C);
   DL3_LAUNCH_CHECK("softmax_xent");
+  return DL3_OK;
+}
+
+extern "C" int dl3_upsample_softmax_xent(const float *logits_lo, const float *labels, const float *weights,
+                                         const float *nnz, float *probs, float *dlogits, float *loss_partial, int N,
+                                         int Hi, int Wi, int Ho, int Wo, int C, void *stream) {
+  DL3_CHECK_ARG(logits_lo && labels && nnz && loss_partial && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0,
+                "upsample_softmax_xent: bad argument");
+  DL3_UNSUPPORTED(C > 32, "upsample_softmax_xent: C=%d > 32 (use resize_bilinear_fwd + softmax_xent)", C);
+  const long M = (long)N * Ho * Wo;
+  const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+  hipLaunchKernelGGL((xent32_kernel<true>), dim3(dl3_rows_partials((int)M)), dim3(256), 0, (hipStream_t)stream,
+                     logits_lo, labels, weights, nnz, probs, dlogits, loss_partial, M, C, Hi, Wi, Ho, Wo, sy, sx);
+  DL3_LAUNCH_CHECK("upsample_softmax_xent");
   return DL3_OK;
 }

@@ -479,6 +479,15 @@ class Engine:
         if v.aff or v.act != ACT_NONE or v.off != 0 or v.ld != C:
             raise NotImplementedError("softmax expects materialised logits")
         self.logits_view = v
+        # training: fuse the final bilinear resize into the loss kernel (the full-resolution logits are interpolated in
+        # registers, never written): drop the resize launch from the forward plan, keep it for logits() on demand
+        self.fused_tail = None
+        last = self.units[-1] if self.units else None
+        if (self.training and isinstance(last, ResizeUnit) and last.outv.buf is v.buf and C <= 32
+                and not last.inv.aff and last.inv.act == ACT_NONE and last.inv.off == 0 and last.inv.ld == C):
+            self.fused_tail = last
+            self._resize_op = self.ops_fwd.pop()
+            assert self._resize_op[0] == "dl3_resize_bilinear_fwd"
         M = v.buf.M
         self.probs = self.empty(M * C)
         self.out_shape = (self.B,) + tuple(l.output.shape)
@@ -500,8 +509,13 @@ class Engine:
         # loss + dlogits (first and only contribution to the logits buffer)
         buf.grad = self.empty(M * buf.ld)
         self.op(self.ops_fwd, "dl3_count_nonzero", ptr(self.sweights), M, ptr(self.nnz))
-        self.op(self.ops_fwd, "dl3_softmax_xent", ptr(buf.t), ptr(self.labels), ptr(self.sweights), ptr(self.nnz),
-                None, ptr(buf.grad), ptr(self.loss_part), M, C)
+        if self.fused_tail is not None:
+            lo = self.fused_tail.inv
+            self.op(self.ops_fwd, "dl3_upsample_softmax_xent", lo.p(), ptr(self.labels), ptr(self.sweights),
+                    ptr(self.nnz), None, ptr(buf.grad), ptr(self.loss_part), self.B, lo.buf.H, lo.buf.W, buf.H, buf.W, C)
+        else:
+            self.op(self.ops_fwd, "dl3_softmax_xent", ptr(buf.t), ptr(self.labels), ptr(self.sweights), ptr(self.nnz),
+                    None, ptr(buf.grad), ptr(self.loss_part), M, C)
         self.op(self.ops_fwd, "dl3_reduce_partials", ptr(self.loss_part), self.lossP, 1, ptr(self.loss))
         buf.done = 1
         assert buf.expected == 1
@@ -609,6 +623,8 @@ class Engine:
 
     def logits(self):
         v = self.logits_view
+        if getattr(self, "fused_tail", None) is not None:
+            self.run_ops([self._resize_op])  # the fused training tail never materialises them
         return v.buf.t.cpu().numpy().reshape(self.B, v.buf.H, v.buf.W, v.C)
 
     def argmax(self):

@@ -19,6 +19,7 @@ class DataParallel:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.device = device
+        backend = os.environ.get("DL3_DIST_BACKEND", backend)  # e.g. gloo to exercise the N>1 logic on one GPU
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         self.backend = backend
@@ -26,7 +27,7 @@ class DataParallel:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             if backend == "nccl":
-                torch.cuda.set_device(self.local_rank)
+                torch.cuda.set_device(self.local_rank % max(torch.cuda.device_count(), 1))
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
 
     def shard(self, n_global):

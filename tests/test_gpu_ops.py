@@ -500,6 +500,27 @@ def test_softmax_argmax_xent(L):
     assert relerr(host(probs), p_ref[0]) < 1e-5
 
 
+def test_fused_upsample_xent(L):
+    """dl3_upsample_softmax_xent == resize_bilinear_fwd followed by softmax_xent"""
+    rng = np.random.default_rng(16)
+    N, Hi, Wi, Ho, Wo, C = 2, 8, 8, 64, 64, 21
+    lo = rng.normal(0, 2, (N, Hi, Wi, C)).astype(np.float32)
+    M = N * Ho * Wo
+    labels = rng.integers(0, C + 1, M).astype(np.float32)
+    w = ((labels < C) * rng.uniform(0.5, 2, M)).astype(np.float32)
+    up = O.resize_bilinear_tf1(lo.astype(np.float64), Ho, Wo).reshape(1, M, C)
+    loss_ref, dl_ref, p_ref = O.loss_sparse_xent_ignoring_last_label(up, labels[None], w.astype(np.float64)[None])
+    nnz = empty(1)
+    call("dl3_count_nonzero", ptr(dev(w)), M, ptr(nnz))
+    P = L.dl3_rows_partials(M)
+    dl, lp, probs = empty(M, C), empty(P), empty(M, C)
+    call("dl3_upsample_softmax_xent", ptr(dev(lo)), ptr(dev(labels)), ptr(dev(w)), ptr(nnz), ptr(probs), ptr(dl), ptr(lp),
+         N, Hi, Wi, Ho, Wo, C)
+    assert relerr(host(dl), dl_ref[0]) < 1e-4
+    assert relerr(host(probs), p_ref[0]) < 1e-4
+    assert abs(host(lp).astype(np.float64).sum() - loss_ref) < 1e-5 * abs(loss_ref)
+
+
 def test_adam_fill(L):
     rng = np.random.default_rng(14)
     n = 10001
