@@ -212,9 +212,17 @@ def main():
             r = roofline_leg(args.batch)
             log("roofline leg done: " + ", ".join("%s %.3f ms" % (k, v["ms"]) for k, v in r.items()))
             k = r["dw_r4_fwd"]
+            # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected separately
+            # with tools/dw_only.py and corrected as MI355X_MICROARCH.md prescribes): committed under profiles/
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r01_dw_r4_b16_pmc.json")
+            if os.path.exists(pmc):
+                pj = json.load(open(pmc))
+                if pj.get("batch") == args.batch:
+                    traffic = pj["dw_march_fwd"]["traffic_bytes"]
             rec["roofline"] = {"bound": "hbm", "kernel": "dw_march_fwd (DepthwiseConv2D 3x3 rate 4, %dx64x64x960)" % args.batch,
                                "achieved": k["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["gbs"] / HBM_PEAK_GBS,
-                               "traffic": None, "avg_ms": k["ms"], "algorithmic_bytes": k["bytes"]}
+                               "traffic": traffic, "avg_ms": k["ms"], "algorithmic_bytes": k["bytes"]}
             rec["kernels"] = r
         if dp.world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline_leg(args)
