@@ -71,6 +71,9 @@ __device__ __forceinline__ f32x4 dl3_mask4(f32x4 z, int act) {
 }
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+// streaming store (global_store_dwordx4 ... nt): activations written once and next read by a LATER kernel should not
+// evict the lines the current kernel still re-reads from L2
+__device__ __forceinline__ void st4_nt(float *p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p)); }
 __device__ __forceinline__ f32x4 splat4(float v) {
   f32x4 r = {v, v, v, v};
   return r;

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x,
       f32x4 h2 = wv[6] * l[j] + wv[7] * m[j] + wv[8] * rr[j];
       f32x4 out = accA + h2;
       if (active && k - 1 >= k0 && k - 1 < k1) {
-        st4(ybase + ((size_t)(a + (k - 1) * r) * W + xx) * C, out);
+        st4_nt(ybase + ((size_t)(a + (k - 1) * r) * W + xx) * C, out);
         s1 += out;
         s2 += out * out;
       }
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
           const size_t off = img + ((size_t)(a + (k - 1) * r) * W + xx) * C;
           out = out * dl3_mask4(s * e_prev + t, act);
           if (dx_add) out += ld4(dx_add + off);
-          st4(dx + off, out);
+          st4_nt(dx + off, out);
           s1 += out;
           s2 += out * ((e_prev - mu) * is);
         }
@@ -299,19 +299,23 @@ __global__ __launch_bounds__(256) void dw_gather_fwd(const float *__restrict__ x
     const int oy = (int)((p / G.Wo) % G.Ho);
     const int n = (int)(p / ((long)G.Wo * G.Ho));
     f32x4 acc = splat4(0.f);
+    f32x4 tap[9];
+    float okf[9];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
       const int iy = oy * G.stride - G.pad_t + i * G.rate;
-      if (iy < 0 || iy >= G.H) continue;
+      const int iyc = min(max(iy, 0), G.H - 1);
 #pragma unroll
       for (int j = 0; j < 3; j++) {
         const int ix = ox * G.stride - G.pad_l + j * G.rate;
-        if (ix < 0 || ix >= G.W) continue;
-        f32x4 v = ld4(x + (((size_t)n * G.H + iy) * G.W + ix) * G.C + c);
-        acc += wv[i * 3 + j] * dl3_act4(s * v + t, act);
+        const int ixc = min(max(ix, 0), G.W - 1);
+        okf[i * 3 + j] = (iy == iyc && ix == ixc) ? 1.f : 0.f;
+        tap[i * 3 + j] = ld4(x + (((size_t)n * G.H + iyc) * G.W + ixc) * G.C + c);  // clamped: always in bounds
       }
     }
-    st4(y + (size_t)p * G.C + c, acc);
+#pragma unroll
+    for (int q = 0; q < 9; q++) acc += (wv[q] * splat4(okf[q])) * dl3_act4(s * tap[q] + t, act);
+    st4_nt(y + (size_t)p * G.C + c, acc);
     s1 += acc;
     s2 += acc * acc;
   }
@@ -362,29 +366,37 @@ __global__ __launch_bounds__(256) void dw_gather_bwd(
     const f32x4 z = s * eraw + t;
     const f32x4 ea = dl3_act4(z, act);
     f32x4 acc = splat4(0.f);
+    const float *yr = two ? yraw : g;
+    f32x4 tg[9], ty_[9];
+    float okf[9];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
       const int ty = iy + G.pad_t - i * G.rate;
-      if (ty < 0 || (ty % G.stride) != 0) continue;
-      const int oy = ty / G.stride;
-      if (oy >= G.Ho) continue;
+      const int oy = max(ty, 0) / G.stride;
+      const bool yok = ty >= 0 && (ty % G.stride) == 0 && oy < G.Ho;
+      const int oyc = min(oy, G.Ho - 1);
 #pragma unroll
       for (int j = 0; j < 3; j++) {
         const int tx = ix + G.pad_l - j * G.rate;
-        if (tx < 0 || (tx % G.stride) != 0) continue;
-        const int ox = tx / G.stride;
-        if (ox >= G.Wo) continue;
-        const size_t off = (((size_t)n * G.Ho + oy) * G.Wo + ox) * G.C + c;
-        f32x4 dd = ld4(g + off);
-        if (two) dd = kA * dd + kB * ld4(yraw + off) + kC;
-        acc += dd * wv[i * 3 + j];
-        dwv[i * 3 + j] += ea * dd;
+        const int ox = max(tx, 0) / G.stride;
+        const bool xok = tx >= 0 && (tx % G.stride) == 0 && ox < G.Wo;
+        const int oxc = min(ox, G.Wo - 1);
+        const size_t off = (((size_t)n * G.Ho + oyc) * G.Wo + oxc) * G.C + c;  // clamped: always in bounds
+        okf[i * 3 + j] = (yok && xok) ? 1.f : 0.f;
+        tg[i * 3 + j] = ld4(g + off);
+        ty_[i * 3 + j] = ld4(yr + off);
       }
+    }
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+      const f32x4 dd = (kA * tg[q] + kB * ty_[q] + kC) * splat4(okf[q]);
+      acc += dd * wv[q];
+      dwv[q] += ea * dd;
     }
     if (dx) {
       f32x4 out = acc * dl3_mask4(z, act);
       if (dx_add) out += ld4(dx_add + (size_t)p * G.C + c);
-      st4(dx + (size_t)p * G.C + c, out);
+      st4_nt(dx + (size_t)p * G.C + c, out);
       s1 += out;
       s2 += out * ((eraw - mu) * is);
     }

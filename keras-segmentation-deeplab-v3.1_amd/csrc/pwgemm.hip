@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmArgs P) {
           if (P.ep_x) v *= dl3_act_mask(es * xr[r] + et, P.ep_act);
           v += ad[r];
           if (ok) {
-            P.c[(size_t)row * P.ldc + col] = v;
+            __builtin_nontemporal_store(v, &P.c[(size_t)row * P.ldc + col]);
             st1[j] += v;
             st2[j] += (P.stat_mode == 2) ? v * ((xr[r] - mu) * is) : v * v;
           }
