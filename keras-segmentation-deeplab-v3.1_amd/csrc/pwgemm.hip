@@ -289,6 +289,230 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmArgs P) {
 }
 
 // ---------------------------------------------------------------------------------------
+// "stream-A" GEMM (the default for 16-byte-aligned operands).
+//
+// The MFMA A operand of v_mfma_f32_32x32x2_f32 is ONE float per lane: lane (r = l&31, h = l>>5) supplies
+// A[row r][k of this step].  A sum over k may pair the k indices in any order, so within a 32-deep K-tile we
+// let the h = 0 lanes walk k = 0..15 and the h = 1 lanes k = 16..31: every lane then needs 16 CONSECUTIVE
+// floats of its own row — four 16-byte global loads, 128 contiguous bytes per row pair — and the activation
+// tile goes HBM -> registers -> MFMA with no LDS round trip, no transposing ds_write, and no barrier on the A
+// side.  Each wave streams its own 32*TM rows; only the small weight tile B (32 x BN) is shared through LDS.
+// BatchNorm+ReLU6 (forward) or the BatchNorm-backward affine of two tensors (bwd-data) is applied to the
+// registers between load and use, one K-tile ahead of the MFMAs.
+// ---------------------------------------------------------------------------------------
+template <int TM, int TN, bool TWO>
+__global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
+  constexpr int BM = 128 * TM, BN = 32 * TN, KT = 32;
+  constexpr int LDB = BN;
+  constexpr int NB = (KT * BN / 4 + 255) / 256;  // float4 B loads per thread per K-tile
+  __shared__ float lds[2 * KT * LDB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int nwg = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = b & 7;
+  const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (b >> 3);
+  const int bx = lid % gridDim.x, by = lid / gridDim.x;
+  const int n0 = bx * BN;
+  const int ktiles = (P.K + KT - 1) / KT;
+  const bool xform = (P.ka != nullptr);
+  constexpr int WM = 4;
+  const int wm = wave;
+
+  float st1[TN], st2[TN];
+#pragma unroll
+  for (int i = 0; i < TN; i++) st1[i] = st2[i] = 0.f;
+
+  for (int mt = by; mt < P.mtiles; mt += gridDim.y) {
+    const int m0 = mt * BM;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const float *arow[TM], *arow2[TM];
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+      const int row = min(m0 + (wm * TM + i) * 32 + l31, P.M - 1);
+      arow[i] = P.a + (size_t)row * P.lda;
+      arow2[i] = TWO ? P.a2 + (size_t)row * P.lda2 : nullptr;
+    }
+    f32x4 an[TM][4], an2[TM][4], ac[TM][4], rb[NB];
+
+    auto load_A = [&](int kt) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int kc = min(kt * KT + 16 * lhi + 4 * j, P.K - 4);
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+          an[i][j] = ld4(arow[i] + kc);
+          if (TWO) an2[i][j] = ld4(arow2[i] + kc);
+        }
+      }
+    };
+    auto load_B = [&](int kt) {
+#pragma unroll
+      for (int i = 0; i < NB; i++) {
+        const int idx = tid + 256 * i;
+        if (NB * 256 == KT * BN / 4 || idx < KT * BN / 4) {
+          const int kk = idx / (BN / 4), nq = idx % (BN / 4);
+          const int krow = min(kt * KT + kk, P.K - 1), col = min(n0 + nq * 4, P.N - 4);
+          rb[i] = ld4(P.b + (size_t)krow * P.ldb + col);
+        }
+      }
+    };
+    auto store_B = [&](float *Bs) {
+#pragma unroll
+      for (int i = 0; i < NB; i++) {
+        const int idx = tid + 256 * i;
+        if (NB * 256 == KT * BN / 4 || idx < KT * BN / 4) st4(&Bs[(idx / (BN / 4)) * LDB + (idx % (BN / 4)) * 4], rb[i]);
+      }
+    };
+    // registers of the NEXT K-tile -> transformed operand values of the CURRENT one (zero beyond K)
+    auto transform = [&](int kt) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int k = kt * KT + 16 * lhi + 4 * j;
+        const int kc = min(k, P.K - 4);
+        const float live = (k < P.K) ? 1.f : 0.f;
+        f32x4 fa = splat4(1.f), fb = splat4(0.f), fc = splat4(0.f);
+        if (xform) {
+          fa = ld4(P.ka + kc);
+          fc = ld4(P.kc + kc);
+          if (TWO) fb = ld4(P.kb + kc);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+          f32x4 v = fa * an[i][j] + fc;
+          if (TWO) v += fb * an2[i][j];
+          ac[i][j] = dl3_act4(v, P.a_act) * splat4(live);
+        }
+      }
+    };
+
+    load_A(0);
+    load_B(0);
+    __syncthreads();  // the previous row tile is done with the LDS
+    store_B(lds);
+    transform(0);
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; ++kt) {
+      const float *Bs = lds + (kt & 1) * KT * LDB;
+      const bool more = kt + 1 < ktiles;
+      if (more) {
+        load_A(kt + 1);
+        load_B(kt + 1);
+      }
+      float bf[2][TN];
+#pragma unroll
+      for (int j = 0; j < TN; j++) bf[0][j] = Bs[(16 * lhi) * LDB + j * 32 + l31];
+#pragma unroll
+      for (int s_ = 0; s_ < 16; ++s_) {
+        const int cur = s_ & 1, nxt = cur ^ 1;
+        if (s_ + 1 < 16) {
+#pragma unroll
+          for (int j = 0; j < TN; j++) bf[nxt][j] = Bs[(16 * lhi + s_ + 1) * LDB + j * 32 + l31];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[i][s_ >> 2][s_ & 3], bf[cur][j], acc[i][j], 0, 0, 0);
+      }
+      if (more) {
+        store_B(lds + ((kt + 1) & 1) * KT * LDB);
+        transform(kt + 1);
+      }
+      __syncthreads();
+    }
+
+    // ---------------- epilogue (same C/D layout as the LDS-staged kernel): all global reads of a 32x32 sub-tile are
+    // issued up front (clamped addresses, no branches) so 16-32 loads per lane are in flight
+    const bool full = (m0 + BM <= P.M) && (n0 + BN <= P.N);
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const int col = n0 + j * 32 + l31;
+      const bool cok = col < P.N;
+      const int colc = min(col, P.N - 1);
+      float bias = 0.f, es = 1.f, et = 0.f, mu = 0.f, is = 0.f;
+      if (P.bias) bias = P.bias[colc];
+      if (P.ep_scale) { es = P.ep_scale[colc]; et = P.ep_shift[colc]; }
+      if (P.stat_mode == 2) { mu = P.ep_mean[colc]; is = P.ep_invstd[colc]; }
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+        const int rbase = m0 + (wm * TM + i) * 32 + 4 * lhi;
+        float xr_[16], ad[16];
+        if (P.ep_x) {
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int row = min(rbase + (r & 3) + 8 * (r >> 2), P.M - 1);
+            xr_[r] = P.ep_x[(size_t)row * P.ld_epx + colc];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; r++) xr_[r] = 0.f;
+        }
+        if (P.ep_add) {
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int row = min(rbase + (r & 3) + 8 * (r >> 2), P.M - 1);
+            const int arow_ = (P.add_div > 1) ? row / P.add_div : row;
+            ad[r] = P.add_scale * P.ep_add[(size_t)arow_ * P.ld_add + colc];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; r++) ad[r] = 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          const bool ok = full || (cok && row < P.M);
+          float v = acc[i][j][r] + bias;
+          if (P.ep_x) v *= dl3_act_mask(es * xr_[r] + et, P.ep_act);
+          v += ad[r];
+          if (ok) {
+            __builtin_nontemporal_store(v, &P.c[(size_t)row * P.ldc + col]);
+            st1[j] += v;
+            st2[j] += (P.stat_mode == 2) ? v * ((xr_[r] - mu) * is) : v * v;
+          }
+        }
+      }
+    }
+  }
+
+  if (P.stat_mode != 0) {
+    float *sred = lds;  // [WM][BN][2]
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      float a1 = st1[j] + __shfl_xor(st1[j], 32, 64);
+      float a2 = st2[j] + __shfl_xor(st2[j], 32, 64);
+      if (lhi == 0) {
+        sred[(wm * BN + j * 32 + l31) * 2 + 0] = a1;
+        sred[(wm * BN + j * 32 + l31) * 2 + 1] = a2;
+      }
+    }
+    __syncthreads();
+    for (int cl = tid; cl < BN; cl += 256) {
+      const int col = n0 + cl;
+      if (col < P.N) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; w++) {
+          a1 += sred[(w * BN + cl) * 2 + 0];
+          a2 += sred[(w * BN + cl) * 2 + 1];
+        }
+        P.part[((size_t)by * P.N + col) * 2 + 0] = a1;
+        P.part[((size_t)by * P.N + col) * 2 + 1] = a2;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // weight gradient: dW[K,N] (+)= sum_m T(X)[m][k] * dY[m][n]; grid (ntn, ntk, S)
 // ---------------------------------------------------------------------------------------
 struct WgradArgs {
@@ -556,6 +780,22 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   const bool avec = (A.K % 4 == 0) && (A.lda % 4 == 0) && al16(A.a) && (!two || ((A.lda2 % 4 == 0) && al16(A.a2)));
   const bool bvec = (A.N % 4 == 0) && (A.ldb % 4 == 0) && al16(A.b);
   const bool vec = avec && bvec;
+  // stream-A kernel for single-tensor operands (forward): 10-20 % faster than the LDS-staged kernel on every layer
+  // shape (tools/gemm_tune.py); with the two-tensor BN-backward operand (bwd-data) its register budget spills and
+  // the staged kernel is as fast or faster, so bwd-data stays there.  DL3_GEMM_IMPL=0 forces the staged kernel.
+  if (vec && !two && env_int("DL3_GEMM_IMPL") != 0) {
+    dim3 blk(256);
+#define DL3_STREAM(TM_, TN_) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false>), grid, blk, 0, st, A)
+    switch (c.id) {
+      case 0: DL3_STREAM(1, 4); break;
+      case 1: DL3_STREAM(2, 2); break;
+      case 2: DL3_STREAM(2, 1); break;
+      case 3: DL3_STREAM(1, 5); break;
+      default: DL3_STREAM(1, 3); break;
+    }
+#undef DL3_STREAM
+    return DL3_OK;
+  }
   switch (c.id) {
     case 0: launch_gemm<2, 2, 2, 2>(A, grid, st, vec); break;
     case 1: launch_gemm<2, 2, 4, 1>(A, grid, st, vec); break;
@@ -573,6 +813,11 @@ const WgCfg kWgCfgs[] = {{0, 64, 64},  {1, 128, 128}, {2, 160, 128}, {3, 128, 16
 WgCfg pick_wgrad(int M, int K, int N, bool two) {
   const int forced = env_int("DL3_WGRAD_CFG");
   if (forced >= 0 && forced < 10) return kWgCfgs[forced];
+  // measured shortcuts (tools/gemm_tune.py, MI355X): small weight matrices want the 64x64 tile (more workgroups per
+  // M split), 160-multiples want the 160-wide tiles so the big operand is read once
+  if (K >= 32 && N >= 32 && (long)K * N <= 32768) return kWgCfgs[0];
+  if (N % 160 == 0 && K >= 128 && K % 160 != 0) return kWgCfgs[3];
+  if (K % 160 == 0 && N >= 128 && N % 160 != 0) return kWgCfgs[2];
   double best = 1e30;
   WgCfg bc = kWgCfgs[0];
   for (const WgCfg &c : kWgCfgs) {
