@@ -157,9 +157,12 @@ int dl3_gap_fwd(const float *x, int ldx, const float *in_scale, const float *in_
 /* tf.image.resize_bilinear, TF1 legacy (align_corners=False, no half-pixel): deeplabv3p.py:382,:418,:439 */
 int dl3_resize_bilinear_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
                             float *y, int ldy, int N, int Hi, int Wi, int Ho, int Wo, int C, void *stream);
-/* dx[N,Hi,Wi,C] (+= if accumulate) = resize^T(dy) — deterministic gather form */
+/* dx[N,Hi,Wi,C] (+= if accumulate) = resize^T(dy) — deterministic gather form.  With a workspace of
+ * dl3_resize_bilinear_bwd_workspace() bytes the transpose runs separably (columns, then rows: each dy element is
+ * read once); workspace == NULL selects the single-pass 2-D gather. */
+size_t dl3_resize_bilinear_bwd_workspace(int N, int Hi, int Wi, int Ho, int Wo, int C);
 int dl3_resize_bilinear_bwd(const float *dy, int lddy, float *dx, int lddx, int N, int Hi, int Wi, int Ho,
-                            int Wo, int C, int accumulate, void *stream);
+                            int Wo, int C, int accumulate, void *workspace, size_t workspace_bytes, void *stream);
 /* Subpixel._phase_shift (subpixel.py:77-88): out[n,ia*r+q,ib*r+p,ch] = in[n,ia,ib,ch*r*r+p*r+q];
  * inverse!=0 applies the inverse permutation (the backward pass) */
 int dl3_phase_shift(const float *in, float *out, int N, int H, int W, int Cout, int r, int inverse, void *stream);

@@ -181,21 +181,33 @@ __global__ __launch_bounds__(256) void grad_finish_kernel(const float *gin, int 
     if (mean) { mu = mean[c]; is = invstd[c]; }
   }
   float s1 = 0.f, s2 = 0.f;
-  if (cok)
-    for (long m = (long)blockIdx.y * 8 + rl; m < M; m += (long)gridDim.y * 8) {
-      float v = gin_scale * gin[(size_t)(gin_div > 1 ? m / gin_div : m) * ldgin + c];
-      if (drop_rate > 0.f)
-        v = (dl3_uniform(seed, (unsigned long long)(m * C + c)) >= drop_rate) ? v * keep_scale : 0.f;
-      float xr = 0.f;
-      if (xraw) {
-        xr = xraw[(size_t)m * ldx + c];
-        v *= dl3_act_mask(es * xr + et, act);
-      }
-      if (add) v += add[(size_t)m * ldadd + c];
-      gout[(size_t)m * ldgout + c] = v;
-      s1 += v;
-      s2 += v * ((xr - mu) * is);
+  const int cc = min(c, C - 1);
+  const long stride = (long)gridDim.y * 8;
+  // 4 rows per iteration, every load issued before the first use (clamped addresses, no branches)
+  for (long m0 = (long)blockIdx.y * 8 + rl; m0 < M; m0 += 4 * stride) {
+    float gv[4], xv[4], av[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const long m = min(m0 + q * stride, M - 1);
+      gv[q] = gin[(size_t)(gin_div > 1 ? m / gin_div : m) * ldgin + cc];
+      xv[q] = xraw ? xraw[(size_t)m * ldx + cc] : 0.f;
+      av[q] = add ? add[(size_t)m * ldadd + cc] : 0.f;
     }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const long m = m0 + q * stride;
+      float v = gin_scale * gv[q];
+      if (drop_rate > 0.f)
+        v = (dl3_uniform(seed, (unsigned long long)(min(m, M - 1) * C + cc)) >= drop_rate) ? v * keep_scale : 0.f;
+      if (xraw) v *= dl3_act_mask(es * xv[q] + et, act);
+      v += av[q];
+      if (cok && m < M) {
+        gout[(size_t)m * ldgout + c] = v;
+        s1 += v;
+        s2 += v * ((xv[q] - mu) * is);
+      }
+    }
+  }
   if (part) {
     red[threadIdx.x * 2] = s1;
     red[threadIdx.x * 2 + 1] = s2;
@@ -224,7 +236,14 @@ __global__ __launch_bounds__(256) void gap_kernel(const float *__restrict__ x, i
     float es = 1.f, et = 0.f;
     if (sc) { es = sc[c]; et = sh[c]; }
     const float *p = x + (size_t)n * HW * ldx + c;
-    for (int i = rl; i < HW; i += 8) s += dl3_act(es * p[(size_t)i * ldx] + et, act);
+    int i = rl;
+    for (; i + 24 < HW; i += 32) {  // 4 independent loads per iteration
+      const float v0 = p[(size_t)i * ldx], v1 = p[(size_t)(i + 8) * ldx], v2 = p[(size_t)(i + 16) * ldx],
+                  v3 = p[(size_t)(i + 24) * ldx];
+      s += (dl3_act(es * v0 + et, act) + dl3_act(es * v1 + et, act)) +
+           (dl3_act(es * v2 + et, act) + dl3_act(es * v3 + et, act));
+    }
+    for (; i < HW; i += 8) s += dl3_act(es * p[(size_t)i * ldx] + et, act);
   }
   red[threadIdx.x] = s;
   __syncthreads();
@@ -278,6 +297,35 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
     m[i] = mi;
     v[i] = vi;
     p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+// float4 variant: C % 4 == 0, all leading dimensions % 4 == 0, fewer than 2^31 elements
+__global__ __launch_bounds__(256) void affine_add4_kernel(const float *__restrict__ a, int lda,
+                                                          const float *__restrict__ sa,
+                                                          const float *__restrict__ ta, int act_a,
+                                                          const float *__restrict__ b, int ldb,
+                                                          const float *__restrict__ sb,
+                                                          const float *__restrict__ tb, int act_b,
+                                                          float *__restrict__ out, int ldo, unsigned total4,
+                                                          unsigned C4, float drop_rate, unsigned long long seed) {
+  const float keep_scale = drop_rate > 0.f ? 1.f / (1.f - drop_rate) : 1.f;
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total4; i += gridDim.x * 256) {
+    const unsigned m = i / C4, c = (i - m * C4) * 4;
+    f32x4 v = ld4(a + (size_t)m * lda + c);
+    if (sa) v = ld4(sa + c) * v + ld4(ta + c);
+    v = dl3_act4(v, act_a);
+    if (b) {
+      f32x4 u = ld4(b + (size_t)m * ldb + c);
+      if (sb) u = ld4(sb + c) * u + ld4(tb + c);
+      v += dl3_act4(u, act_b);
+    }
+    if (drop_rate > 0.f) {
+      const unsigned long long e0 = (unsigned long long)m * (C4 * 4) + c;
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] = (dl3_uniform(seed, e0 + j) >= drop_rate) ? v[j] * keep_scale : 0.f;
+    }
+    st4(out + (size_t)m * ldo + c, v);
   }
 }
 
@@ -351,8 +399,16 @@ extern "C" int dl3_affine_add(const float *a, int lda, const float *sa, const fl
   DL3_CHECK_ARG((sa == nullptr) == (ta == nullptr) && (sb == nullptr) == (tb == nullptr),
                 "affine_add: scale/shift must come together");
   DL3_CHECK_ARG(drop_rate >= 0.f && drop_rate < 1.f, "affine_add: drop_rate must be in [0,1)");
-  hipLaunchKernelGGL(affine_add_kernel, dim3(ew_blocks((size_t)M * C)), dim3(256), 0, (hipStream_t)stream, a, lda,
-                     sa, ta, act_a, b, ldb, sb, tb, act_b, out, ldo, (long)M, C, drop_rate, drop_seed);
+  const bool v4 = C % 4 == 0 && lda % 4 == 0 && ldo % 4 == 0 && (!b || ldb % 4 == 0) && (size_t)M * C < (1ull << 31) &&
+                  (((uintptr_t)a | (uintptr_t)out | (uintptr_t)b | (uintptr_t)sa | (uintptr_t)ta | (uintptr_t)sb |
+                    (uintptr_t)tb) & 15) == 0;
+  if (v4)
+    hipLaunchKernelGGL(affine_add4_kernel, dim3(ew_blocks((size_t)M * C / 4)), dim3(256), 0, (hipStream_t)stream, a,
+                       lda, sa, ta, act_a, b, ldb, sb, tb, act_b, out, ldo, (unsigned)((size_t)M * C / 4),
+                       (unsigned)(C / 4), drop_rate, drop_seed);
+  else
+    hipLaunchKernelGGL(affine_add_kernel, dim3(ew_blocks((size_t)M * C)), dim3(256), 0, (hipStream_t)stream, a, lda,
+                       sa, ta, act_a, b, ldb, sb, tb, act_b, out, ldo, (long)M, C, drop_rate, drop_seed);
   DL3_LAUNCH_CHECK("affine_add");
   return DL3_OK;
 }

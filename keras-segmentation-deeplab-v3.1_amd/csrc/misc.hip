@@ -84,6 +84,50 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float *__restrict
   }
 }
 
+// separable form of the same transpose: pass X folds the output columns of every output row onto the input columns
+// (tmp [N,Ho,Wi,C]), pass Y folds the output rows onto the input rows.  Each dy element is read once instead of four
+// times and the per-element loop is 2f+3 long instead of (2f+3)^2.
+__global__ __launch_bounds__(256) void resize_bwd_x_kernel(const float *__restrict__ dy, int lddy,
+                                                           float *__restrict__ tmp, int Wi, int Wo, int C, float sx) {
+  // grid.y = output row (n, oy); threads cover (ix, c)
+  const float *row = dy + (size_t)blockIdx.y * Wo * lddy;
+  float *trow = tmp + (size_t)blockIdx.y * Wi * C;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < Wi * C; i += gridDim.x * 256) {
+    const int ix = i / C, c = i - ix * C;
+    int ox0 = (int)floorf((float)(ix - 1) / sx) - 1, ox1 = (int)ceilf((float)(ix + 1) / sx) + 1;
+    ox0 = max(ox0, 0);
+    ox1 = min(ox1, Wo - 1);
+    float acc = 0.f;
+    for (int ox = ox0; ox <= ox1; ++ox) {
+      const Lerp lx = tf1_lerp(ox, sx, Wi);
+      const float wx = (lx.lo == ix ? 1.f - lx.w : 0.f) + (lx.hi == ix ? lx.w : 0.f);
+      acc += wx * row[(size_t)ox * lddy + c];
+    }
+    trow[i] = acc;
+  }
+}
+__global__ __launch_bounds__(256) void resize_bwd_y_kernel(const float *__restrict__ tmp, float *__restrict__ dx,
+                                                           int lddx, int Hi, int Wi, int Ho, int C, float sy,
+                                                           int accumulate) {
+  // grid.y = input row (n, iy); threads cover (ix, c)
+  const int n = blockIdx.y / Hi, iy = blockIdx.y - n * Hi;
+  int oy0 = (int)floorf((float)(iy - 1) / sy) - 1, oy1 = (int)ceilf((float)(iy + 1) / sy) + 1;
+  oy0 = max(oy0, 0);
+  oy1 = min(oy1, Ho - 1);
+  const float *tn = tmp + (size_t)n * Ho * Wi * C;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < Wi * C; i += gridDim.x * 256) {
+    const int ix = i / C, c = i - ix * C;
+    float acc = 0.f;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+      const Lerp ly = tf1_lerp(oy, sy, Hi);
+      const float wy = (ly.lo == iy ? 1.f - ly.w : 0.f) + (ly.hi == iy ? ly.w : 0.f);
+      acc += wy * tn[(size_t)oy * Wi * C + i];
+    }
+    float *o = dx + ((size_t)blockIdx.y * Wi + ix) * lddx + c;
+    *o = accumulate ? (*o + acc) : acc;
+  }
+}
+
 // out[n, ia*r+q, ib*r+p, ch] = in[n, ia, ib, ch*r*r + p*r + q]   (subpixel.py:81-87)
 __global__ __launch_bounds__(256) void phase_shift_kernel(const float *__restrict__ in, float *__restrict__ out,
                                                           int N, int H, int W, int Cout, int r, int inverse) {
@@ -304,11 +348,27 @@ extern "C" int dl3_resize_bilinear_fwd(const float *x, int ldx, const float *in_
   return DL3_OK;
 }
 
+extern "C" size_t dl3_resize_bilinear_bwd_workspace(int N, int Hi, int Wi, int Ho, int Wo, int C) {
+  (void)Hi; (void)Wo;
+  return (size_t)N * Ho * Wi * C * sizeof(float);
+}
+
 extern "C" int dl3_resize_bilinear_bwd(const float *dy, int lddy, float *dx, int lddx, int N, int Hi, int Wi,
-                                       int Ho, int Wo, int C, int accumulate, void *stream) {
+                                       int Ho, int Wo, int C, int accumulate, void *workspace,
+                                       size_t workspace_bytes, void *stream) {
   DL3_CHECK_ARG(dy && dx && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "resize_bwd: bad argument");
   DL3_CHECK_ARG(lddy >= C && lddx >= C, "resize_bwd: leading dimension too small");
   const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+  if (workspace && workspace_bytes >= dl3_resize_bilinear_bwd_workspace(N, Hi, Wi, Ho, Wo, C)) {
+    int gx = dl3_cdiv(Wi * C, 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(resize_bwd_x_kernel, dim3(gx, N * Ho), dim3(256), 0, (hipStream_t)stream, dy, lddy,
+                       (float *)workspace, Wi, Wo, C, sx);
+    hipLaunchKernelGGL(resize_bwd_y_kernel, dim3(gx, N * Hi), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)workspace, dx, lddx, Hi, Wi, Ho, C, sy, accumulate);
+    DL3_LAUNCH_CHECK("resize_bwd(separable)");
+    return DL3_OK;
+  }
   int gx = dl3_cdiv(Wi * C, 256);
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(resize_bwd_kernel, dim3(gx, N * Hi), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx, lddx, N,

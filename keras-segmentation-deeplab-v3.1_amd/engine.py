@@ -916,13 +916,16 @@ class ResizeUnit:
             eng.contrib_elementwise(ibuf, inv, ptr(tmp), C)
         elif plain:
             gout, add, last = eng.contrib_kernel(ibuf)
-            eng.op(eng.ops_bwd, "dl3_resize_bilinear_bwd", g, outv.ld, ptr(gout), ibuf.ld, B, Hi, Wi, Ho, Wo, C,
-                   1 if add is not None else 0)
+            ws = eng.lib.dl3_resize_bilinear_bwd_workspace(B, Hi, Wi, Ho, Wo, C)
+            eng.op_ws(eng.ops_bwd, "dl3_resize_bilinear_bwd", ws, 11, g, outv.ld, ptr(gout), ibuf.ld, B, Hi, Wi, Ho, Wo,
+                      C, 1 if add is not None else 0, 0, ws)
             if add is not None and add is not gout:
                 raise NotImplementedError("resize backward with a foreign addend")
         else:
             tmp = eng.empty(ibuf.M * C)
-            eng.op(eng.ops_bwd, "dl3_resize_bilinear_bwd", g, outv.ld, ptr(tmp), C, B, Hi, Wi, Ho, Wo, C, 0)
+            ws = eng.lib.dl3_resize_bilinear_bwd_workspace(B, Hi, Wi, Ho, Wo, C)
+            eng.op_ws(eng.ops_bwd, "dl3_resize_bilinear_bwd", ws, 11, g, outv.ld, ptr(tmp), C, B, Hi, Wi, Ho, Wo, C, 0,
+                      0, ws)
             eng.contrib_elementwise(ibuf, inv, ptr(tmp), C)
 
 

@@ -439,10 +439,14 @@ def test_resize_bilinear(L, dims):
     g = rng.normal(0, 1, ref.shape).astype(np.float32)
     dx_ref = tape.backward(ref, g)[id(x)]
     dx = empty(N, Hi, Wi, C)
-    call("dl3_resize_bilinear_bwd", ptr(dev(g)), C, ptr(dx), C, N, Hi, Wi, Ho, Wo, C, 0)
+    call("dl3_resize_bilinear_bwd", ptr(dev(g)), C, ptr(dx), C, N, Hi, Wi, Ho, Wo, C, 0, None, 0)
     assert relerr(host(dx), dx_ref) < 1e-4
-    call("dl3_resize_bilinear_bwd", ptr(dev(g)), C, ptr(dx), C, N, Hi, Wi, Ho, Wo, C, 1)
+    call("dl3_resize_bilinear_bwd", ptr(dev(g)), C, ptr(dx), C, N, Hi, Wi, Ho, Wo, C, 1, None, 0)
     assert relerr(host(dx), 2 * dx_ref) < 1e-4
+    nb = L.dl3_resize_bilinear_bwd_workspace(N, Hi, Wi, Ho, Wo, C)  # separable two-pass form
+    ws = empty(nb // 4 + 4)
+    call("dl3_resize_bilinear_bwd", ptr(dev(g)), C, ptr(dx), C, N, Hi, Wi, Ho, Wo, C, 0, ptr(ws), nb)
+    assert relerr(host(dx), dx_ref) < 1e-4
 
 
 def test_subsample(L):
