@@ -46,18 +46,22 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(const float *__restric
     const int oy = (int)((p / G.Wo) % G.Ho);
     const int n = (int)(p / ((long)G.Wo * G.Ho));
     f32x4 acc = splat4(0.f);
+    // clamped tap coordinates + 0/1 weights instead of branches: all loads of a pixel are issued together
+#pragma unroll
     for (int i = 0; i < 3; i++) {
       const int iy = oy * G.stride - G.pad_t + i;
-      if (iy < 0 || iy >= G.H) continue;
+      const int iyc = min(max(iy, 0), G.H - 1);
+#pragma unroll
       for (int j = 0; j < 3; j++) {
         const int ix = ox * G.stride - G.pad_l + j;
-        if (ix < 0 || ix >= G.W) continue;
-        const float *xp = x + (((size_t)n * G.H + iy) * G.W + ix) * G.Cin;
+        const int ixc = min(max(ix, 0), G.W - 1);
+        const float live = (iy == iyc && ix == ixc) ? 1.f : 0.f;
+        const float *xp = x + (((size_t)n * G.H + iyc) * G.W + ixc) * G.Cin;
         const float *wp = w + ((size_t)(i * 3 + j) * G.Cin) * G.Cout + co;
         for (int ci = 0; ci < G.Cin; ci++) {
           float v = xp[ci];
           if (sc) v = sc[ci] * v + sh[ci];
-          v = dl3_act(v, act);
+          v = dl3_act(v, act) * live;
           acc += splat4(v) * ld4(wp + (size_t)ci * G.Cout);
         }
       }
@@ -108,27 +112,30 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float *__restr
     const int n = (int)(p / ((long)G.Wo * G.Ho));
     f32x4 dd = ld4(g + (size_t)p * G.Cout + co);
     if (two) dd = kA * dd + kB * ld4(yraw + (size_t)p * G.Cout + co) + kC;
+    float xv[9][CI_CHUNK];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
       const int iy = oy * G.stride - G.pad_t + i;
-      if (iy < 0 || iy >= G.H) continue;
+      const int iyc = min(max(iy, 0), G.H - 1);
 #pragma unroll
       for (int j = 0; j < 3; j++) {
         const int ix = ox * G.stride - G.pad_l + j;
-        if (ix < 0 || ix >= G.W) continue;
-        const float *xp = x + (((size_t)n * G.H + iy) * G.W + ix) * G.Cin;
+        const int ixc = min(max(ix, 0), G.W - 1);
+        const float live = (iy == iyc && ix == ixc) ? 1.f : 0.f;
+        const float *xp = x + (((size_t)n * G.H + iyc) * G.W + ixc) * G.Cin;
 #pragma unroll
         for (int k = 0; k < CI_CHUNK; k++) {
-          const int ci = ci0 + k;
-          if (ci < G.Cin) {
-            float v = xp[ci];
-            if (sc) v = sc[ci] * v + sh[ci];
-            v = dl3_act(v, act);
-            acc[i * 3 + j][k] += splat4(v) * dd;
-          }
+          const int ci = min(ci0 + k, G.Cin - 1);
+          float v = xp[ci];
+          if (sc) v = sc[ci] * v + sh[ci];
+          xv[i * 3 + j][k] = dl3_act(v, act) * ((ci0 + k < G.Cin) ? live : 0.f);
         }
       }
     }
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+      for (int k = 0; k < CI_CHUNK; k++) acc[t][k] += splat4(xv[t][k]) * dd;
   }
 #pragma unroll
   for (int t = 0; t < 9; t++) {
