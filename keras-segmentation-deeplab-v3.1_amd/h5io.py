@@ -3,8 +3,9 @@ deeplabv3p.py:465; positional load utils.py:207,:229; ModelCheckpoint(save_weigh
 
 Layout [TF-semantics: Keras 2.2.x save_weights] — root attrs `layer_names`, `backend`, `keras_version`;
 one group per layer with attr `weight_names`; datasets `/<layer>/<layer>/<var>:0`, float32, HWIO.
-`.h5` files need h5py (absent from this image's main interpreter — probed at call time); the same
-content is always readable/writable as `.npz` with keys "<layer>/<var>:0" plus "__layer_names__".
+`.h5` files go through h5py when it is importable, otherwise through the package's own HDF5 subset
+reader/writer (h5lite.py; validated against h5py/libhdf5 1.10.6 in both directions).  The same content can also be
+read/written as `.npz` with keys "<layer>/<var>:0" plus "__layer_names__".
 """
 import numpy as np
 
@@ -32,7 +33,9 @@ def save_weights(model, path):
         return
     h5py = _h5py()
     if h5py is None:
-        raise ImportError("saving Keras .h5 weights needs h5py; use a .npz path (same keys) on this machine")
+        from . import h5lite
+        h5lite.write_keras_weights(path, [(l.name, list(zip(l.weights.keys(), l.get_weights()))) for l in layers])
+        return
     with h5py.File(path, "w", libver="earliest") as f:
         f.attrs["layer_names"] = np.array([l.name.encode() for l in layers], dtype="S")
         f.attrs["backend"] = b"tensorflow"
@@ -58,8 +61,8 @@ def _read_file(path):
         return names, per
     h5py = _h5py()
     if h5py is None:
-        raise ImportError("reading Keras .h5 weights needs h5py, which this interpreter lacks; convert the file to "
-                          ".npz (keys '<layer>/<var>:0') on a machine that has it")
+        from . import h5lite
+        return h5lite.read_keras_weights(path)
     with h5py.File(path, "r") as f:
         root = f["model_weights"] if "model_weights" in f else f
         dec = lambda s: s.decode() if isinstance(s, bytes) else str(s)

@@ -159,3 +159,54 @@ def test_host_metrics():
     # class 2: 1
     assert abs(Jaccard(y_true, probs) - np.mean([np.mean([1 / 2, 1 / 4]), 1 / 2, 1.0])) < 1e-6
     assert abs(Jaccard(y_true, probs) - O.jaccard(y_true[:, :, 0], probs)) < 1e-12
+
+
+def _fixture_value(name, shape):
+    n = int(np.prod(shape))
+    return ((np.arange(n, dtype=np.float32) * 0.25 + len(name)) % 7.0 - 3.0).reshape(shape)
+
+
+def test_h5lite_reads_a_real_h5py_file():
+    """tests/golden/keras_style_h5py.h5 was written by h5py/libhdf5 (make_h5_fixture.py) in the Keras 2.2.x layout"""
+    import os
+    from dl3_amd import h5lite
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "keras_style_h5py.h5")
+    names, per = h5lite.read_keras_weights(path)
+    assert len(names) == 46 and names[:4] == ["input_1", "lambda_1", "Conv", "Conv_BN"]
+    assert per["input_1"] == [] and [w for w, _ in per["Conv_BN"]] == [
+        "Conv_BN/gamma:0", "Conv_BN/beta:0", "Conv_BN/moving_mean:0", "Conv_BN/moving_variance:0"]
+    n = 0
+    for l in names:
+        for w, a in per[l]:
+            assert a.dtype == np.float32 and np.array_equal(a, _fixture_value(w, a.shape)), w
+            n += 1
+    assert n == 48
+    r = h5lite.Reader(path)
+    a = r.attrs(r.root["ohdr"])
+    assert a["backend"] == b"tensorflow" and a["keras_version"] == b"2.2.4"
+
+
+def test_h5_weight_roundtrip_through_h5lite(tmp_path, monkeypatch):
+    """model.save_weights('x.h5') / load_weights('x.h5', by_name) with the package's own HDF5 writer/reader"""
+    from dl3_amd import h5io, h5lite
+    monkeypatch.setattr(h5io, "_h5py", lambda: None)  # force the self-contained path even if h5py exists
+    G.clear_session()
+    m = Deeplabv3(weights=None, input_shape=(64, 64, 3), classes=21)
+    path = str(tmp_path / "deeplabv3_mobilenetv2_tf_dim_ordering_tf_kernels.h5")
+    m.save_weights(path)
+    names, per = h5lite.read_keras_weights(path)
+    assert names == [l.name for l in m.layers]
+    G.clear_session(seed=3)
+    m2 = Deeplabv3(weights=None, input_shape=(64, 64, 3), classes=21)
+    m2.load_weights(path, by_name=True)
+    for a, b in zip(m.get_weights(), m2.get_weights()):
+        assert np.array_equal(a, b)
+    # weights='pascal_voc' resolves the bonlime file name locally (deeplabv3p.py:456-465 without the download)
+    monkeypatch.setenv("DL3_WEIGHTS_DIR", str(tmp_path))
+    G.clear_session(seed=4)
+    m3 = Deeplabv3(weights="pascal_voc", input_shape=(64, 64, 3), classes=21)
+    assert np.array_equal(m3.get_layer("aspp0").get_weights()[0], m.get_layer("aspp0").get_weights()[0])
+    with pytest.raises(h5lite.H5Error):
+        bad = tmp_path / "bad.h5"
+        bad.write_bytes(b"not hdf5 at all")
+        h5lite.read_keras_weights(str(bad))
