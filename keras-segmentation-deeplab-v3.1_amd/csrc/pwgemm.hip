@@ -38,6 +38,9 @@ struct GemmArgs {
 };
 
 constexpr int BK = 16;
+#ifndef DL3_WGRAD_MS
+#define DL3_WGRAD_MS 16
+#endif
 
 // Main loop structure (both kernels): global -> registers -> LDS, double-buffered LDS (ONE barrier per
 // K-tile), MFMA operand fragments prefetched one k-step ahead.  Out-of-range rows / columns are handled by
@@ -300,9 +303,10 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmArgs P) {
 // BatchNorm+ReLU6 (forward) or the BatchNorm-backward affine of two tensors (bwd-data) is applied to the
 // registers between load and use, one K-tile ahead of the MFMAs.
 // ---------------------------------------------------------------------------------------
-template <int TM, int TN, bool TWO>
+template <int TM, int TN, bool TWO, int KT>
 __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
-  constexpr int BM = 128 * TM, BN = 32 * TN, KT = 32;
+  // KT = depth of one K-tile: each half-wave walks KT/2 consecutive k (KT/8 float4 loads per lane and tensor)
+  constexpr int BM = 128 * TM, BN = 32 * TN, KH = KT / 2, NJ = KT / 8;
   constexpr int LDB = BN;
   constexpr int NB = (KT * BN / 4 + 255) / 256;  // float4 B loads per thread per K-tile
   __shared__ float lds[2 * KT * LDB];
@@ -340,12 +344,12 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
       arow[i] = P.a + (size_t)row * P.lda;
       arow2[i] = TWO ? P.a2 + (size_t)row * P.lda2 : nullptr;
     }
-    f32x4 an[TM][4], an2[TM][4], ac[TM][4], rb[NB];
+    f32x4 an[TM][NJ], an2[TM][NJ], ac[TM][NJ], rb[NB];
 
     auto load_A = [&](int kt) {
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int kc = min(kt * KT + 16 * lhi + 4 * j, P.K - 4);
+      for (int j = 0; j < NJ; j++) {
+        const int kc = min(kt * KT + KH * lhi + 4 * j, P.K - 4);
 #pragma unroll
         for (int i = 0; i < TM; i++) {
           an[i][j] = ld4(arow[i] + kc);
@@ -374,8 +378,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
     // registers of the NEXT K-tile -> transformed operand values of the CURRENT one (zero beyond K)
     auto transform = [&](int kt) {
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int k = kt * KT + 16 * lhi + 4 * j;
+      for (int j = 0; j < NJ; j++) {
+        const int k = kt * KT + KH * lhi + 4 * j;
         const int kc = min(k, P.K - 4);
         const float live = (k < P.K) ? 1.f : 0.f;
         f32x4 fa = splat4(1.f), fb = splat4(0.f), fc = splat4(0.f);
@@ -408,13 +412,13 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
       }
       float bf[2][TN];
 #pragma unroll
-      for (int j = 0; j < TN; j++) bf[0][j] = Bs[(16 * lhi) * LDB + j * 32 + l31];
+      for (int j = 0; j < TN; j++) bf[0][j] = Bs[(KH * lhi) * LDB + j * 32 + l31];
 #pragma unroll
-      for (int s_ = 0; s_ < 16; ++s_) {
+      for (int s_ = 0; s_ < KH; ++s_) {
         const int cur = s_ & 1, nxt = cur ^ 1;
-        if (s_ + 1 < 16) {
+        if (s_ + 1 < KH) {
 #pragma unroll
-          for (int j = 0; j < TN; j++) bf[nxt][j] = Bs[(16 * lhi + s_ + 1) * LDB + j * 32 + l31];
+          for (int j = 0; j < TN; j++) bf[nxt][j] = Bs[(KH * lhi + s_ + 1) * LDB + j * 32 + l31];
         }
 #pragma unroll
         for (int i = 0; i < TM; i++)
@@ -528,9 +532,10 @@ struct WgradArgs {
 template <int TA, int TB, int WA, int WB, bool VEC>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
   static_assert(WA * WB == 4, "4 waves per workgroup");
-  constexpr int BKT = 32 * TA * WA, BNT = 32 * TB * WB, MS = 16;
+  constexpr int BKT = 32 * TA * WA, BNT = 32 * TB * WB, MS = DL3_WGRAD_MS;
   constexpr int LDX = BKT + 4, LDD = BNT + 4;
-  constexpr int NX = (4 * BKT + 255) / 256, ND = (4 * BNT + 255) / 256;
+  constexpr int XQ = MS * BKT / 4, DQ = MS * BNT / 4;  // float4s per stage
+  constexpr int NX = (XQ + 255) / 256, ND = (DQ + 255) / 256;
   constexpr int STAGE = MS * LDX + MS * LDD;
   __shared__ float lds[2 * STAGE];
 
@@ -586,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
 #pragma unroll
     for (int i = 0; i < NX; i++) {
       const int idx = tid + 256 * i;
-      if (NX * 256 == 4 * BKT || idx < 4 * BKT) {
+      if (NX * 256 == XQ || idx < XQ) {
         const int mr = idx / (BKT / 4), kq = idx % (BKT / 4);
         const int row = min(m0 + mr, P.M - 1), k = kbase + kq * 4;
         if (VEC) {
@@ -600,7 +605,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
 #pragma unroll
     for (int i = 0; i < ND; i++) {
       const int idx = tid + 256 * i;
-      if (ND * 256 == 4 * BNT || idx < 4 * BNT) {
+      if (ND * 256 == DQ || idx < DQ) {
         const int mr = idx / (BNT / 4), nq = idx % (BNT / 4);
         const int row = min(m0 + mr, P.M - 1), col = nbase + nq * 4;
         if (VEC) {
@@ -623,7 +628,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
 #pragma unroll
     for (int i = 0; i < NX; i++) {
       const int idx = tid + 256 * i;
-      if (NX * 256 == 4 * BKT || idx < 4 * BKT) {
+      if (NX * 256 == XQ || idx < XQ) {
         const int mr = idx / (BKT / 4), kq = idx % (BKT / 4);
         const bool rok = (m0 + mr) < mend;
         f32x4 v = dl3_act4(xs4[i] * rx[i] + xt4[i], P.x_act);
@@ -636,7 +641,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
 #pragma unroll
     for (int i = 0; i < ND; i++) {
       const int idx = tid + 256 * i;
-      if (ND * 256 == 4 * BNT || idx < 4 * BNT) {
+      if (ND * 256 == DQ || idx < DQ) {
         const int mr = idx / (BNT / 4), nq = idx % (BNT / 4);
         const bool rok = (m0 + mr) < mend;
         f32x4 v = kA4[i] * rg[i] + kC4[i];
@@ -780,12 +785,17 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   const bool avec = (A.K % 4 == 0) && (A.lda % 4 == 0) && al16(A.a) && (!two || ((A.lda2 % 4 == 0) && al16(A.a2)));
   const bool bvec = (A.N % 4 == 0) && (A.ldb % 4 == 0) && al16(A.b);
   const bool vec = avec && bvec;
-  // stream-A kernel for single-tensor operands (forward): 10-20 % faster than the LDS-staged kernel on every layer
-  // shape (tools/gemm_tune.py); with the two-tensor BN-backward operand (bwd-data) its register budget spills and
-  // the staged kernel is as fast or faster, so bwd-data stays there.  DL3_GEMM_IMPL=0 forces the staged kernel.
-  if (vec && !two && env_int("DL3_GEMM_IMPL") != 0) {
+  // stream-A kernel: 10-25 % faster than the LDS-staged kernel on every layer shape, forward and bwd-data
+  // (tools/gemm_tune.py).  The two-tensor bwd-data operand uses 16-deep K-tiles so that its register budget does not
+  // spill.  DL3_GEMM_IMPL=0 forces the staged kernel (which also serves unaligned operands).
+  const int impl = env_int("DL3_GEMM_IMPL");
+  if (vec && impl != 0) {
     dim3 blk(256);
-#define DL3_STREAM(TM_, TN_) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false>), grid, blk, 0, st, A)
+#define DL3_STREAM(TM_, TN_)                                                                              \
+  do {                                                                                                    \
+    if (two) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, true, 16>), grid, blk, 0, st, A);        \
+    else hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, 16>), grid, blk, 0, st, A);           \
+  } while (0)
     switch (c.id) {
       case 0: DL3_STREAM(1, 4); break;
       case 1: DL3_STREAM(2, 2); break;
@@ -975,7 +985,7 @@ extern "C" int dl3_pwconv_bwd_weight(const float *x, int ldx, const float *in_sc
   A.cA = cA; A.cB = cB; A.cC = cC;
   A.ws = (float *)workspace;
   A.M = M; A.K = K; A.N = N;
-  A.Mper = dl3_cdiv(dl3_cdiv(M, S), 16) * 16;
+  A.Mper = dl3_cdiv(dl3_cdiv(M, S), DL3_WGRAD_MS) * DL3_WGRAD_MS;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(dl3_cdiv(N, c.BNT), dl3_cdiv(K, c.BKT), S);
   const bool xvec = (K % 4 == 0) && (ldx % 4 == 0) && al16(x);
