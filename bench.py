@@ -150,7 +150,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU (SegModel.batch_size default, utils.py:162)")
+    ap.add_argument("--batch", type=int, default=32,
+                    help="images per GPU (2x SegModel.batch_size, utils.py:162; 25 GB of the 288 GB HBM)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--backbone", default="mobilenetv2")
     ap.add_argument("--os", type=int, default=16, help="output stride (Xception only; MobileNetV2 always runs at 8)")
@@ -160,6 +161,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="launch only the roofline kernels (the rocprofv3 --stats profile of this mode is the per-kernel "
+                         "average that must agree with roofline.avg_ms)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -168,6 +172,10 @@ def main():
     dp = DataParallel(backend="nccl")
     assert dp.world == args.gpus or (args.gpus == 1 and dp.world == 1), "launch with torch.distributed.run for --gpus > 1"
 
+    if args.roofline_only:
+        r = roofline_leg(args.batch)
+        print(json.dumps({k: v["ms"] for k, v in r.items()}))
+        return
     log("building engine (batch %d per GPU, %d GPU)" % (args.batch, dp.world))
     model, eng = build_engine(args)
     log("engine built: %d fwd ops, %d bwd ops, %.2f GB device memory" % (
@@ -215,7 +223,7 @@ def main():
             # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected separately
             # with tools/dw_only.py and corrected as MI355X_MICROARCH.md prescribes): committed under profiles/
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_dw_r4_b16_pmc.json")
+            pmc = os.path.join(ROOT, "profiles", "r01_dw_r4_b%d_pmc.json" % args.batch)
             if os.path.exists(pmc):
                 pj = json.load(open(pmc))
                 if pj.get("batch") == args.batch:
