@@ -15,6 +15,7 @@
 // BatchNorm + ReLU6 of the producer are applied on load ("input transform"); the BN batch
 // statistics of THIS layer's output are reduced in the epilogue into deterministic partials.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -64,30 +65,36 @@ __global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x,
                                                     const float *__restrict__ sh, int act,
                                                     const float *__restrict__ w, float *__restrict__ y,
                                                     int H, int W, int C, int r, int nchunk, int TK, int nxseg,
-                                                    float *__restrict__ part) {
+                                                    int nphase, int ppb, float *__restrict__ part) {
   __shared__ float red[4 * 8 * 8];
   const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
   const int xs = blockIdx.x % nxseg, slab = blockIdx.x / nxseg;
   const int pc = blockIdx.y, n = blockIdx.z;
-  const int a = pc / nchunk, ch = pc % nchunk;
   const int c = slab * 32 + cq * 4;
   const int xx = xs * 32 + pl;
   const bool active = (c < C) && (xx < W);
-  const int Ka = (a < H) ? (H - a + r - 1) / r : 0;
-  const int k0 = ch * TK;
-  const int k1 = min(k0 + TK, Ka);
 
   f32x4 wv[9], s = splat4(1.f), t = splat4(0.f);
 #pragma unroll
   for (int i = 0; i < 9; i++) wv[i] = ld4(w + (size_t)i * C + min(c, C - 4));
   if (sc) { s = ld4(sc + min(c, C - 4)); t = ld4(sh + min(c, C - 4)); }
+  f32x4 s1 = splat4(0.f), s2 = splat4(0.f);
+  // a workgroup owns `ppb` consecutive row phases (large rates leave only 2-3 rows per phase: several phases per
+  // workgroup amortise the prologue) or, for ppb == 1, one chunk of TK rows of one phase
+  for (int pi = 0; pi < ppb; ++pi) {
+  const int a = (ppb > 1) ? pc * ppb + pi : pc / nchunk;
+  const int ch = (ppb > 1) ? 0 : pc % nchunk;
+  if (a >= nphase) break;
+  const int Ka = (a < H) ? (H - a + r - 1) / r : 0;
+  const int k0 = ch * TK;
+  const int k1 = min(k0 + TK, Ka);
+  const int Kc = max(Ka - 1, 0);
   const bool xl_ok = (xx - r >= 0), xr_ok = (xx + r < W);
   // clamped coordinates: every lane always issues in-bounds loads (no branches -> the loads of a row group are
   // all in flight together); out-of-image taps and idle lanes are zeroed by a select afterwards
   const int cc = min(c, C - 4), xc = min(xx, W - 1), xlc = min(max(xx - r, 0), W - 1), xrc = min(xx + r, W - 1);
   const float *xbase = x + ((size_t)n * H * W) * C + cc;
   float *ybase = y + ((size_t)n * H * W) * C + c;
-  const int Kc = max(Ka - 1, 0);
 
   auto ldrow = [&](int k, f32x4 &l, f32x4 &m, f32x4 &rr) {
     const bool rok = active && k >= 0 && k < Ka;
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x,
     rr = vr * splat4((rok && xr_ok) ? 1.f : 0.f);
   };
 
-  f32x4 accA = splat4(0.f), accB = splat4(0.f), s1 = splat4(0.f), s2 = splat4(0.f);
+  f32x4 accA = splat4(0.f), accB = splat4(0.f);
   // rows are processed in groups of R: all 3*R loads of a group are issued before the first use, so every lane
   // keeps R cache-missing (centre-tap) loads in flight — the kernel is latency-bound otherwise
   constexpr int R = 4;
@@ -127,6 +134,7 @@ __global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x,
       accB = h0;
     }
   }
+  }  // phases of this workgroup
   if (part) {
     float v[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
     reduce_px<8>(v, red);
@@ -147,18 +155,14 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
     const float *__restrict__ sc, const float *__restrict__ sh, int act, const float *__restrict__ w,
     float *__restrict__ dx, const float *__restrict__ dx_add, const float *__restrict__ xmean,
     const float *__restrict__ xinvstd, float *__restrict__ dpart, float *__restrict__ wpart, int H, int W, int C,
-    int r, int nchunk, int TK, int nxseg) {
+    int r, int nchunk, int TK, int nxseg, int nphase, int ppb) {
   __shared__ float red[4 * 8 * 36];
   const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
   const int xs = blockIdx.x % nxseg, slab = blockIdx.x / nxseg;
   const int pc = blockIdx.y, n = blockIdx.z;
-  const int a = pc / nchunk, ch = pc % nchunk;
   const int c = slab * 32 + cq * 4;
   const int xx = xs * 32 + pl;
   const bool active = (c < C) && (xx < W);
-  const int Ka = (a < H) ? (H - a + r - 1) / r : 0;
-  const int k0 = ch * TK;
-  const int k1 = min(k0 + TK, Ka);
 
   f32x4 wv[9], s = splat4(1.f), t = splat4(0.f);
   f32x4 kA = splat4(1.f), kB = splat4(0.f), kC = splat4(0.f), mu = splat4(0.f), is = splat4(0.f);
@@ -175,6 +179,17 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
   const int cc = min(c, C - 4), xc = min(xx, W - 1), xlc = min(max(xx - r, 0), W - 1), xrc = min(xx + r, W - 1);
   const size_t img = ((size_t)n * H * W) * C + c;    // own position (stores)
   const size_t imgc = ((size_t)n * H * W) * C + cc;  // clamped (loads)
+  f32x4 dwv[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) dwv[i] = splat4(0.f);
+  f32x4 s1 = splat4(0.f), s2 = splat4(0.f);
+  for (int pi = 0; pi < ppb; ++pi) {  // row phases owned by this workgroup (see dw_march_fwd)
+  const int a = (ppb > 1) ? pc * ppb + pi : pc / nchunk;
+  const int ch = (ppb > 1) ? 0 : pc % nchunk;
+  if (a >= nphase) break;
+  const int Ka = (a < H) ? (H - a + r - 1) / r : 0;
+  const int k0 = ch * TK;
+  const int k1 = min(k0 + TK, Ka);
   const int Kc = max(Ka - 1, 0);
   const float *yr = two ? yraw : g;  // when dY = g the second stream aliases the first (coefficient 0)
 
@@ -198,10 +213,7 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
     return v * splat4(ok ? 1.f : 0.f);
   };
 
-  f32x4 dwv[9];
-#pragma unroll
-  for (int i = 0; i < 9; i++) dwv[i] = splat4(0.f);
-  f32x4 accA = splat4(0.f), accB = splat4(0.f), s1 = splat4(0.f), s2 = splat4(0.f);
+  f32x4 accA = splat4(0.f), accB = splat4(0.f);
 
   if (k0 < k1) {
     // groups of R dY rows: the 7*R loads of a group (3 taps x {g, yraw} + the forward input row) are issued
@@ -251,6 +263,7 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
       }
     }
   }
+  }  // phases of this workgroup
   const int p = (n * gridDim.y + pc) * nxseg + xs;
   {
     float v[36];
@@ -430,6 +443,7 @@ __global__ __launch_bounds__(256) void dw_gather_bwd(
 struct DwPlan {
   int impl;                      // DL3_IMPL_MARCH / DL3_IMPL_GATHER
   int nslab, nxseg, nphase, nchunk, TK;  // march
+  int ppb, ny;                           // march: row phases per workgroup, grid.y
   int PB;                        // gather
   int P;
 };
@@ -451,7 +465,19 @@ DwPlan dw_plan(int N, int H, int W, int C, int stride, int rate, int Ho, int Wo,
     while (TK > 8 && (long)N * p.nslab * p.nxseg * p.nphase * dl3_cdiv(Kmax, TK) < 2048) TK = (TK + 1) / 2;
     p.TK = TK;
     p.nchunk = dl3_cdiv(Kmax, TK);
-    p.P = N * p.nphase * p.nchunk * p.nxseg;
+    // large rates: a phase holds only Kmax = 2..6 rows -> give a workgroup several phases (~12 rows of work)
+    int ppb = 1;
+    if (p.nchunk == 1 && Kmax < 12) {
+      ppb = 12 / Kmax;
+      if (ppb > p.nphase) ppb = p.nphase;
+      while (ppb > 1 && (long)N * p.nslab * p.nxseg * dl3_cdiv(p.nphase, ppb) < 2048) --ppb;
+      if (const char *e = getenv("DL3_DW_PPB")) ppb = atoi(e);  // tuning / test override
+      if (ppb > p.nphase) ppb = p.nphase;
+      if (ppb < 1) ppb = 1;
+    }
+    p.ppb = ppb;
+    p.ny = (ppb > 1) ? dl3_cdiv(p.nphase, ppb) : p.nphase * p.nchunk;
+    p.P = N * p.ny * p.nxseg;
   } else {
     const long NP = bwd ? (long)N * H * W : (long)N * Ho * Wo;
     long pb = (NP + 31) / 32;
@@ -505,9 +531,9 @@ extern "C" int dl3_dwconv3x3_fwd(const float *x, const float *in_scale, const fl
   DwPlan p = dw_plan(N, H, W, C, stride, rate, Ho, Wo, im, false);
   hipStream_t st = (hipStream_t)stream;
   if (im == DL3_IMPL_MARCH) {
-    dim3 grid(p.nslab * p.nxseg, p.nphase * p.nchunk, N);
+    dim3 grid(p.nslab * p.nxseg, p.ny, N);
     hipLaunchKernelGGL(dw_march_fwd, grid, dim3(256), 0, st, x, in_scale, in_shift, in_act, w, y, H, W, C, rate,
-                       p.nchunk, p.TK, p.nxseg, stat_partial);
+                       p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, stat_partial);
   } else {
     DwGeom G{N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo};
     dim3 grid(p.nslab, p.PB);
@@ -539,10 +565,10 @@ extern "C" int dl3_dwconv3x3_bwd(const float *g, const float *yraw, const float 
   DwPlan p = dw_plan(N, H, W, C, stride, rate, Ho, Wo, im, true);
   hipStream_t st = (hipStream_t)stream;
   if (im == DL3_IMPL_MARCH) {
-    dim3 grid(p.nslab * p.nxseg, p.nphase * p.nchunk, N);
+    dim3 grid(p.nslab * p.nxseg, p.ny, N);
     hipLaunchKernelGGL(dw_march_bwd, grid, dim3(256), 0, st, g, yraw, cA, cB, cC, x, in_scale, in_shift, in_act,
                        w, dx, dx_add, x_mean, x_invstd, dstat_partial, dw_partial, H, W, C, rate, p.nchunk, p.TK,
-                       p.nxseg);
+                       p.nxseg, p.nphase, p.ppb);
   } else {
     DwGeom G{N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo};
     dim3 grid(p.nslab, p.PB);

@@ -40,6 +40,7 @@ DW_CASES = [
     (3, 64, 64, 144, 1, 1, None, 0, 2),  # C not a multiple of 32, several row chunks
     (2, 8, 8, 64, 1, 2, None, 0, 2),     # map narrower than the 32 pixel lanes (idle lanes must stay in bounds)
     (1, 4, 4, 32, 1, 1, None, 0, 1),
+    (16, 36, 36, 512, 1, 18, None, 0, 2),  # large rate: several row phases per workgroup (ASPP rates 12/24/36)
 ]
 
 
@@ -110,6 +111,15 @@ def test_dwconv_bwd(L, case):
     s1, s2 = fold_partials(dpart, P, C)
     assert relerr(s1, dx_ref.sum((0, 1, 2))) < 1e-3
     assert relerr(s2, (dx_ref * (x - mean) * invstd).sum((0, 1, 2))) < 1e-3
+
+
+@pytest.mark.parametrize("ppb", [2, 3, 5])
+def test_dwconv_phases_per_workgroup(L, ppb, monkeypatch):
+    """march kernels with a forced number of row phases per workgroup (uneven last group, rate 5 on 16 rows)"""
+    monkeypatch.setenv("DL3_DW_PPB", str(ppb))
+    case = (2, 16, 20, 40, 1, 5, None, 2, 2)
+    test_dwconv_fwd(L, case)
+    test_dwconv_bwd(L, case)
 
 
 def test_dwconv_bwd_plain_operand(L):
