@@ -58,18 +58,37 @@ __device__ __forceinline__ void write_stat_partial(float *part, int p, int C, in
   d[4] = s1.z; d[5] = s2.z; d[6] = s1.w; d[7] = s2.w;
 }
 
+// Workgroup -> tile decode for the march kernels.  The grid is 1-D and padded to a multiple of 8: hardware hands
+// consecutive workgroup ids to the 8 XCDs round-robin, so id L runs on XCD L%8.  Virtual id v = (L%8)*chunk + L/8
+// makes consecutive v share an XCD (and its 4 MB L2) at about the same time; with the x segment as the fastest
+// coordinate the +-rate taps that cross a 32-pixel segment boundary are served by that L2 instead of a second HBM
+// fetch (at rate 36 on a 64 wide map every tap crosses).
+struct DwTile { int xs, slab, pc, n; };
+__device__ __forceinline__ bool dw_tile(int nxseg, int nslab, int ny, int N, int xcd, DwTile &t) {
+  const int L = blockIdx.x, chunk = gridDim.x >> 3;
+  int v = xcd ? (L & 7) * chunk + (L >> 3) : L;
+  if (v >= nxseg * nslab * ny * N) return false;
+  t.xs = v % nxseg; v /= nxseg;
+  t.slab = v % nslab; v /= nslab;
+  t.pc = v % ny;
+  t.n = v / ny;
+  return true;
+}
+
 // ======================================================================================
-// march forward: grid (nslab*nxseg, nphase*nchunk, N), block 256
+// march forward: 1-D grid over (x segment, channel slab, row phase/chunk, image), block 256
 // ======================================================================================
 __global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x, const float *__restrict__ sc,
                                                     const float *__restrict__ sh, int act,
                                                     const float *__restrict__ w, float *__restrict__ y,
                                                     int H, int W, int C, int r, int nchunk, int TK, int nxseg,
-                                                    int nphase, int ppb, float *__restrict__ part) {
+                                                    int nphase, int ppb, int nslab, int ny, int N, int xcd,
+                                                    float *__restrict__ part) {
   __shared__ float red[4 * 8 * 8];
   const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
-  const int xs = blockIdx.x % nxseg, slab = blockIdx.x / nxseg;
-  const int pc = blockIdx.y, n = blockIdx.z;
+  DwTile tile;
+  if (!dw_tile(nxseg, nslab, ny, N, xcd, tile)) return;
+  const int xs = tile.xs, slab = tile.slab, pc = tile.pc, n = tile.n;
   const int c = slab * 32 + cq * 4;
   const int xx = xs * 32 + pl;
   const bool active = (c < C) && (xx < W);
@@ -112,14 +131,18 @@ __global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x,
   // rows are processed in groups of R: all 3*R loads of a group are issued before the first use, so every lane
   // keeps R cache-missing (centre-tap) loads in flight — the kernel is latency-bound otherwise
   constexpr int R = 4;
-  for (int kg = k0 - 1; kg <= k1 && k0 < k1; kg += R) {
+  // input row slots ks..ke: one halo row above / below the chunk only where the phase continues there (a slot
+  // outside the phase is an all-zero row: skipped, the last output row is flushed after the loop instead)
+  const bool bot_halo = k1 < Ka;
+  const int ks = (k0 > 0) ? k0 - 1 : k0, ke = bot_halo ? k1 : k1 - 1;
+  for (int kg = ks; kg <= ke && k0 < k1; kg += R) {
     f32x4 l[R], m[R], rr[R];
 #pragma unroll
-    for (int j = 0; j < R; j++) ldrow((kg + j <= k1) ? kg + j : -1, l[j], m[j], rr[j]);
+    for (int j = 0; j < R; j++) ldrow((kg + j <= ke) ? kg + j : -1, l[j], m[j], rr[j]);
 #pragma unroll
     for (int j = 0; j < R; j++) {
       const int k = kg + j;
-      if (k > k1) break;
+      if (k > ke) break;
       // input row k feeds out[k+1] (tap row 0), out[k] (tap row 1), out[k-1] (tap row 2)
       f32x4 h0 = wv[0] * l[j] + wv[1] * m[j] + wv[2] * rr[j];
       f32x4 h1 = wv[3] * l[j] + wv[4] * m[j] + wv[5] * rr[j];
@@ -134,12 +157,17 @@ __global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x,
       accB = h0;
     }
   }
+  if (!bot_halo && k0 < k1 && active) {  // last row of the phase: no row below contributes
+    st4_nt(ybase + ((size_t)(a + (k1 - 1) * r) * W + xx) * C, accA);
+    s1 += accA;
+    s2 += accA * accA;
+  }
   }  // phases of this workgroup
   if (part) {
     float v[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
     reduce_px<8>(v, red);
     if (tid < 8 && c < C) {
-      const int p = (n * gridDim.y + pc) * nxseg + xs;
+      const int p = (n * ny + pc) * nxseg + xs;
       f32x4 r1 = {v[0], v[1], v[2], v[3]}, r2 = {v[4], v[5], v[6], v[7]};
       write_stat_partial(part, p, C, c, r1, r2);
     }
@@ -155,11 +183,12 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
     const float *__restrict__ sc, const float *__restrict__ sh, int act, const float *__restrict__ w,
     float *__restrict__ dx, const float *__restrict__ dx_add, const float *__restrict__ xmean,
     const float *__restrict__ xinvstd, float *__restrict__ dpart, float *__restrict__ wpart, int H, int W, int C,
-    int r, int nchunk, int TK, int nxseg, int nphase, int ppb) {
+    int r, int nchunk, int TK, int nxseg, int nphase, int ppb, int nslab, int ny, int N, int xcd) {
   __shared__ float red[4 * 8 * 36];
   const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
-  const int xs = blockIdx.x % nxseg, slab = blockIdx.x / nxseg;
-  const int pc = blockIdx.y, n = blockIdx.z;
+  DwTile tile;
+  if (!dw_tile(nxseg, nslab, ny, N, xcd, tile)) return;
+  const int xs = tile.xs, slab = tile.slab, pc = tile.pc, n = tile.n;
   const int c = slab * 32 + cq * 4;
   const int xx = xs * 32 + pl;
   const bool active = (c < C) && (xx < W);
@@ -221,20 +250,23 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
     constexpr int R = 2;
     f32x4 e_prev = splat4(0.f), e_cur, e_next;
     bool ok_prev = false, ok_cur, ok_next;
-    ld_e(k0 - 1, e_cur, ok_cur);
-    ld_e(k0, e_next, ok_next);
-    for (int kg = k0 - 1; kg <= k1; kg += R) {
+    // dY row slots ks..ke (halo slots outside the phase are all-zero rows: skipped, see dw_march_fwd)
+    const bool bot_halo = k1 < Ka;
+    const int ks = (k0 > 0) ? k0 - 1 : k0, ke = bot_halo ? k1 : k1 - 1;
+    ld_e(ks, e_cur, ok_cur);
+    ld_e(ks + 1, e_next, ok_next);
+    for (int kg = ks; kg <= ke; kg += R) {
       f32x4 l[R], m[R], rr[R], e_new[R];
       bool ok_new[R];
 #pragma unroll
       for (int j = 0; j < R; j++) {
-        ld_dd((kg + j <= k1) ? kg + j : -1, l[j], m[j], rr[j]);
+        ld_dd((kg + j <= ke) ? kg + j : -1, l[j], m[j], rr[j]);
         ld_e(kg + j + 2, e_new[j], ok_new[j]);
       }
 #pragma unroll
       for (int j = 0; j < R; j++) {
         const int k = kg + j;
-        if (k > k1) break;
+        if (k > ke) break;
         if (k >= k0 && k < k1) {
           // dW[i][j] += T(x)[k+i-1][x] * dY[k][x-(j-1)r] : j=0 -> right tap, j=2 -> left tap
           f32x4 ea0 = eact(e_prev, ok_prev), ea1 = eact(e_cur, ok_cur), ea2 = eact(e_next, ok_next);
@@ -262,9 +294,17 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
         e_next = e_new[j]; ok_next = ok_new[j];
       }
     }
+    if (!bot_halo && dx && active) {  // last dx row of the phase (e_prev now holds forward input row k1-1)
+      const size_t off = img + ((size_t)(a + (k1 - 1) * r) * W + xx) * C;
+      f32x4 out = accA * dl3_mask4(s * e_prev + t, act);
+      if (dx_add) out += ld4(dx_add + off);
+      st4_nt(dx + off, out);
+      s1 += out;
+      s2 += out * ((e_prev - mu) * is);
+    }
   }
   }  // phases of this workgroup
-  const int p = (n * gridDim.y + pc) * nxseg + xs;
+  const int p = (n * ny + pc) * nxseg + xs;
   {
     float v[36];
 #pragma unroll
@@ -448,6 +488,15 @@ struct DwPlan {
   int P;
 };
 
+unsigned march_grid(const DwPlan &p, int N) {
+  const long total = (long)p.nxseg * p.nslab * p.ny * N;
+  return (unsigned)((total + 7) / 8 * 8);
+}
+int march_xcd() {
+  const char *e = getenv("DL3_DW_XCD");  // 0 = plain workgroup order (tuning aid)
+  return e ? atoi(e) : 1;
+}
+
 bool march_ok(int H, int W, int stride, int rate, int pad_t, int pad_l, int Ho, int Wo) {
   return stride == 1 && pad_t == rate && pad_l == rate && Ho == H && Wo == W;
 }
@@ -531,9 +580,9 @@ extern "C" int dl3_dwconv3x3_fwd(const float *x, const float *in_scale, const fl
   DwPlan p = dw_plan(N, H, W, C, stride, rate, Ho, Wo, im, false);
   hipStream_t st = (hipStream_t)stream;
   if (im == DL3_IMPL_MARCH) {
-    dim3 grid(p.nslab * p.nxseg, p.ny, N);
+    dim3 grid(march_grid(p, N));
     hipLaunchKernelGGL(dw_march_fwd, grid, dim3(256), 0, st, x, in_scale, in_shift, in_act, w, y, H, W, C, rate,
-                       p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, stat_partial);
+                       p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial);
   } else {
     DwGeom G{N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo};
     dim3 grid(p.nslab, p.PB);
@@ -565,10 +614,10 @@ extern "C" int dl3_dwconv3x3_bwd(const float *g, const float *yraw, const float 
   DwPlan p = dw_plan(N, H, W, C, stride, rate, Ho, Wo, im, true);
   hipStream_t st = (hipStream_t)stream;
   if (im == DL3_IMPL_MARCH) {
-    dim3 grid(p.nslab * p.nxseg, p.ny, N);
+    dim3 grid(march_grid(p, N));
     hipLaunchKernelGGL(dw_march_bwd, grid, dim3(256), 0, st, g, yraw, cA, cB, cC, x, in_scale, in_shift, in_act,
                        w, dx, dx_add, x_mean, x_invstd, dstat_partial, dw_partial, H, W, C, rate, p.nchunk, p.TK,
-                       p.nxseg, p.nphase, p.ppb);
+                       p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd());
   } else {
     DwGeom G{N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo};
     dim3 grid(p.nslab, p.PB);
