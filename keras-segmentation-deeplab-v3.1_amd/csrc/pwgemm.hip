@@ -38,6 +38,12 @@ struct GemmArgs {
 };
 
 constexpr int BK = 16;
+#ifndef DL3_STREAM_KMAX
+#define DL3_STREAM_KMAX 2048  // largest reduction depth the stream kernel takes (coefficient vectors in LDS)
+#endif
+#ifndef DL3_STREAM_TAIL
+#define DL3_STREAM_TAIL 2
+#endif
 #ifndef DL3_WGRAD_MS
 #define DL3_WGRAD_MS 16
 #endif
@@ -309,7 +315,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
   constexpr int BM = 128 * TM, BN = 32 * TN, KH = KT / 2, NJ = KT / 8;
   constexpr int LDB = BN;
   constexpr int NB = (KT * BN / 4 + 255) / 256;  // float4 B loads per thread per K-tile
+  constexpr int KC = DL3_STREAM_KMAX + KT;       // per-k operand-transform coefficients live in LDS
   __shared__ float lds[2 * KT * LDB];
+  __shared__ float cf[(TWO ? 3 : 2) * KC];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -326,6 +334,17 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
   float st1[TN], st2[TN];
 #pragma unroll
   for (int i = 0; i < TN; i++) st1[i] = st2[i] = 0.f;
+
+  // T(a)[k] = act(ka[k]*a + kb[k]*a2 + kc[k]); k >= K gets all-zero coefficients, so the clamped (in-bounds) loads
+  // beyond K contribute act(0) = 0
+  for (int i = tid; i < ktiles * KT; i += 256) {
+    const bool in = i < P.K;
+    const int k = min(i, P.K - 1);
+    cf[i] = in ? (xform ? P.ka[k] : 1.f) : 0.f;
+    cf[KC + i] = (in && xform) ? P.kc[k] : 0.f;
+    if (TWO) cf[2 * KC + i] = in ? P.kb[k] : 0.f;
+  }
+  __syncthreads();
 
   for (int mt = by; mt < P.mtiles; mt += gridDim.y) {
     const int m0 = mt * BM;
@@ -375,26 +394,25 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
         if (NB * 256 == KT * BN / 4 || idx < KT * BN / 4) st4(&Bs[(idx / (BN / 4)) * LDB + (idx % (BN / 4)) * 4], rb[i]);
       }
     };
-    // registers of the NEXT K-tile -> transformed operand values of the CURRENT one (zero beyond K)
+    // loaded registers of K-tile kt -> MFMA operand values, in place (an <- T(an))
     auto transform = [&](int kt) {
 #pragma unroll
       for (int j = 0; j < NJ; j++) {
         const int k = kt * KT + KH * lhi + 4 * j;
-        const int kc = min(k, P.K - 4);
-        const float live = (k < P.K) ? 1.f : 0.f;
-        f32x4 fa = splat4(1.f), fb = splat4(0.f), fc = splat4(0.f);
-        if (xform) {
-          fa = ld4(P.ka + kc);
-          fc = ld4(P.kc + kc);
-          if (TWO) fb = ld4(P.kb + kc);
-        }
+        const f32x4 fa = ld4(cf + k), fc = ld4(cf + KC + k);
 #pragma unroll
         for (int i = 0; i < TM; i++) {
           f32x4 v = fa * an[i][j] + fc;
-          if (TWO) v += fb * an2[i][j];
-          ac[i][j] = dl3_act4(v, P.a_act) * splat4(live);
+          if (TWO) v += ld4(cf + 2 * KC + k) * an2[i][j];
+          an[i][j] = dl3_act4(v, P.a_act);
         }
       }
+    };
+    auto adopt = [&]() {
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++) ac[i][j] = an[i][j];
     };
 
     load_A(0);
@@ -402,6 +420,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
     __syncthreads();  // the previous row tile is done with the LDS
     store_B(lds);
     transform(0);
+    adopt();
     __syncthreads();
     for (int kt = 0; kt < ktiles; ++kt) {
       const float *Bs = lds + (kt & 1) * KT * LDB;
@@ -425,11 +444,14 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
 #pragma unroll
           for (int j = 0; j < TN; j++)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[i][s_ >> 2][s_ & 3], bf[cur][j], acc[i][j], 0, 0, 0);
+        // next tile's weight tile -> LDS and operand transform while the last DL3_STREAM_TAIL k-steps' MFMAs are
+        // still to be issued: their VALU / LDS work hides behind the matrix pipe instead of trailing it
+        if (s_ == KH - 1 - DL3_STREAM_TAIL && more) {
+          store_B(lds + ((kt + 1) & 1) * KT * LDB);
+          transform(kt + 1);
+        }
       }
-      if (more) {
-        store_B(lds + ((kt + 1) & 1) * KT * LDB);
-        transform(kt + 1);
-      }
+      if (more) adopt();
       __syncthreads();
     }
 
@@ -789,7 +811,7 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   // (tools/gemm_tune.py).  The two-tensor bwd-data operand uses 16-deep K-tiles so that its register budget does not
   // spill.  DL3_GEMM_IMPL=0 forces the staged kernel (which also serves unaligned operands).
   const int impl = env_int("DL3_GEMM_IMPL");
-  if (vec && impl != 0) {
+  if (vec && impl != 0 && A.K <= DL3_STREAM_KMAX) {
     dim3 blk(256);
 #define DL3_STREAM(TM_, TN_)                                                                              \
   do {                                                                                                    \
