@@ -192,6 +192,24 @@ int dl3_fill(float *p, float value, size_t n, void *stream);
 int dl3_adam_step(float *p, const float *g, float *m, float *v, size_t n, float lr_t, float beta1, float beta2,
                   float eps, float grad_scale, void *stream);
 
+/* ---- either side of the network: targets in, metric counts out -------------------------- */
+#define DL3_LABEL_U8 0  /* cv2.imread(path, 0) label maps (utils.py:314) */
+#define DL3_LABEL_I32 1 /* label.astype('int32') (utils.py:371) */
+/* Tensor contract of SegmentationGenerator.__getitem__ (utils.py:375-402) from raw label maps labels[B][HW]:
+ *   y = label, values > C-1 (and negative ones) -> C ("void")            utils.py:377
+ *   Y[B][HW]  (nullable) = y as float (the [B,HW,1] target of train_on_batch)   utils.py:379
+ *   SW[B][HW] (nullable) = per-image 'balanced' class weight n_valid / (n_present * count[y]) evaluated in double and
+ *                          rounded to float; 0 on void pixels                  utils.py:391-400
+ *   hist[B][C+1] (required, int32) = per-image label histogram (bin C = void), also the scratch of the op.
+ * C <= 255.  Integer counting with int atomics: results are exact and run-to-run identical. */
+int dl3_prepare_targets(const void *labels, int label_dtype, int B, int HW, int C, float *Y, float *SW, int *hist,
+                        void *stream);
+/* Pixel counts behind Jaccard / sparse_accuracy_ignoring_last_label (utils.py:132-157), per image b and class c:
+ *   counts[b][0][c] = #(y_true == c), counts[b][1][c] = #(pred == c), counts[b][2][c] = #(y_true == c && pred == c)
+ * pred = dl3_argmax output (int32), y_true as fed to the loss (float, void = C).  The ratios stay on the host
+ * (utils.Jaccard_from_counts): union = true + pred - inter, exactly the reference's inter/union sums. */
+int dl3_seg_counts(const int *pred, const float *y_true, int B, int HW, int C, int *counts, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,12 +16,15 @@ LIBPATH = os.path.join(_HERE, "libdl3.so")
 
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 IMPL_AUTO, IMPL_GATHER, IMPL_MARCH = 0, 1, 2
+LABEL_U8, LABEL_I32 = 0, 1
 
 _CTYPES = {
     "const float *": ctypes.c_void_p,
     "float *": ctypes.c_void_p,
     "int *": ctypes.c_void_p,
+    "const int *": ctypes.c_void_p,
     "void *": ctypes.c_void_p,
+    "const void *": ctypes.c_void_p,
     "const char *": ctypes.c_char_p,
     "int": ctypes.c_int,
     "float": ctypes.c_float,

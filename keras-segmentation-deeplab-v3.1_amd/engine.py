@@ -634,13 +634,37 @@ class Engine:
         return out.cpu().numpy().reshape(self.B, v.buf.H, v.buf.W)
 
     def set_targets(self, y, sw=None):
+        """labels [B,HW,1] (void = classes) and temporal sample weights [B,HW]; numpy arrays or device tensors (e.g. the
+        output of utils.prepare_targets, which then never leaves the GPU)"""
         M = self.logits_view.buf.M
-        yt = torch.from_numpy(np.ascontiguousarray(np.asarray(y, np.float32).reshape(-1)))
+        if torch.is_tensor(y):
+            yt = y.reshape(-1).to(torch.float32)
+        else:
+            yt = torch.from_numpy(np.ascontiguousarray(np.asarray(y, np.float32).reshape(-1)))
         assert yt.numel() == M, (yt.numel(), M)
-        self.labels.copy_(yt.to(self.device))
+        self.labels.copy_(yt.to(self.device, non_blocking=True))
         if sw is None:
-            sw = (np.asarray(y).reshape(-1) != self.logits_view.C).astype(np.float32)
-        self.sweights.copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(sw, np.float32).reshape(-1))).to(self.device))
+            self.sweights.copy_((self.labels != float(self.logits_view.C)).to(torch.float32))
+        elif torch.is_tensor(sw):
+            self.sweights.copy_(sw.reshape(-1).to(self.device, torch.float32, non_blocking=True))
+        else:
+            self.sweights.copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(sw, np.float32).reshape(-1))).to(self.device))
+
+    def seg_counts(self, y):
+        """after forward(): per-image, per-class pixel counts [B,3,C] of the argmax mask against labels y
+        (dl3_argmax + dl3_seg_counts on the device; utils.Jaccard_from_counts turns them into the metric)"""
+        v = self.logits_view
+        st = torch.cuda.current_stream().cuda_stream
+        pred = torch.empty(v.buf.M, dtype=torch.int32, device=self.device)
+        capi.call("dl3_argmax", ptr(v.buf.t), pred.data_ptr(), v.buf.M, v.C, st)
+        if torch.is_tensor(y):
+            yt = y.reshape(-1).to(self.device, torch.float32)
+        else:
+            yt = torch.from_numpy(np.ascontiguousarray(np.asarray(y, np.float32).reshape(-1))).to(self.device)
+        assert yt.numel() == v.buf.M, (yt.numel(), v.buf.M)
+        counts = torch.empty(self.B, 3, v.C, dtype=torch.int32, device=self.device)
+        capi.call("dl3_seg_counts", pred.data_ptr(), yt.data_ptr(), self.B, v.buf.M // self.B, v.C, counts.data_ptr(), st)
+        return counts.cpu().numpy()
 
     def fwd_bwd(self):
         """forward + loss + backward on the resident batch (the benchmarked hot path)"""

@@ -486,6 +486,33 @@ class Model:
             outs.append(eng.predict(xb))
         return np.concatenate(outs, axis=0)
 
+    def evaluate(self, x, y, batch_size=32, sample_weight=None, verbose=0):
+        """keras Model.evaluate for the notebook's metrics (cell 2: metrics=[Jaccard, sparse_accuracy_ignoring_last_label]):
+        returns [loss, Jaccard, accuracy].  The argmax mask and the per-image/per-class pixel counts are produced on
+        the device (dl3_argmax, dl3_seg_counts); the metric ratios (utils.py:132-157) and the loss (utils.py:127-130,
+        Keras weighted mean) are evaluated on the host from those counts / the probabilities."""
+        from . import utils as U
+        x = np.asarray(x, np.float32) if not hasattr(x, "data_ptr") else x
+        y = np.asarray(y)
+        n = x.shape[0]
+        bs = min(int(batch_size), n)
+        counts, num, den = [], 0.0, 0.0
+        for i in range(0, n, bs):
+            xb, yb = x[i:i + bs], y[i:i + bs]
+            eng = self._engine(xb.shape[0], False)
+            probs = eng.predict(xb)
+            counts.append(eng.seg_counts(yb))
+            C = probs.shape[-1]
+            probs = probs.reshape(xb.shape[0], -1, C)
+            yb = yb.reshape(xb.shape[0], -1, 1)
+            w = (yb[:, :, 0] != C).astype(np.float64) if sample_weight is None else \
+                np.asarray(sample_weight[i:i + bs], np.float64).reshape(xb.shape[0], -1)
+            ell = U.sparse_crossentropy_ignoring_last_label(yb, probs)
+            num += float((ell * w).sum() / max((w != 0).mean(), 1e-30) / w.size) * xb.shape[0]
+            den += xb.shape[0]
+        counts = np.concatenate(counts, 0)
+        return [num / den, U.Jaccard_from_counts(counts), U.accuracy_from_counts(counts)]
+
     def train_on_batch(self, x, y, sample_weight=None, **engine_kw):
         eng = self._engine(x.shape[0], True, **engine_kw)
         opt = (self._compiled or {}).get("optimizer") or {}

@@ -3,7 +3,9 @@
 `sparse_crossentropy_ignoring_last_label` (utils.py:127-130) — executed on the GPU by
 dl3_softmax_xent — and host restatements of the metrics that the north star leaves on the host
 (`Jaccard` utils.py:139-157, `sparse_accuracy_ignoring_last_label` utils.py:132-138).
-Out of scope by the SURVEY §8 contract: SegmentationGenerator, do_crf, plotting.
+Next-ring rows of SURVEY §8(f): `prepare_targets` (N2, the label half of SegmentationGenerator.__getitem__ on the
+device) and `Jaccard_from_counts` / `accuracy_from_counts` (N3, metrics from dl3_seg_counts).
+Out of scope by the SURVEY §8 contract: image file I/O + cv2 augmentation, do_crf, plotting.
 """
 import numpy as np
 
@@ -53,6 +55,48 @@ def Jaccard(y_true, y_pred):
             union = (tl | pl).sum(axis=1)[legal]
             ious.append(float(np.mean(inter / union)))
     return float(np.mean(ious)) if ious else float("nan")
+
+
+def Jaccard_from_counts(counts):
+    """`Jaccard` (utils.py:139-157) from the integer counts of dl3_seg_counts, counts[B][3][C] =
+    (#true==c, #pred==c, #both): union = true + pred - inter; same float64 ratios and means as `Jaccard`."""
+    counts = np.asarray(counts, np.int64)
+    t, p, inter = counts[:, 0], counts[:, 1], counts[:, 2]
+    ious = []
+    for i in range(counts.shape[2]):
+        legal = t[:, i] > 0
+        if legal.any():
+            union = (t[:, i] + p[:, i] - inter[:, i])[legal]
+            ious.append(float(np.mean(inter[:, i][legal] / union)))
+    return float(np.mean(ious)) if ious else float("nan")
+
+
+def accuracy_from_counts(counts):
+    """`sparse_accuracy_ignoring_last_label` (utils.py:132-138) from dl3_seg_counts output."""
+    counts = np.asarray(counts, np.int64)
+    return float(counts[:, 2].sum() / max(counts[:, 0].sum(), 1))
+
+
+def prepare_targets(labels, n_classes=21):
+    """Device-side label half of SegmentationGenerator.__getitem__ (utils.py:375-402): raw label maps
+    [B,H,W] or [B,HW] (uint8 / int32; numpy array or cuda tensor) -> (Y [B,HW,1], SW [B,HW]) cuda float32 tensors, ready
+    for `Model.train_on_batch(X, Y, SW)`.  Runs dl3_prepare_targets; raises if libdl3.so is missing."""
+    import torch
+    from . import capi
+    if isinstance(labels, np.ndarray):
+        if labels.dtype not in (np.uint8, np.int32):
+            labels = labels.astype(np.int32)
+        labels = torch.from_numpy(np.ascontiguousarray(labels)).cuda()
+    if labels.dtype not in (torch.uint8, torch.int32):
+        labels = labels.to(torch.int32)
+    labels = labels.contiguous().reshape(labels.shape[0], -1)
+    B, HW = labels.shape
+    Y = torch.empty(B, HW, 1, device=labels.device, dtype=torch.float32)
+    SW = torch.empty(B, HW, device=labels.device, dtype=torch.float32)
+    hist = torch.empty(B, n_classes + 1, device=labels.device, dtype=torch.int32)
+    capi.call("dl3_prepare_targets", capi.ptr(labels), capi.LABEL_U8 if labels.dtype == torch.uint8 else capi.LABEL_I32,
+              B, HW, n_classes, capi.ptr(Y), capi.ptr(SW), capi.ptr(hist), torch.cuda.current_stream().cuda_stream)
+    return Y, SW
 
 
 class SegModel:

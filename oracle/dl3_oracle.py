@@ -706,3 +706,51 @@ def jaccard(labels, probs):
         if legal.any():
             ious.append(float(np.mean(inter[legal] / union[legal])))
     return float(np.mean(ious)) if ious else float("nan")
+
+
+# ---------------------------------------------------------------------------------------
+# either side of the network
+# ---------------------------------------------------------------------------------------
+def balanced_class_weights(y):
+    """sklearn.utils.class_weight.compute_class_weight('balanced', np.unique(y), y) restated (the reference calls it at
+    utils.py:393-395; scikit-learn is un-pinned there): n_samples / (n_classes_present * bincount), float64."""
+    y = np.asarray(y)
+    classes, counts = np.unique(y, return_counts=True)
+    return classes, len(y) / (len(classes) * counts.astype(np.float64))
+
+
+def prepare_targets(labels, n_classes):
+    """The label half of SegmentationGenerator.__getitem__ (utils.py:371-400) for a batch of raw label maps
+    labels[B][HW] (any integer dtype): returns Y [B,HW,1] float32, SW [B,HW] float32 and the per-image histogram
+    [B, n_classes+1] int32.  (The relabelling of interpolation artefacts at utils.py:372-373 belongs to the
+    augmentation, which is out of scope.)"""
+    labels = np.asarray(labels)
+    B, HW = labels.shape
+    Y = np.zeros((B, HW, 1), np.float32)
+    SW = np.zeros((B, HW), np.float32)
+    hist = np.zeros((B, n_classes + 1), np.int32)
+    for n in range(B):
+        y = labels[n].astype(np.int32).copy()
+        y[(y > n_classes - 1) | (y < 0)] = n_classes                      # utils.py:377
+        Y[n] = y[:, None]                                                 # utils.py:379
+        hist[n] = np.bincount(y, minlength=n_classes + 1)
+        filt_y = y[y != n_classes]                                        # utils.py:391
+        if len(filt_y):
+            classes, w = balanced_class_weights(filt_y)                   # utils.py:392-395
+            for c, wc in zip(classes, w):
+                np.putmask(SW[n], y == c, wc)                             # utils.py:397-398 (float64 -> float32)
+        np.putmask(SW[n], y == n_classes, 0)                              # utils.py:400
+    return Y, SW, hist
+
+
+def seg_counts(pred, y_true, n_classes):
+    """Per-image, per-class pixel counts of utils.py:143-148: [B,3,C] = #(true==c), #(pred==c), #(true==c & pred==c)."""
+    pred = np.asarray(pred).reshape(len(pred), -1)
+    t = np.asarray(y_true).reshape(len(pred), -1).astype(np.int64)
+    out = np.zeros((len(pred), 3, n_classes), np.int32)
+    for c in range(n_classes):
+        tl, pl = t == c, pred == c
+        out[:, 0, c] = tl.sum(1)
+        out[:, 1, c] = pl.sum(1)
+        out[:, 2, c] = (tl & pl).sum(1)
+    return out

@@ -243,3 +243,31 @@ def test_full_size_properties():
     model.predict(x2, batch_size=2)
     l2 = model._active.logits()
     assert np.array_equal(l1[0], l2[0]) and not np.array_equal(l1[1], l2[1])
+
+
+def test_device_targets_and_evaluate():
+    """N2 / N3 around the path: targets prepared on the device (utils.prepare_targets = dl3_prepare_targets) drive the
+    same training step as the host-prepared ones, and Model.evaluate's device-counted metrics equal the reference's
+    host metric definitions evaluated on the predicted probabilities."""
+    from dl3_amd import utils as U
+    C = 3
+    rng = np.random.default_rng(11)
+    x = rng.integers(0, 256, (2, 64, 64, 3)).astype(np.float32)
+    raw = rng.choice([0, 1, 2, 255], (2, 64, 64), p=[0.6, 0.25, 0.1, 0.05]).astype(np.uint8)
+    Yh, SWh, _ = O.prepare_targets(raw.reshape(2, -1), C)
+    Yd, SWd = U.prepare_targets(raw, C)
+    assert np.array_equal(Yd.cpu().numpy(), Yh) and np.array_equal(SWd.cpu().numpy(), SWh)
+    losses = []
+    for tgt in ((Yh, SWh), (Yd, SWd)):
+        model, params = _build(input_shape=(64, 64, 3), classes=C)
+        _load(model, params)
+        model.compile(optimizer=dict(lr=7e-4, epsilon=1e-8, decay=1e-6))
+        losses.append([model.train_on_batch(x, *tgt) for _ in range(3)])
+    assert losses[0] == losses[1], losses
+    loss, jac, acc = model.evaluate(x, Yh, batch_size=2)
+    probs = model.predict(x, batch_size=2)
+    assert jac == U.Jaccard(Yh, probs) and acc == U.sparse_accuracy_ignoring_last_label(Yh, probs)
+    ell = U.sparse_crossentropy_ignoring_last_label(Yh, probs)
+    w = (Yh[:, :, 0] != C).astype(np.float64)
+    assert abs(loss - (ell * w).sum() / (w != 0).mean() / w.size) < 1e-12
+    assert 0.0 <= jac <= 1.0 and 0.0 <= acc <= 1.0

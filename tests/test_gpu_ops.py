@@ -560,3 +560,75 @@ def test_error_reporting(L):
     x = empty(16, 6)
     rc = L.dl3_dwconv3x3_fwd(ptr(x), None, None, 0, ptr(x), ptr(x), 1, 4, 4, 6, 1, 1, 1, 1, 4, 4, None, 0, stream())
     assert rc == -4
+
+
+# ---------------------------------------------------------------------------------------
+# either side of the network: dl3_prepare_targets (utils.py:375-402), dl3_seg_counts (utils.py:132-157) — bit-exact
+# ---------------------------------------------------------------------------------------
+def _label_batch(rng, B, HW, C, dtype):
+    lab = rng.integers(0, C, (B, HW)).astype(np.int64)
+    lab[rng.random((B, HW)) < 0.1] = 255                    # VOC void
+    if B > 1:
+        lab[1] = 255                                        # an image with no valid pixel
+    if B > 2:
+        lab[2] = 3                                          # a single class
+        lab[2, : HW // 7] = C + 2                           # labels above C-1 are void too
+    if B > 3:
+        lab[3] = rng.choice([0, 5, C - 1], HW, p=[0.9, 0.09, 0.01])  # strongly unbalanced
+    return lab.astype(dtype)
+
+
+@pytest.mark.parametrize("B,HW,C,dtype", [(4, 1000, 21, np.uint8), (5, 64 * 64, 21, np.int32), (2, 7, 2, np.uint8),
+                                          (3, 512 * 512, 21, np.uint8), (1, 300, 255, np.int32)])
+def test_prepare_targets_bit_exact(L, B, HW, C, dtype):
+    from dl3_amd import capi
+    rng = np.random.default_rng(B * 1000 + HW)
+    lab = _label_batch(rng, B, HW, C, dtype)
+    if dtype == np.int32 and B > 4:
+        lab[4, ::3] = -7                                    # negative labels (int32 only) count as void
+    Yr, SWr, Hr = O.prepare_targets(lab, C)
+    t = torch.from_numpy(lab).cuda()
+    Y, SW = empty(B, HW), empty(B, HW)
+    hist = torch.full((B, C + 1), -1, dtype=torch.int32, device="cuda")
+    call("dl3_prepare_targets", t.data_ptr(), capi.LABEL_U8 if dtype == np.uint8 else capi.LABEL_I32, B, HW, C, ptr(Y),
+         ptr(SW), hist.data_ptr())
+    assert np.array_equal(host(hist), Hr)
+    assert np.array_equal(host(Y), Yr[:, :, 0])
+    assert np.array_equal(host(SW).view(np.uint32), SWr.view(np.uint32))    # same float32 bits
+    # histogram only (Y == SW == NULL)
+    hist.fill_(-1)
+    call("dl3_prepare_targets", t.data_ptr(), capi.LABEL_U8 if dtype == np.uint8 else capi.LABEL_I32, B, HW, C, None,
+         None, hist.data_ptr())
+    assert np.array_equal(host(hist), Hr)
+
+
+def test_prepare_targets_rejects_bad_arguments(L):
+    from dl3_amd import capi
+    t = torch.zeros(4, dtype=torch.uint8, device="cuda")
+    h = torch.zeros(400, dtype=torch.int32, device="cuda")
+    assert L.dl3_prepare_targets(t.data_ptr(), 0, 1, 4, 256, None, None, h.data_ptr(), stream()) == -1
+    assert b"classes" in L.dl3_last_error()
+    assert L.dl3_prepare_targets(t.data_ptr(), 7, 1, 4, 21, None, None, h.data_ptr(), stream()) == -1
+    assert L.dl3_prepare_targets(None, 0, 1, 4, 21, None, None, h.data_ptr(), stream()) == -1
+    with pytest.raises(capi.DL3Error):
+        call("dl3_seg_counts", None, None, 1, 4, 21, h.data_ptr())
+
+
+@pytest.mark.parametrize("B,HW,C", [(3, 1000, 21), (2, 512 * 512, 21), (4, 33, 2)])
+def test_seg_counts_and_metrics_bit_exact(L, B, HW, C):
+    from dl3_amd import utils as U
+    rng = np.random.default_rng(HW)
+    yt = rng.integers(0, C + 1, (B, HW)).astype(np.float32)                 # C = void
+    yt[0][yt[0] == 1] = 0                                                   # class 1 absent from image 0
+    probs = rng.random((B, HW, C)).astype(np.float32)
+    pred = probs.argmax(-1).astype(np.int32)
+    ref = O.seg_counts(pred, yt, C)
+    counts = torch.full((B, 3, C), -1, dtype=torch.int32, device="cuda")
+    pt = torch.from_numpy(pred).cuda()
+    call("dl3_seg_counts", pt.data_ptr(), ptr(dev(yt)), B, HW, C, counts.data_ptr())
+    got = host(counts)
+    assert np.array_equal(got, ref)
+    # the metric ratios computed from the device counts are the host metrics of the reference, to the last bit
+    assert U.Jaccard_from_counts(got) == U.Jaccard(yt[:, :, None], probs)
+    assert U.accuracy_from_counts(got) == U.sparse_accuracy_ignoring_last_label(yt[:, :, None], probs)
+    assert U.Jaccard_from_counts(got) == O.jaccard(yt, probs)

@@ -203,3 +203,54 @@ def test_golden_cfg1_model():
     for k in list(params)[:40]:
         if "/moving_" in k:
             assert np.allclose(params[k], g["bn:" + k], rtol=1e-4, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------
+# either side of the network
+# ---------------------------------------------------------------------------------------
+def test_balanced_class_weights_against_scikit_learn():
+    """the reference calls sklearn's compute_class_weight('balanced', ...) (utils.py:393-395): when scikit-learn is
+    importable the restatement is checked against the real dependency, otherwise against the published formula"""
+    rng = np.random.default_rng(0)
+    y = rng.choice([0, 3, 7, 20], 5000, p=[0.7, 0.2, 0.09, 0.01])
+    classes, w = O.balanced_class_weights(y)
+    assert list(classes) == [0, 3, 7, 20]
+    assert np.array_equal(w, 5000 / (4 * np.bincount(y)[[0, 3, 7, 20]].astype(np.float64)))
+    try:
+        from sklearn.utils import class_weight
+    except Exception:  # pragma: no cover
+        pytest.skip("scikit-learn not importable")
+    ref = class_weight.compute_class_weight("balanced", classes=np.unique(y), y=y)
+    assert np.array_equal(w, ref)
+
+
+def test_prepare_targets_known_answers():
+    lab = np.array([[0, 0, 0, 1, 255, 30, 1, 0],      # classes {0:4, 1:2}, void 2
+                    [255] * 8,                         # no valid pixel
+                    [2] * 8], np.uint8)                # one class
+    Y, SW, hist = O.prepare_targets(lab, 21)
+    assert Y.shape == (3, 8, 1) and SW.shape == (3, 8) and Y.dtype == np.float32 and SW.dtype == np.float32
+    assert Y[0, :, 0].tolist() == [0, 0, 0, 1, 21, 21, 1, 0]
+    # n_valid / (n_present * count): 6/(2*4) = .75 for class 0, 6/(2*2) = 1.5 for class 1, 0 on void
+    assert SW[0].tolist() == [0.75, 0.75, 0.75, 1.5, 0.0, 0.0, 1.5, 0.75]
+    assert not SW[1].any() and (Y[1] == 21).all()
+    assert (SW[2] == 1.0).all()
+    assert hist[0, 0] == 4 and hist[0, 1] == 2 and hist[0, 21] == 2 and hist[1, 21] == 8 and hist[2, 2] == 8
+
+
+def test_seg_counts_reproduce_the_metrics():
+    import dl3_amd  # noqa: F401
+    from dl3_amd import utils as U
+    rng = np.random.default_rng(3)
+    B, HW, C = 4, 500, 5
+    yt = rng.integers(0, C + 1, (B, HW)).astype(np.float32)
+    yt[1][yt[1] == 2] = 0
+    probs = rng.random((B, HW, C)).astype(np.float32)
+    counts = O.seg_counts(probs.argmax(-1), yt, C)
+    assert counts.shape == (B, 3, C)
+    assert U.Jaccard_from_counts(counts) == U.Jaccard(yt[:, :, None], probs) == O.jaccard(yt, probs)
+    assert U.accuracy_from_counts(counts) == U.sparse_accuracy_ignoring_last_label(yt[:, :, None], probs)
+    # hand case: one image, two classes
+    c = O.seg_counts(np.array([[0, 0, 1, 1]]), np.array([[0, 1, 1, 2]], np.float32), 2)
+    assert c.tolist() == [[[1, 2], [2, 2], [1, 1]]]
+    assert U.Jaccard_from_counts(c) == (1 / 2 + 1 / 3) / 2
