@@ -223,6 +223,93 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// MFMA route for a dense 3x3 conv with many input channels (xception entry_flow_conv1_2: 32 -> 64 at 256x256,
+// 1.2 GMAC / image, deeplabv3p.py:289): im2col -> the 1x1-conv GEMM kernels -> col2im.  The column matrix
+// [N*Ho*Wo][9*Cin] costs one extra write + read of 9x the input, which the matrix pipe wins back ~10x over.
+// ---------------------------------------------------------------------------------------
+// col[m][(i*3+j)*Cin + c] = T(x)[n, oy*stride-pad_t+i, ox*stride-pad_l+j, c] (0 outside the image).
+// thread = one float4 of one (output pixel, tap); consecutive threads walk the row of the column matrix.
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const float *__restrict__ x, const float *__restrict__ sc,
+                                                        const float *__restrict__ sh, int act,
+                                                        float *__restrict__ col, CGeom G) {
+  const int CQ = G.Cin / 4, RQ = 9 * CQ;
+  const long total = (long)G.N * G.Ho * G.Wo * RQ;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int q = (int)(idx % RQ);
+    const long m = idx / RQ;
+    const int tap = q / CQ, c = (q % CQ) * 4;
+    const int ox = (int)(m % G.Wo), oy = (int)((m / G.Wo) % G.Ho), n = (int)(m / ((long)G.Wo * G.Ho));
+    const int iy = oy * G.stride - G.pad_t + tap / 3, ix = ox * G.stride - G.pad_l + tap % 3;
+    const int iyc = min(max(iy, 0), G.H - 1), ixc = min(max(ix, 0), G.W - 1);
+    const float live = (iy == iyc && ix == ixc) ? 1.f : 0.f;
+    f32x4 v = ld4(x + (((size_t)n * G.H + iyc) * G.W + ixc) * G.Cin + c);
+    if (sc) v = ld4(sc + c) * v + ld4(sh + c);
+    v = dl3_act4(v, act) * splat4(live);
+    st4_nt(col + (size_t)idx * 4, v);
+  }
+}
+
+// dx[n,iy,ix,c] = mask(x) * sum over the taps (i,j) whose output pixel exists of dcol[(n,oy,ox)][(i*3+j)*Cin + c]
+// (+ dx_add); deterministic gather form of the transposed im2col.  Same epilogue / partial layout as the direct
+// bwd-data kernel: thread = (input pixel, 4 input channels).
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const float *__restrict__ dcol, float *__restrict__ dx,
+                                                        const float *__restrict__ x, const float *__restrict__ sc,
+                                                        const float *__restrict__ sh, int act,
+                                                        const float *__restrict__ dx_add,
+                                                        const float *__restrict__ xmean,
+                                                        const float *__restrict__ xinvstd, float *__restrict__ part,
+                                                        CGeom G) {
+  __shared__ float red[256 * 8];
+  const int CQ = G.Cin / 4;
+  const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ, PL = 256 / CQ;
+  const int ci = cq * 4;
+  f32x4 s = splat4(1.f), t = splat4(0.f), mu = splat4(0.f), is = splat4(0.f);
+  if (sc) { s = ld4(sc + ci); t = ld4(sh + ci); }
+  if (part) { mu = ld4(xmean + ci); is = ld4(xinvstd + ci); }
+  f32x4 s1 = splat4(0.f), s2 = splat4(0.f);
+  const long NP = (long)G.N * G.H * G.W;
+  const size_t ldc = (size_t)9 * G.Cin;
+  for (long p = (long)blockIdx.x * PL + pl; p < NP; p += (long)gridDim.x * PL) {
+    const int ix = (int)(p % G.W), iy = (int)((p / G.W) % G.H), n = (int)(p / ((long)G.W * G.H));
+    f32x4 acc = splat4(0.f);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int ty = iy + G.pad_t - i;
+      const int oy = ty / G.stride;
+      const bool yok = ty >= 0 && (ty % G.stride) == 0 && oy < G.Ho;
+      const int oyc = min(max(oy, 0), G.Ho - 1);
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int tx = ix + G.pad_l - j;
+        const int ox = tx / G.stride;
+        const bool ok = yok && tx >= 0 && (tx % G.stride) == 0 && ox < G.Wo;
+        const int oxc = min(max(ox, 0), G.Wo - 1);
+        const f32x4 v = ld4(dcol + (((size_t)n * G.Ho + oyc) * G.Wo + oxc) * ldc + (i * 3 + j) * G.Cin + ci);
+        acc += v * splat4(ok ? 1.f : 0.f);
+      }
+    }
+    f32x4 out = acc, xr = splat4(0.f);
+    if (x) {
+      xr = ld4(x + (size_t)p * G.Cin + ci);
+      out = out * dl3_mask4(s * xr + t, act);
+    }
+    if (dx_add) out += ld4(dx_add + (size_t)p * G.Cin + ci);
+    st4(dx + (size_t)p * G.Cin + ci, out);
+    s1 += out;
+    s2 += out * ((xr - mu) * is);
+  }
+  if (part) {
+    float v[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
+    reduce_over_pixels<8>(v, red, CQ);
+    if ((int)threadIdx.x < CQ) {
+      float *d = part + ((size_t)blockIdx.x * G.Cin + ci) * 2;
+      d[0] = v[0]; d[1] = v[4]; d[2] = v[1]; d[3] = v[5];
+      d[4] = v[2]; d[5] = v[6]; d[6] = v[3]; d[7] = v[7];
+    }
+  }
+}
+
 int conv_blocks(long NP) {
   long b = (NP + 31) / 32;
   if (b > 2048) b = 2048;
@@ -294,5 +381,105 @@ extern "C" int dl3_conv3x3_bwd_data(const float *g, const float *yraw, const flo
   hipLaunchKernelGGL(conv3x3_dgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, yraw, cA, cB, cC, w,
                      dx, x, in_scale, in_shift, in_act, dx_add, x_mean, x_invstd, dstat_partial, G);
   DL3_LAUNCH_CHECK("conv3x3_bwd_data");
+  return DL3_OK;
+}
+
+// ---- MFMA route (im2col + the pointwise GEMM kernels) -----------------------------------
+namespace {
+size_t col_bytes(int N, int Ho, int Wo, int Cin) { return (size_t)N * Ho * Wo * 9 * Cin * sizeof(float); }
+size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+int gemm_check(const char *name, const CGeom &G) {
+  DL3_CHECK_ARG(G.N > 0 && G.H > 0 && G.W > 0 && G.Cin > 0 && G.Cout > 0 && G.Ho > 0 && G.Wo > 0 && G.stride >= 1,
+                "%s: bad dimension", name);
+  DL3_UNSUPPORTED(G.Cin % 4 != 0 || 256 % (G.Cin / 4) != 0 || G.Cout % 4 != 0,
+                  "%s: needs Cin = 4*(a divisor of 256) and Cout %% 4 == 0 (got %d, %d)", name, G.Cin, G.Cout);
+  DL3_UNSUPPORTED((long)G.N * G.Ho * G.Wo * 9 * G.Cin >= (1l << 31) * 4, "%s: column matrix too large", name);
+  return DL3_OK;
+}
+int im2col_blocks(long total) {
+  long b = (total + 255) / 256;
+  return (int)(b > 16384 ? 16384 : b);
+}
+}  // namespace
+
+extern "C" size_t dl3_conv3x3_gemm_workspace(int N, int H, int W, int Cin, int Cout, int stride, int Ho, int Wo) {
+  (void)H; (void)W; (void)stride;
+  if (N <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  return align256(col_bytes(N, Ho, Wo, Cin)) + dl3_pwconv_bwd_weight_workspace(N * Ho * Wo, 9 * Cin, Cout);
+}
+
+extern "C" int dl3_conv3x3_gemm_fwd(const float *x, const float *in_scale, const float *in_shift, int in_act,
+                                    const float *w, float *y, int N, int H, int W, int Cin, int Cout, int stride,
+                                    int pad_t, int pad_l, int Ho, int Wo, float *stat_partial, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
+  CGeom G{N, H, W, Cin, Cout, stride, pad_t, pad_l, Ho, Wo};
+  int rc = gemm_check("conv3x3_gemm_fwd", G);
+  if (rc) return rc;
+  DL3_CHECK_ARG(x && w && y && workspace, "conv3x3_gemm_fwd: null pointer");
+  DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "conv3x3_gemm_fwd: scale/shift must come together");
+  if (workspace_bytes < col_bytes(N, Ho, Wo, Cin)) {
+    dl3_set_error("conv3x3_gemm_fwd: workspace %zu < %zu bytes", workspace_bytes, col_bytes(N, Ho, Wo, Cin));
+    return DL3_EWORKSPACE;
+  }
+  float *col = (float *)workspace;
+  const long M = (long)N * Ho * Wo;
+  hipLaunchKernelGGL(im2col3x3_kernel, dim3(im2col_blocks(M * 9 * (Cin / 4))), dim3(256), 0, (hipStream_t)stream, x,
+                     in_scale, in_shift, in_act, col, G);
+  DL3_LAUNCH_CHECK("conv3x3_gemm_fwd(im2col)");
+  return dl3_pwconv_fwd(col, 9 * Cin, nullptr, nullptr, DL3_ACT_NONE, w, nullptr, y, Cout, (int)M, 9 * Cin, Cout,
+                        stat_partial, stream);
+}
+
+extern "C" int dl3_conv3x3_gemm_bwd_weight(const float *x, const float *in_scale, const float *in_shift, int in_act,
+                                           const float *g, const float *yraw, const float *cA, const float *cB,
+                                           const float *cC, float *dw, int N, int H, int W, int Cin, int Cout,
+                                           int stride, int pad_t, int pad_l, int Ho, int Wo, void *workspace,
+                                           size_t workspace_bytes, void *stream) {
+  CGeom G{N, H, W, Cin, Cout, stride, pad_t, pad_l, Ho, Wo};
+  int rc = gemm_check("conv3x3_gemm_bwd_weight", G);
+  if (rc) return rc;
+  DL3_CHECK_ARG(x && g && dw && workspace, "conv3x3_gemm_bwd_weight: null pointer");
+  DL3_CHECK_ARG(!cA || (yraw && cB && cC), "conv3x3_gemm_bwd_weight: cA needs yraw, cB, cC");
+  const size_t need = dl3_conv3x3_gemm_workspace(N, H, W, Cin, Cout, stride, Ho, Wo);
+  if (workspace_bytes < need) {
+    dl3_set_error("conv3x3_gemm_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);
+    return DL3_EWORKSPACE;
+  }
+  float *col = (float *)workspace;
+  const size_t cb = align256(col_bytes(N, Ho, Wo, Cin));
+  const long M = (long)N * Ho * Wo;
+  hipLaunchKernelGGL(im2col3x3_kernel, dim3(im2col_blocks(M * 9 * (Cin / 4))), dim3(256), 0, (hipStream_t)stream, x,
+                     in_scale, in_shift, in_act, col, G);
+  DL3_LAUNCH_CHECK("conv3x3_gemm_bwd_weight(im2col)");
+  return dl3_pwconv_bwd_weight(col, 9 * Cin, nullptr, nullptr, DL3_ACT_NONE, g, Cout, yraw, Cout, cA, cB, cC, dw,
+                               nullptr, (int)M, 9 * Cin, Cout, (char *)workspace + cb, workspace_bytes - cb, stream);
+}
+
+extern "C" int dl3_conv3x3_gemm_bwd_data(const float *g, const float *yraw, const float *cA, const float *cB,
+                                         const float *cC, const float *wT, float *dx, const float *x,
+                                         const float *in_scale, const float *in_shift, int in_act,
+                                         const float *dx_add, const float *x_mean, const float *x_invstd,
+                                         float *dstat_partial, int N, int H, int W, int Cin, int Cout, int stride,
+                                         int pad_t, int pad_l, int Ho, int Wo, void *workspace,
+                                         size_t workspace_bytes, void *stream) {
+  CGeom G{N, H, W, Cin, Cout, stride, pad_t, pad_l, Ho, Wo};
+  int rc = gemm_check("conv3x3_gemm_bwd_data", G);
+  if (rc) return rc;
+  DL3_CHECK_ARG(g && wT && dx && workspace, "conv3x3_gemm_bwd_data: null pointer");
+  DL3_CHECK_ARG(!cA || (yraw && cB && cC), "conv3x3_gemm_bwd_data: cA needs yraw, cB, cC");
+  DL3_CHECK_ARG(in_act == DL3_ACT_NONE || x, "conv3x3_gemm_bwd_data: activation mask needs x");
+  DL3_CHECK_ARG(!dstat_partial || (x && x_mean && x_invstd), "conv3x3_gemm_bwd_data: dstat needs x, x_mean, x_invstd");
+  if (workspace_bytes < col_bytes(N, Ho, Wo, Cin)) {
+    dl3_set_error("conv3x3_gemm_bwd_data: workspace %zu < %zu bytes", workspace_bytes, col_bytes(N, Ho, Wo, Cin));
+    return DL3_EWORKSPACE;
+  }
+  float *dcol = (float *)workspace;
+  const long M = (long)N * Ho * Wo;
+  rc = dl3_pwconv_bwd_data(g, Cout, yraw, Cout, cA, cB, cC, wT, dcol, 9 * Cin, nullptr, 0, nullptr, nullptr,
+                           DL3_ACT_NONE, nullptr, 0, 1, 1.f, nullptr, nullptr, nullptr, (int)M, 9 * Cin, Cout, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(col2im3x3_kernel, dim3(conv_blocks((long)N * H * W)), dim3(256), 0, (hipStream_t)stream, dcol, dx,
+                     x, in_scale, in_shift, in_act, dx_add, x_mean, x_invstd, dstat_partial, G);
+  DL3_LAUNCH_CHECK("conv3x3_gemm_bwd_data(col2im)");
   return DL3_OK;
 }

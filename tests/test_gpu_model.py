@@ -175,9 +175,12 @@ def test_xception_train_step_gradients(OS):
                                               sw.astype(np.float64), **kw)
     assert relerr(eng.logits(), logits) < 1e-3
     assert abs(float(eng.loss[0].item()) - loss) < 1e-4 * abs(loss)
+    # yardstick for the deep, ill-conditioned tensors: the fp32 run of the ORACLE itself against its float64 run
+    _, grads32, _, _ = O.train_grads(params, x, labels, sw, **kw)
     for name in ("decoder_conv1_pointwise/kernel:0", "aspp3_depthwise/depthwise_kernel:0", "feature_projection0/kernel:0",
                  "exit_flow_block1_shortcut/kernel:0", "middle_flow_unit_8_separable_conv2_pointwise/kernel:0"):
-        assert _l2(eng.grad_of(name), grads[name]) < 2e-2, name
+        tol_g = max(2e-2, 2.0 * _l2(grads32[name], grads[name]))
+        assert _l2(eng.grad_of(name), grads[name]) < tol_g, (name, tol_g)
     num = den = 0.0
     for name, g in grads.items():
         if g is None or "/moving_" in name or np.abs(g).max() < 1e-6:

@@ -562,6 +562,67 @@ def test_error_reporting(L):
     assert rc == -4
 
 
+
+@pytest.mark.parametrize("shape", [(2, 24, 20, 32, 64, 1), (1, 17, 19, 16, 24, 2), (2, 16, 16, 8, 32, 1)])
+def test_conv3x3_gemm_route(L, shape):
+    """dense 3x3 conv through im2col + the MFMA GEMM kernels + col2im (xception entry_flow_conv1_2)"""
+    N, H, W, Cin, Cout, stride = shape
+    rng = np.random.default_rng(16)
+    Ho, pt, _ = O.same_pads(H, 3, stride, 1)
+    Wo, pl, _ = O.same_pads(W, 3, stride, 1)
+    M = N * Ho * Wo
+    x = rng.normal(0, 1, (N, H, W, Cin)).astype(np.float32)
+    w = rng.normal(0, 0.2, (3, 3, Cin, Cout)).astype(np.float32)
+    s = rng.uniform(0.5, 1.5, Cin).astype(np.float32)
+    t = rng.normal(0, 0.5, Cin).astype(np.float32)
+    z = s * x.astype(np.float64) + t
+    xin = np.maximum(z, 0)
+    tape = O.Tape()
+    wv = w.astype(np.float64)
+    ref = O.conv2d(xin, wv, stride, pt, pl, Ho, Wo, tape=tape)
+    wsb = L.dl3_conv3x3_gemm_workspace(N, H, W, Cin, Cout, stride, Ho, Wo)
+    ws = empty((wsb + 3) // 4)
+    P = L.dl3_pwconv_partials(M, 9 * Cin, Cout)
+    y, part = empty(N, Ho, Wo, Cout), empty(P, Cout, 2)
+    xd, sd, td, wd = dev(x), dev(s), dev(t), dev(w)
+    geom = (N, H, W, Cin, Cout, stride, pt, pl, Ho, Wo)
+    call("dl3_conv3x3_gemm_fwd", ptr(xd), ptr(sd), ptr(td), 1, ptr(wd), ptr(y), *geom, ptr(part), ptr(ws), wsb)
+    assert relerr(host(y), ref) < TOL
+    s1, s2 = fold_partials(part, P, Cout)
+    assert relerr(s1, ref.sum((0, 1, 2))) < 1e-3 and relerr(s2, (ref ** 2).sum((0, 1, 2))) < 1e-3
+    g = rng.normal(0, 1, ref.shape).astype(np.float32)
+    cA, cB, cC = [rng.normal(0, 1, Cout).astype(np.float32) for _ in range(3)]
+    yraw = host(y)
+    dY = cA * g.astype(np.float64) + cB * yraw + cC
+    grads = tape.backward(ref, dY)
+    gd, cAd, cBd, cCd = dev(g), dev(cA), dev(cB), dev(cC)
+    dw = empty(3, 3, Cin, Cout)
+    call("dl3_conv3x3_gemm_bwd_weight", ptr(xd), ptr(sd), ptr(td), 1, ptr(gd), ptr(y), ptr(cAd), ptr(cBd), ptr(cCd),
+         ptr(dw), *geom, ptr(ws), wsb)
+    assert relerr(host(dw), grads[id(wv)]) < 1e-3
+    wT = empty(Cout, 9 * Cin)
+    call("dl3_transpose", ptr(wd), ptr(wT), 9 * Cin, Cout)
+    P2 = L.dl3_conv3x3_partials(N, H, W, Cin)
+    dx, dpart = empty(N, H, W, Cin), empty(P2, Cin, 2)
+    add = rng.normal(0, 1, (N, H, W, Cin)).astype(np.float32)
+    mean = rng.normal(0, 1, Cin).astype(np.float32)
+    invstd = rng.uniform(0.5, 2, Cin).astype(np.float32)
+    call("dl3_conv3x3_gemm_bwd_data", ptr(gd), ptr(y), ptr(cAd), ptr(cBd), ptr(cCd), ptr(wT), ptr(dx), ptr(xd), ptr(sd),
+         ptr(td), 1, ptr(dev(add)), ptr(dev(mean)), ptr(dev(invstd)), ptr(dpart), *geom, ptr(ws), wsb)
+    dx_ref = grads[id(xin)] * (z > 0) + add
+    assert relerr(host(dx), dx_ref) < TOL
+    d1, d2 = fold_partials(dpart, P2, Cin)
+    assert relerr(d1, dx_ref.sum((0, 1, 2))) < 1e-3
+    assert relerr(d2, (dx_ref * (x - mean) * invstd).sum((0, 1, 2))) < 1e-3
+    # same result as the direct vector-ALU kernel
+    if 256 % (Cout // 4) == 0:
+        y2 = empty(N, Ho, Wo, Cout)
+        call("dl3_conv3x3_fwd", ptr(xd), ptr(sd), ptr(td), 1, ptr(wd), ptr(y2), *geom, None)
+        assert relerr(host(y2), host(y)) < TOL
+    # too small a workspace is refused
+    assert L.dl3_conv3x3_gemm_fwd(ptr(xd), ptr(sd), ptr(td), 1, ptr(wd), ptr(y), *geom, None, ptr(ws), 16, stream()) == -3
+
+
 # ---------------------------------------------------------------------------------------
 # either side of the network: dl3_prepare_targets (utils.py:375-402), dl3_seg_counts (utils.py:132-157) — bit-exact
 # ---------------------------------------------------------------------------------------
