@@ -849,7 +849,7 @@ WgCfg pick_wgrad(int M, int K, int N, bool two) {
   // M split), 160-multiples want the 160-wide tiles so the big operand is read once
   if (K >= 32 && N >= 32 && (long)K * N <= 32768) return kWgCfgs[0];
   if (N % 160 == 0 && K >= 128 && K % 160 != 0) return kWgCfgs[3];
-  if (K % 160 == 0 && N >= 128 && N % 160 != 0) return kWgCfgs[2];
+  if (K % 160 == 0 && K % 128 != 0 && N >= 128 && N % 160 != 0) return kWgCfgs[2];
   double best = 1e30;
   WgCfg bc = kWgCfgs[0];
   for (const WgCfg &c : kWgCfgs) {

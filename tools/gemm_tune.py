@@ -17,6 +17,13 @@ SHAPES = [  # (pixels per image, K, N) of every distinct 1x1 conv of MobileNetV2
 ]
 
 
+XCEPTION_SHAPES = [  # Xception OS=8 at 512x512
+    (4096, 728, 728), (4096, 728, 1024), (4096, 1024, 1024), (4096, 1024, 1536), (4096, 1536, 1536), (4096, 1536, 2048),
+    (4096, 2048, 256), (4096, 1280, 256), (4096, 256, 728), (16384, 256, 256), (16384, 304, 256), (16384, 128, 256),
+    (65536, 128, 128), (65536, 64, 128), (65536, 288, 64),
+]
+
+
 def worker(batch, kind):
     import torch
     import dl3_amd  # noqa: F401
@@ -62,7 +69,11 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--worker", default=None)
+    ap.add_argument("--xception", action="store_true")
     args = ap.parse_args()
+    if args.xception or os.environ.get("DL3_TUNE_XCEPTION"):
+        SHAPES[:] = XCEPTION_SHAPES
+        os.environ["DL3_TUNE_XCEPTION"] = "1"
     if args.worker:
         worker(args.batch, args.worker)
         sys.exit(0)
