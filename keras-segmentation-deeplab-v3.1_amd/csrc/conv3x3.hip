@@ -224,6 +224,157 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// The two stem convolutions on the raw image (Cin = 3 -> 32: deeplabv3p.py:283 entry_flow_conv1_1, :318 Conv).
+// ---------------------------------------------------------------------------------------
+// Forward on the matrix pipe (default for Cin*9 <= 32, Cout == 32): y[p][co] = sum_t col[p][t] * W[t][co] with the
+// 27 (padded to 28) taps as the reduction axis of 14 v_mfma_f32_32x32x2_f32 steps per 32-pixel tile.  The column
+// matrix is never formed: lane (pixel = lane & 31, half = lane >> 5) gathers tap 2s+half of its own pixel as the A
+// operand; the weights sit in 14 registers per lane for the whole kernel.  The C layout has one output channel per
+// lane, so every store instruction writes two full 128-byte pixel rows and the BN sums are in-lane.
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3x3_stem_fwd_mfma_kernel(const float *__restrict__ x,
+                                                                    const float *__restrict__ sc,
+                                                                    const float *__restrict__ sh, int act,
+                                                                    const float *__restrict__ w,
+                                                                    float *__restrict__ y, CGeom G,
+                                                                    float *__restrict__ part) {
+  static_assert(COUT == 32, "one 32-column MFMA tile");
+  constexpr int KS = 14;  // k-steps: 28 >= 9*Cin taps
+  __shared__ float red[4][2 * COUT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int T = 9 * G.Cin;
+  float bw[KS], fs[KS], ft[KS];
+  int dy[KS], dx_[KS], dc[KS];
+#pragma unroll
+  for (int s = 0; s < KS; s++) {
+    const int kk = 2 * s + lhi, t = min(kk, T - 1);
+    bw[s] = (kk < T) ? w[(size_t)t * COUT + l31] : 0.f;
+    dy[s] = t / (3 * G.Cin);
+    dx_[s] = (t / G.Cin) % 3;
+    dc[s] = t % G.Cin;
+    fs[s] = sc ? sc[dc[s]] : 1.f;
+    ft[s] = sc ? sh[dc[s]] : 0.f;
+    if (kk >= T) { fs[s] = 0.f; ft[s] = 0.f; }  // act(0) = 0: the padding tap contributes nothing
+  }
+  float s1 = 0.f, s2 = 0.f;
+  const long NP = (long)G.N * G.Ho * G.Wo;
+  const long ntiles = (NP + 31) / 32;
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+    const long p = min(tile * 32 + l31, NP - 1);
+    const int ox = (int)(p % G.Wo), oy = (int)((p / G.Wo) % G.Ho), n = (int)(p / ((long)G.Wo * G.Ho));
+    const int iy0 = oy * G.stride - G.pad_t, ix0 = ox * G.stride - G.pad_l;
+    float av[KS];
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+      const int iy = iy0 + dy[s], ix = ix0 + dx_[s];
+      const int iyc = min(max(iy, 0), G.H - 1), ixc = min(max(ix, 0), G.W - 1);
+      const float live = (iy == iyc && ix == ixc) ? 1.f : 0.f;
+      av[s] = x[(((size_t)n * G.H + iyc) * G.W + ixc) * G.Cin + dc[s]] * live;
+      // (live scales the raw value; the shift ft is masked below)
+      av[s] = dl3_act(fs[s] * av[s] + ft[s] * live, act);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bw[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const long row = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      if (row < NP) {
+        __builtin_nontemporal_store(acc[r], &y[(size_t)row * COUT + l31]);
+        s1 += acc[r];
+        s2 += acc[r] * acc[r];
+      }
+    }
+  }
+  if (part) {
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (lhi == 0) { red[wave][2 * l31] = s1; red[wave][2 * l31 + 1] = s2; }
+    __syncthreads();
+    if (threadIdx.x < 2 * COUT)
+      part[(size_t)blockIdx.x * COUT * 2 + threadIdx.x] =
+          red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  }
+}
+
+// Weight gradient of the same convolutions on the matrix pipe: dW[t][co] = sum_p T(x)[p, tap t] * dY[p][co] with
+// t = (i*3+j)*Cin + ci < 32 rows of one v_mfma_f32_32x32x2_f32 tile and the pixel index p as the reduction axis
+// (two pixels per MFMA).  A lane supplies, for its own pixel (parity = lane >> 5), the input value under tap
+// (lane & 31) on the A side and dY of channel (lane & 31) on the B side: three dword loads per MFMA, no LDS.
+// grid = conv_blocks; every workgroup owns a contiguous range of output pixels, its 4 waves interleave pixel pairs.
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3x3_stem_wgrad_kernel(
+    const float *__restrict__ x, const float *__restrict__ sc, const float *__restrict__ sh, int act,
+    const float *__restrict__ g, const float *__restrict__ yraw, const float *__restrict__ cA,
+    const float *__restrict__ cB, const float *__restrict__ cC, float *__restrict__ wpart, CGeom G) {
+  constexpr int NJ = COUT / 32, U = 4;
+  __shared__ float red[4][32][COUT];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int T = 9 * G.Cin;
+  const int t = min(l31, T - 1), ti = t / (3 * G.Cin), tj = (t / G.Cin) % 3, tc = t % G.Cin;
+  const float tlive = (l31 < T) ? 1.f : 0.f;
+  const float fs = sc ? sc[tc] : 1.f, ft = sc ? sh[tc] : 0.f;
+  const bool two = cA != nullptr;
+  float kA[NJ], kB[NJ], kC[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    kA[j] = two ? cA[j * 32 + l31] : 1.f;
+    kB[j] = two ? cB[j * 32 + l31] : 0.f;
+    kC[j] = two ? cC[j * 32 + l31] : 0.f;
+  }
+  const float *yr = two ? yraw : g;
+  f32x16 acc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+
+  const long NP = (long)G.N * G.Ho * G.Wo;
+  const long per = ((NP + gridDim.x - 1) / gridDim.x + 7) & ~7l;  // pixels per workgroup, multiple of 8
+  const long pbeg = (long)blockIdx.x * per, pend = min(NP, pbeg + per);
+  // wave w takes pixel pairs w, w+4, w+8, ... of the range; U pairs are in flight per iteration
+  for (long q = pbeg + 2 * wave; q < pend; q += 8 * U) {
+    float av[U], gv[U][NJ], yv[U][NJ], lv[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const long p = q + 8 * u + lhi;
+      const long pc = min(p, NP - 1);
+      const int ox = (int)(pc % G.Wo), oy = (int)((pc / G.Wo) % G.Ho), n = (int)(pc / ((long)G.Wo * G.Ho));
+      const int iy = oy * G.stride - G.pad_t + ti, ix = ox * G.stride - G.pad_l + tj;
+      const int iyc = min(max(iy, 0), G.H - 1), ixc = min(max(ix, 0), G.W - 1);
+      lv[u] = (p < pend && iy == iyc && ix == ixc) ? tlive : 0.f;
+      av[u] = x[(((size_t)n * G.H + iyc) * G.W + ixc) * G.Cin + tc];
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        gv[u][j] = g[(size_t)pc * COUT + j * 32 + l31];
+        yv[u][j] = yr[(size_t)pc * COUT + j * 32 + l31];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const float a = dl3_act(fs * av[u] + ft, act) * lv[u];
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const float b = kA[j] * gv[u][j] + kB[j] * yv[u][j] + kC[j];
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  // fixed-order sum of the 4 waves, then one partial row [9*Cin][COUT] per workgroup
+#pragma unroll
+  for (int j = 0; j < NJ; j++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) red[wave][(r & 3) + 8 * (r >> 2) + 4 * lhi][j * 32 + l31] = acc[j][r];
+  __syncthreads();
+  for (int i = threadIdx.x; i < T * COUT; i += 256) {
+    const int row = i / COUT, col = i % COUT;
+    wpart[(size_t)blockIdx.x * T * COUT + i] = red[0][row][col] + red[1][row][col] + red[2][row][col] + red[3][row][col];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // MFMA route for a dense 3x3 conv with many input channels (xception entry_flow_conv1_2: 32 -> 64 at 256x256,
 // 1.2 GMAC / image, deeplabv3p.py:289): im2col -> the 1x1-conv GEMM kernels -> col2im.  The column matrix
 // [N*Ho*Wo][9*Cin] costs one extra write + read of 9x the input, which the matrix pipe wins back ~10x over.
@@ -340,8 +491,12 @@ extern "C" int dl3_conv3x3_fwd(const float *x, const float *in_scale, const floa
   if (rc) return rc;
   DL3_CHECK_ARG(x && w && y, "conv3x3_fwd: null pointer");
   DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "conv3x3_fwd: scale/shift must come together");
-  hipLaunchKernelGGL(conv3x3_fwd_kernel, dim3(conv_blocks((long)N * Ho * Wo)), dim3(256), 0, (hipStream_t)stream,
-                     x, in_scale, in_shift, in_act, w, y, G, stat_partial);
+  if (9 * Cin <= 28 && Cout == 32)
+    hipLaunchKernelGGL((conv3x3_stem_fwd_mfma_kernel<32>), dim3(conv_blocks((long)N * Ho * Wo)), dim3(256), 0,
+                       (hipStream_t)stream, x, in_scale, in_shift, in_act, w, y, G, stat_partial);
+  else
+    hipLaunchKernelGGL(conv3x3_fwd_kernel, dim3(conv_blocks((long)N * Ho * Wo)), dim3(256), 0, (hipStream_t)stream,
+                       x, in_scale, in_shift, in_act, w, y, G, stat_partial);
   DL3_LAUNCH_CHECK("conv3x3_fwd");
   return DL3_OK;
 }
@@ -356,9 +511,14 @@ extern "C" int dl3_conv3x3_bwd_weight(const float *x, const float *in_scale, con
   DL3_CHECK_ARG(x && g && dw_partial, "conv3x3_bwd_weight: null pointer");
   DL3_CHECK_ARG(!cA || (yraw && cB && cC), "conv3x3_bwd_weight: cA needs yraw, cB, cC");
   DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "conv3x3_bwd_weight: scale/shift must come together");
-  dim3 grid(conv_blocks((long)N * Ho * Wo), dl3_cdiv(Cin, CI_CHUNK));
-  hipLaunchKernelGGL(conv3x3_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, in_scale, in_shift, in_act,
-                     g, yraw, cA, cB, cC, dw_partial, G);
+  if (9 * Cin <= 32 && Cout == 32) {
+    hipLaunchKernelGGL((conv3x3_stem_wgrad_kernel<32>), dim3(conv_blocks((long)N * Ho * Wo)), dim3(256), 0,
+                       (hipStream_t)stream, x, in_scale, in_shift, in_act, g, yraw, cA, cB, cC, dw_partial, G);
+  } else {
+    dim3 grid(conv_blocks((long)N * Ho * Wo), dl3_cdiv(Cin, CI_CHUNK));
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, in_scale, in_shift, in_act,
+                       g, yraw, cA, cB, cC, dw_partial, G);
+  }
   DL3_LAUNCH_CHECK("conv3x3_bwd_weight");
   return DL3_OK;
 }
