@@ -479,6 +479,121 @@ __global__ __launch_bounds__(256) void dw_gather_bwd(
   }
 }
 
+// ======================================================================================
+// stride-2 backward (rate 1, pad 0 or 1: MobileNetV2 blocks 1 and 3, Xception entry flow): thread = one 2x2 block
+// of INPUT pixels x 4 channels.  With iy0 = 2a - pad_t the block rows are "e" = iy0 (taps ky = 0 from output row a
+// and ky = 2 from row a-1) and "o" = iy0+1 (tap ky = 1 from row a), same for columns, so the four dY values at
+// (a, b), (a-1, b), (a, b-1), (a-1, b-1) feed the four dx pixels and all nine dW taps: 8 gradient loads per 4 output
+// pixels instead of the 72 the generic gather issues (of which 9 are live).
+// ======================================================================================
+__global__ __launch_bounds__(256) void dw_s2_bwd(
+    const float *__restrict__ g, const float *__restrict__ yraw, const float *__restrict__ cA,
+    const float *__restrict__ cB, const float *__restrict__ cC, const float *__restrict__ x,
+    const float *__restrict__ sc, const float *__restrict__ sh, int act, const float *__restrict__ w,
+    float *__restrict__ dx, const float *__restrict__ dx_add, const float *__restrict__ xmean,
+    const float *__restrict__ xinvstd, float *__restrict__ dpart, float *__restrict__ wpart, DwGeom G) {
+  __shared__ float red[4 * 8 * 36];
+  const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
+  const int c = blockIdx.x * 32 + cq * 4;
+  const bool cok = c < G.C;
+  const int cc = min(c, G.C - 4);
+  f32x4 wv[9], s = splat4(1.f), t = splat4(0.f);
+  f32x4 kA = splat4(1.f), kB = splat4(0.f), kC = splat4(0.f), mu = splat4(0.f), is = splat4(0.f);
+#pragma unroll
+  for (int i = 0; i < 9; i++) wv[i] = ld4(w + (size_t)i * G.C + cc);
+  if (sc) { s = ld4(sc + cc); t = ld4(sh + cc); }
+  if (cA) { kA = ld4(cA + cc); kB = ld4(cB + cc); kC = ld4(cC + cc); }
+  if (dpart) { mu = ld4(xmean + cc); is = ld4(xinvstd + cc); }
+  const float *yr = cA ? yraw : g;
+  f32x4 dwv[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) dwv[i] = splat4(0.f);
+  f32x4 s1 = splat4(0.f), s2 = splat4(0.f);
+  const int A = (G.H + G.pad_t + 1) / 2, Bn = (G.W + G.pad_l + 1) / 2;
+  const long NB = (long)G.N * A * Bn;
+  for (long q = (long)blockIdx.y * 32 + pl; q < NB; q += (long)gridDim.y * 32) {
+    const int b = (int)(q % Bn), a = (int)((q / Bn) % A), n = (int)(q / ((long)Bn * A));
+    const int iy0 = 2 * a - G.pad_t, ix0 = 2 * b - G.pad_l;
+    // dY at (a - i, b - j), i, j in {0, 1}: clamped addresses, 0/1 validity multipliers (branch-free loads)
+    f32x4 dd[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int oy = a - i, ox = b - j;
+        const int oyc = min(max(oy, 0), G.Ho - 1), oxc = min(max(ox, 0), G.Wo - 1);
+        const float ok = (cok && oy == oyc && ox == oxc) ? 1.f : 0.f;
+        const size_t off = (((size_t)n * G.Ho + oyc) * G.Wo + oxc) * G.C + cc;
+        dd[i][j] = (kA * ld4(g + off) + kB * ld4(yr + off) + kC) * splat4(ok);
+      }
+    // the 2x2 input pixels
+    f32x4 xr[2][2], ad[2][2];
+    float pok[2][2];
+    size_t poff[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int iy = iy0 + i, ix = ix0 + j;
+        const int iyc = min(max(iy, 0), G.H - 1), ixc = min(max(ix, 0), G.W - 1);
+        pok[i][j] = (cok && iy == iyc && ix == ixc) ? 1.f : 0.f;
+        poff[i][j] = (((size_t)n * G.H + iyc) * G.W + ixc) * G.C + cc;
+        xr[i][j] = ld4(x + poff[i][j]);
+        ad[i][j] = dx_add ? ld4(dx_add + poff[i][j]) : splat4(0.f);
+      }
+    f32x4 acc[2][2];
+    acc[0][0] = wv[0] * dd[0][0] + wv[6] * dd[1][0] + wv[2] * dd[0][1] + wv[8] * dd[1][1];
+    acc[0][1] = wv[1] * dd[0][0] + wv[7] * dd[1][0];
+    acc[1][0] = wv[3] * dd[0][0] + wv[5] * dd[0][1];
+    acc[1][1] = wv[4] * dd[0][0];
+    f32x4 ea[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) ea[i][j] = dl3_act4(s * xr[i][j] + t, act) * splat4(pok[i][j]);
+    dwv[0] += ea[0][0] * dd[0][0]; dwv[6] += ea[0][0] * dd[1][0]; dwv[2] += ea[0][0] * dd[0][1]; dwv[8] += ea[0][0] * dd[1][1];
+    dwv[1] += ea[0][1] * dd[0][0]; dwv[7] += ea[0][1] * dd[1][0];
+    dwv[3] += ea[1][0] * dd[0][0]; dwv[5] += ea[1][0] * dd[0][1];
+    dwv[4] += ea[1][1] * dd[0][0];
+    if (dx) {
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          f32x4 out = acc[i][j] * dl3_mask4(s * xr[i][j] + t, act) + ad[i][j];
+          if (pok[i][j] != 0.f) {
+            st4_nt(dx + poff[i][j], out);
+            s1 += out;
+            s2 += out * ((xr[i][j] - mu) * is);
+          }
+        }
+    }
+  }
+  {
+    float v[36];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      v[i * 4 + 0] = dwv[i].x; v[i * 4 + 1] = dwv[i].y; v[i * 4 + 2] = dwv[i].z; v[i * 4 + 3] = dwv[i].w;
+    }
+    reduce_px<36>(v, red);
+    if (tid < 8 && cok) {
+#pragma unroll
+      for (int i = 0; i < 9; i++) {
+        f32x4 o = {v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]};
+        st4(wpart + ((size_t)blockIdx.y * 9 + i) * G.C + c, o);
+      }
+    }
+  }
+  if (dpart) {
+    float v[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
+    reduce_px<8>(v, red);
+    if (tid < 8 && cok) {
+      f32x4 r1 = {v[0], v[1], v[2], v[3]}, r2 = {v[4], v[5], v[6], v[7]};
+      write_stat_partial(dpart, blockIdx.y, G.C, c, r1, r2);
+    }
+  }
+}
+
 // ---- host-side decomposition (shared by *_partials and the launchers) -------------------
 struct DwPlan {
   int impl;                      // DL3_IMPL_MARCH / DL3_IMPL_GATHER
@@ -621,8 +736,13 @@ extern "C" int dl3_dwconv3x3_bwd(const float *g, const float *yraw, const float 
   } else {
     DwGeom G{N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo};
     dim3 grid(p.nslab, p.PB);
-    hipLaunchKernelGGL(dw_gather_bwd, grid, dim3(256), 0, st, g, yraw, cA, cB, cC, x, in_scale, in_shift, in_act,
-                       w, dx, dx_add, x_mean, x_invstd, dstat_partial, dw_partial, G);
+    const char *e = getenv("DL3_DW_S2");  // 0 = generic gather for stride 2 as well (tuning / test aid)
+    if (stride == 2 && rate == 1 && pad_t <= 1 && pad_l <= 1 && !(e && atoi(e) == 0))
+      hipLaunchKernelGGL(dw_s2_bwd, grid, dim3(256), 0, st, g, yraw, cA, cB, cC, x, in_scale, in_shift, in_act, w, dx,
+                         dx_add, x_mean, x_invstd, dstat_partial, dw_partial, G);
+    else
+      hipLaunchKernelGGL(dw_gather_bwd, grid, dim3(256), 0, st, g, yraw, cA, cB, cC, x, in_scale, in_shift, in_act,
+                         w, dx, dx_add, x_mean, x_invstd, dstat_partial, dw_partial, G);
     const int Pmax = dl3_dwconv3x3_partials(N, H, W, C, stride, rate, Ho, Wo, im);
     if (Pmax > p.P) {
       (void)hipMemsetAsync(dw_partial + (size_t)p.P * 9 * C, 0, (size_t)(Pmax - p.P) * 9 * C * sizeof(float), st);

@@ -48,15 +48,16 @@ def _l2(a, b):
     return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
 
 
-def _assert_argmax_parity(mask, ref_logits):
+def _assert_argmax_parity(mask, ref_logits, rel=1e-3):
     """masks must be identical except where the ORACLE's own top-2 margin is below the fp32 agreement of the logits
-    (1e-3 relative): a different fp32 summation order may legitimately flip such near-ties.  The count is reported."""
+    (`rel`, 1e-3 relative unless the case is documented as ill-conditioned): a different fp32 summation order may
+    legitimately flip such near-ties.  The count is reported."""
     ref_mask = ref_logits.argmax(-1)
     diff = mask != ref_mask
     if diff.any():
         srt = np.sort(ref_logits, axis=-1)
         margin = (srt[..., -1] - srt[..., -2])[diff]
-        assert margin.max() < 1e-3 * np.abs(ref_logits).max(), ("argmax flipped on a clear winner", int(diff.sum()), margin.max())
+        assert margin.max() < rel * np.abs(ref_logits).max(), ("argmax flipped on a clear winner", int(diff.sum()), margin.max())
         assert diff.mean() < 2e-3, int(diff.sum())
         print("argmax near-tie flips: %d of %d pixels (max margin %.2e)" % (diff.sum(), diff.size, margin.max()))
 
@@ -163,7 +164,7 @@ def test_xception_train_step_gradients(OS):
     # the fp32 ORACLE's own distance to float64 is the yardstick there
     tol = max(1e-3, 2.0 * relerr(ref32, ref))
     assert relerr(model._active.logits(), ref) < tol, (relerr(model._active.logits(), ref), tol)
-    _assert_argmax_parity(model._active.argmax(), ref)
+    _assert_argmax_parity(model._active.argmax(), ref, rel=tol)
     labels = rng.integers(0, classes + 1, (B, shape[0] * shape[1])).astype(np.float32)
     sw = (labels < classes).astype(np.float32)
     eng = model._engine(B, True, dropout=False, use_graph=False)
