@@ -297,6 +297,46 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmArgs P) {
   }
 }
 
+// Epilogue of the stream kernel for a tile that lies inside the matrix, specialised at compile time on what it has to
+// do.  (The generic version below tests its run-time flags and the bounds on every element; its exec-mask branches and
+// waits cost ~28k cycles per 128x160 tile — two thirds of the main loop of a K=160 GEMM.)  EPX: activation mask from
+// the forward input (bwd-data); ADD: residual gradient; MODE2: second statistic is sum(c * xhat) instead of sum(c^2).
+// All 16 (32 with ADD) global reads of a 32x32 sub-tile are issued before the first use.
+template <int TM, int TN, bool EPX, bool ADD, bool MODE2>
+__device__ __forceinline__ void stream_epilogue_full(const GemmArgs &P, const f32x16 (&acc)[TM][TN], int m0, int n0,
+                                                     int wm, int l31, int lhi, float (&st1)[TN], float (&st2)[TN]) {
+#pragma unroll
+  for (int j = 0; j < TN; j++) {
+    const int col = n0 + j * 32 + l31;
+    float bias = 0.f, es = 1.f, et = 0.f, mu = 0.f, is = 0.f;
+    if (P.bias) bias = P.bias[col];
+    if (EPX && P.ep_scale) { es = P.ep_scale[col]; et = P.ep_shift[col]; }
+    if (MODE2) { mu = P.ep_mean[col]; is = P.ep_invstd[col]; }
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+      const int rbase = m0 + (wm * TM + i) * 32 + 4 * lhi;
+      float xr_[16], ad[16];
+      if (EPX) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) xr_[r] = P.ep_x[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * P.ld_epx + col];
+      }
+      if (ADD) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) ad[r] = P.add_scale * P.ep_add[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * P.ld_add + col];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float v = acc[i][j][r] + bias;
+        if (EPX) v *= dl3_act_mask(es * xr_[r] + et, P.ep_act);
+        if (ADD) v += ad[r];
+        __builtin_nontemporal_store(v, &P.c[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * P.ldc + col]);
+        st1[j] += v;
+        st2[j] += MODE2 ? v * ((xr_[r] - mu) * is) : v * v;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // "stream-A" GEMM (the default for 16-byte-aligned operands).
 //
@@ -309,7 +349,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmArgs P) {
 // BatchNorm+ReLU6 (forward) or the BatchNorm-backward affine of two tensors (bwd-data) is applied to the
 // registers between load and use, one K-tile ahead of the MFMAs.
 // ---------------------------------------------------------------------------------------
-template <int TM, int TN, bool TWO, int KT>
+// FWD: the launch has no masked epilogue (no ep_x, stat_mode != 2, no per-image broadcast residual) — the forward
+// GEMMs; their interior tiles take the straight-line epilogue and the masked code is not compiled in at all.
+template <int TM, int TN, bool TWO, int KT, bool FWD>
 __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
   // KT = depth of one K-tile: each half-wave walks KT/2 consecutive k (KT/8 float4 loads per lane and tensor)
   constexpr int BM = 128 * TM, BN = 32 * TN, KH = KT / 2, NJ = KT / 8;
@@ -455,9 +497,14 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
       __syncthreads();
     }
 
-    // ---------------- epilogue (same C/D layout as the LDS-staged kernel): all global reads of a 32x32 sub-tile are
-    // issued up front (clamped addresses, no branches) so 16-32 loads per lane are in flight
+    // ---------------- epilogue (same C/D layout as the LDS-staged kernel)
     const bool full = (m0 + BM <= P.M) && (n0 + BN <= P.N);
+    if (FWD && full) {
+      if (!P.ep_add) stream_epilogue_full<TM, TN, false, false, false>(P, acc, m0, n0, wm, l31, lhi, st1, st2);
+      else stream_epilogue_full<TM, TN, false, true, false>(P, acc, m0, n0, wm, l31, lhi, st1, st2);
+      continue;
+    }
+    // everything else: generic path, every element predicated
 #pragma unroll
     for (int j = 0; j < TN; j++) {
       const int col = n0 + j * 32 + l31;
@@ -465,13 +512,13 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
       const int colc = min(col, P.N - 1);
       float bias = 0.f, es = 1.f, et = 0.f, mu = 0.f, is = 0.f;
       if (P.bias) bias = P.bias[colc];
-      if (P.ep_scale) { es = P.ep_scale[colc]; et = P.ep_shift[colc]; }
-      if (P.stat_mode == 2) { mu = P.ep_mean[colc]; is = P.ep_invstd[colc]; }
+      if (!FWD && P.ep_scale) { es = P.ep_scale[colc]; et = P.ep_shift[colc]; }
+      if (!FWD && P.stat_mode == 2) { mu = P.ep_mean[colc]; is = P.ep_invstd[colc]; }
 #pragma unroll
       for (int i = 0; i < TM; i++) {
         const int rbase = m0 + (wm * TM + i) * 32 + 4 * lhi;
         float xr_[16], ad[16];
-        if (P.ep_x) {
+        if (!FWD && P.ep_x) {
 #pragma unroll
           for (int r = 0; r < 16; r++) {
             const int row = min(rbase + (r & 3) + 8 * (r >> 2), P.M - 1);
@@ -485,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
 #pragma unroll
           for (int r = 0; r < 16; r++) {
             const int row = min(rbase + (r & 3) + 8 * (r >> 2), P.M - 1);
-            const int arow_ = (P.add_div > 1) ? row / P.add_div : row;
+            const int arow_ = (!FWD && P.add_div > 1) ? row / P.add_div : row;
             ad[r] = P.add_scale * P.ep_add[(size_t)arow_ * P.ld_add + colc];
           }
         } else {
@@ -497,12 +544,12 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
           const int row = rbase + (r & 3) + 8 * (r >> 2);
           const bool ok = full || (cok && row < P.M);
           float v = acc[i][j][r] + bias;
-          if (P.ep_x) v *= dl3_act_mask(es * xr_[r] + et, P.ep_act);
+          if (!FWD && P.ep_x) v *= dl3_act_mask(es * xr_[r] + et, P.ep_act);
           v += ad[r];
           if (ok) {
             __builtin_nontemporal_store(v, &P.c[(size_t)row * P.ldc + col]);
             st1[j] += v;
-            st2[j] += (P.stat_mode == 2) ? v * ((xr_[r] - mu) * is) : v * v;
+            st2[j] += (!FWD && P.stat_mode == 2) ? v * ((xr_[r] - mu) * is) : v * v;
           }
         }
       }
@@ -813,10 +860,12 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   const int impl = env_int("DL3_GEMM_IMPL");
   if (vec && impl != 0 && A.K <= DL3_STREAM_KMAX) {
     dim3 blk(256);
-#define DL3_STREAM(TM_, TN_)                                                                              \
-  do {                                                                                                    \
-    if (two) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, true, 16>), grid, blk, 0, st, A);        \
-    else hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, 16>), grid, blk, 0, st, A);           \
+    const bool fwd = !two && !A.ep_x && A.stat_mode != 2 && !(A.ep_add && A.add_div > 1);
+#define DL3_STREAM(TM_, TN_)                                                                                    \
+  do {                                                                                                          \
+    if (two) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, true, 16, false>), grid, blk, 0, st, A);       \
+    else if (fwd) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, 16, true>), grid, blk, 0, st, A);  \
+    else hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, 16, false>), grid, blk, 0, st, A);          \
   } while (0)
     switch (c.id) {
       case 0: DL3_STREAM(1, 4); break;
