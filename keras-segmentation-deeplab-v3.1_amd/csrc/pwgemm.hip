@@ -305,6 +305,12 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmArgs P) {
 template <int TM, int TN, bool EPX, bool ADD, bool MODE2>
 __device__ __forceinline__ void stream_epilogue_full(const GemmArgs &P, const f32x16 (&acc)[TM][TN], int m0, int n0,
                                                      int wm, int l31, int lhi, float (&st1)[TN], float (&st2)[TN]) {
+  // addresses = wave-uniform base (scalar registers) + ONE 32-bit lane offset per tensor: the rows of a sub-tile differ
+  // by uniform multiples of the leading dimension, only (lane >> 5, lane & 31) is lane-specific
+  const int wmu = __builtin_amdgcn_readfirstlane(wm);
+  const unsigned lo_c = (unsigned)(4 * lhi * P.ldc + l31);
+  const unsigned lo_x = EPX ? (unsigned)(4 * lhi * P.ld_epx + l31) : 0u;
+  const unsigned lo_a = ADD ? (unsigned)(4 * lhi * P.ld_add + l31) : 0u;
 #pragma unroll
   for (int j = 0; j < TN; j++) {
     const int col = n0 + j * 32 + l31;
@@ -314,45 +320,43 @@ __device__ __forceinline__ void stream_epilogue_full(const GemmArgs &P, const f3
     if (MODE2) { mu = P.ep_mean[col]; is = P.ep_invstd[col]; }
 #pragma unroll
     for (int i = 0; i < TM; i++) {
-      const int rbase = m0 + (wm * TM + i) * 32 + 4 * lhi;
+      const size_t urow = (size_t)(m0 + (wmu * TM + i) * 32);
+      const int ucol = n0 + j * 32;
+      float *pc = P.c + urow * P.ldc + ucol;
+      const float *px = EPX ? P.ep_x + urow * P.ld_epx + ucol : nullptr;
+      const float *pa = ADD ? P.ep_add + urow * P.ld_add + ucol : nullptr;
       float xr_[16], ad[16];
       if (EPX) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) xr_[r] = P.ep_x[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * P.ld_epx + col];
+        for (int r = 0; r < 16; r++) xr_[r] = (px + (size_t)((r & 3) + 8 * (r >> 2)) * P.ld_epx)[lo_x];
       }
       if (ADD) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) ad[r] = P.add_scale * P.ep_add[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * P.ld_add + col];
+        for (int r = 0; r < 16; r++) ad[r] = P.add_scale * (pa + (size_t)((r & 3) + 8 * (r >> 2)) * P.ld_add)[lo_a];
       }
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         float v = acc[i][j][r] + bias;
         if (EPX) v *= dl3_act_mask(es * xr_[r] + et, P.ep_act);
         if (ADD) v += ad[r];
-        __builtin_nontemporal_store(v, &P.c[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * P.ldc + col]);
+        __builtin_nontemporal_store(v, &(pc + (size_t)((r & 3) + 8 * (r >> 2)) * P.ldc)[lo_c]);
         st1[j] += v;
         st2[j] += MODE2 ? v * ((xr_[r] - mu) * is) : v * v;
       }
+      // keep the sub-tiles apart: interleaving them would hold several sub-tiles' operands live on top of the
+      // accumulators (spills)
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// "stream-A" GEMM (the default for 16-byte-aligned operands).
-//
-// The MFMA A operand of v_mfma_f32_32x32x2_f32 is ONE float per lane: lane (r = l&31, h = l>>5) supplies
-// A[row r][k of this step].  A sum over k may pair the k indices in any order, so within a 32-deep K-tile we
-// let the h = 0 lanes walk k = 0..15 and the h = 1 lanes k = 16..31: every lane then needs 16 CONSECUTIVE
-// floats of its own row — four 16-byte global loads, 128 contiguous bytes per row pair — and the activation
-// tile goes HBM -> registers -> MFMA with no LDS round trip, no transposing ds_write, and no barrier on the A
-// side.  Each wave streams its own 32*TM rows; only the small weight tile B (32 x BN) is shared through LDS.
-// BatchNorm+ReLU6 (forward) or the BatchNorm-backward affine of two tensors (bwd-data) is applied to the
-// registers between load and use, one K-tile ahead of the MFMAs.
-// ---------------------------------------------------------------------------------------
 // FWD: the launch has no masked epilogue (no ep_x, stat_mode != 2, no per-image broadcast residual) — the forward
 // GEMMs; their interior tiles take the straight-line epilogue and the masked code is not compiled in at all.
-template <int TM, int TN, bool TWO, int KT, bool FWD>
+template <int TM, int TN, bool TWO, int KT, int EPI>
 __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
+  // EPI: 0 generic epilogue only, 1 forward (see above).  A straight-line MASKED bwd-data variant was measured too:
+  // on top of 80 accumulators its operand registers push long-lived values into scratch and it came out slower.
+  constexpr bool FWD = (EPI == 1);
   // KT = depth of one K-tile: each half-wave walks KT/2 consecutive k (KT/8 float4 loads per lane and tensor)
   constexpr int BM = 128 * TM, BN = 32 * TN, KH = KT / 2, NJ = KT / 8;
   constexpr int LDB = BN;
@@ -863,9 +867,9 @@ int run_gemm(GemmArgs A, hipStream_t st) {
     const bool fwd = !two && !A.ep_x && A.stat_mode != 2 && !(A.ep_add && A.add_div > 1);
 #define DL3_STREAM(TM_, TN_)                                                                                    \
   do {                                                                                                          \
-    if (two) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, true, 16, false>), grid, blk, 0, st, A);       \
-    else if (fwd) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, 16, true>), grid, blk, 0, st, A);  \
-    else hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, 16, false>), grid, blk, 0, st, A);          \
+    if (two) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, true, 16, 0>), grid, blk, 0, st, A);      \
+    else if (fwd) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, 16, 1>), grid, blk, 0, st, A);     \
+    else hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, 16, 0>), grid, blk, 0, st, A);              \
   } while (0)
     switch (c.id) {
       case 0: DL3_STREAM(1, 4); break;
