@@ -277,3 +277,64 @@ def test_device_targets_and_evaluate():
     w = (Yh[:, :, 0] != C).astype(np.float64)
     assert abs(loss - (ell * w).sum() / (w != 0).mean() / w.size) < 1e-12
     assert 0.0 <= jac <= 1.0 and 0.0 <= acc <= 1.0
+
+
+def test_frozen_bn_train_step_gradients():
+    """bn_mode='frozen' (the notebook's fine-tuning intent): BatchNorm uses the moving statistics in the
+    training step, its gamma/beta still receive gradients, the moving statistics stay untouched."""
+    classes, B, shape = 3, 2, (64, 64, 3)
+    model, params = _build("mobilenetv2", shape, classes, "deeplab")
+    rng = np.random.default_rng(5)
+    x = rng.integers(0, 256, (B,) + shape).astype(np.float32)
+    kw = dict(backbone="mobilenetv2", input_shape=shape, classes=classes, OS=16, head="deeplab")
+    params = O.calibrate_bn(params, x, **kw)
+    _load(model, params)
+    labels = rng.integers(0, classes + 1, (B, shape[0] * shape[1])).astype(np.float32)
+    sw = (labels < classes).astype(np.float32)
+    eng = model._engine(B, True, bn_mode="frozen", dropout=False, use_graph=False)
+    eng.set_input(x)
+    eng.set_targets(labels, sw)
+    eng.fwd_bwd()
+    torch.cuda.synchronize()
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    loss, grads, logits, net = O.train_grads(p64, x.astype(np.float64), labels.astype(np.float64), sw.astype(np.float64),
+                                              bn_frozen=True, **kw)
+    assert relerr(eng.logits(), logits) < 1e-3
+    assert abs(float(eng.loss[0].item()) - loss) < 1e-4 * abs(loss)
+    num = den = 0.0
+    for name, g in grads.items():
+        if g is None or "/moving_" in name or np.abs(g).max() < 1e-6:
+            continue
+        got = eng.grad_of(name).astype(np.float64)
+        num += float(np.sum((got - g) ** 2))
+        den += float(np.sum(g ** 2))
+    # frozen BN is a per-channel affine map: the fp32 path is well conditioned
+    # (no batch statistics in the chain, far below the 2e-2 floor of the batch-statistics case)
+    assert np.sqrt(num / den) < 5e-3, np.sqrt(num / den)
+    # per tensor: against the fp32 run of the oracle itself (aspp0/kernel: 7e-3 from cancellation in fp32)
+    _, g32, _, _ = O.train_grads(params, x, labels, sw, bn_frozen=True, **kw)
+    for name in ("Conv_BN/gamma:0", "expanded_conv_16_project_BN/beta:0", "aspp0/kernel:0", "Conv/kernel:0"):
+        assert _l2(eng.grad_of(name), grads[name]) < max(5e-3, 2.0 * _l2(g32[name], grads[name])), name
+    eng.sync_all_to_host()
+    mm = model.get_layer("Conv_BN").get_weights()[2]
+    assert np.array_equal(mm, params["Conv_BN/moving_mean:0"])
+
+
+def test_single_image_batch_statistics_trap():
+    """with B=1 the image-pooling BatchNorm sees one sample per channel (variance 0): its output is beta and
+    no gradient reaches image_pooling.  The step must stay finite and reproduce exactly that."""
+    classes, shape = 3, (64, 64, 3)
+    model, params = _build("mobilenetv2", shape, classes, "deeplab")
+    _load(model, params)
+    rng = np.random.default_rng(6)
+    x = rng.integers(0, 256, (1,) + shape).astype(np.float32)
+    labels = rng.integers(0, classes + 1, (1, shape[0] * shape[1])).astype(np.float32)
+    eng = model._engine(1, True, dropout=False, use_graph=False)
+    eng.set_input(x)
+    eng.set_targets(labels)
+    eng.fwd_bwd()
+    torch.cuda.synchronize()
+    assert np.isfinite(float(eng.loss[0].item()))
+    assert np.isfinite(eng.grads.cpu().numpy()).all()
+    assert np.abs(eng.grad_of("image_pooling/kernel:0")).max() < 1e-6
+    assert np.abs(eng.grad_of("aspp0/kernel:0")).max() > 1e-6
