@@ -609,8 +609,30 @@ class Engine:
         self.xbuf.t.copy_(xt.reshape(-1).to(self.device, non_blocking=True))
 
     def forward(self):
+        """forward launch sequence; the inference engine replays it as one hipGraph from the second call on (68
+        launches of a few microseconds each: at batch 1 the Python/ctypes launch path costs more than the kernels)"""
         self._prep()
-        self.run_ops(self.ops_fwd)
+        if self.training or not self.use_graph:
+            self.run_ops(self.ops_fwd)
+            return
+        if self._calls >= 1:
+            if self.graph is None:
+                torch.cuda.synchronize()
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self.run_ops(self.ops_fwd)
+                    self.graph = g
+                except Exception as e:  # pragma: no cover - depends on the runtime
+                    print("dl3: hipGraph capture failed (%s); running eagerly" % e)
+                    self.use_graph = False
+                    torch.cuda.synchronize()
+                    self.run_ops(self.ops_fwd)
+                    return
+            self.graph.replay()
+        else:
+            self.run_ops(self.ops_fwd)
+        self._calls += 1
 
     def predict(self, x):
         assert not self.training

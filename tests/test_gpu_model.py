@@ -338,3 +338,30 @@ def test_single_image_batch_statistics_trap():
     assert np.isfinite(eng.grads.cpu().numpy()).all()
     assert np.abs(eng.grad_of("image_pooling/kernel:0")).max() < 1e-6
     assert np.abs(eng.grad_of("aspp0/kernel:0")).max() > 1e-6
+
+
+def test_inference_graph_replay_matches_eager():
+    """Model.predict replays the forward launch sequence as a hipGraph from the second call on: same bits as the
+    eager first call, also after the input and the weights changed."""
+    model, params = _build(input_shape=(64, 64, 3), classes=3)
+    _load(model, params)
+    rng = np.random.default_rng(8)
+    x1 = rng.integers(0, 256, (2, 64, 64, 3)).astype(np.float32)
+    x2 = rng.integers(0, 256, (2, 64, 64, 3)).astype(np.float32)
+    p_eager = model.predict(x1, batch_size=2)          # call 1: eager
+    p_cap = model.predict(x1, batch_size=2)            # call 2: capture + replay
+    p_rep = model.predict(x1, batch_size=2)            # call 3: replay
+    assert np.array_equal(p_eager, p_cap) and np.array_equal(p_eager, p_rep)
+    q = model.predict(x2, batch_size=2)
+    assert not np.array_equal(q, p_eager)
+    eng = model._active
+    assert eng.graph is not None
+    eager = model._engine(2, False, use_graph=False)
+    assert np.array_equal(eager.predict(x2), q)
+    # new weights reach the replayed graph (device buffers are updated in place)
+    layer = model.get_layer("logits_semantic" if False else "custom_logits_semantic")
+    w = layer.get_weights()
+    layer.set_weights([w[0] * 0.5, w[1] + 0.25])
+    q2 = model.predict(x2, batch_size=2)
+    assert not np.array_equal(q2, q)
+    assert np.array_equal(model._engine(2, False, use_graph=False).predict(x2), q2)
