@@ -6,7 +6,7 @@
 # Outputs land in gpurun_out/prof_<tag>/ ; tools/pmc_parse.py + the copy step put the summaries under profiles/.
 set -u
 TAG=${1:-r01}
-B=${2:-32}
+B=${2:-64}
 REPO=$(pwd)
 export TMPDIR=/tmp
 mkdir -p $REPO/gpurun_out
