@@ -203,6 +203,16 @@ int dl3_softmax_xent(const float *logits, const float *labels, const float *weig
 int dl3_upsample_softmax_xent(const float *logits_lo, const float *labels, const float *weights, const float *nnz,
                               float *probs, float *dlogits, float *loss_partial, int N, int Hi, int Wi, int Ho, int Wo,
                               int C, void *stream);
+/* the training tail without the full-resolution gradient: loss as above, and the x half of the transposed resize
+ * applied on chip — dlogits_xfold [N,Ho,Wi,C] = sum over the output columns of each output row (fixed order);
+ * dl3_resize_bilinear_bwd_rows folds the rows (the y half) into dx [N,Hi,Wi,C].  loss_partial has
+ * P = dl3_xent_fold_partials(N, Ho) entries.  C <= 32 and Wo*C*4 <= 64 KB (one output row lives in LDS). */
+int dl3_xent_fold_partials(int N, int Ho);
+int dl3_upsample_softmax_xent_fold(const float *logits_lo, const float *labels, const float *weights, const float *nnz,
+                                   float *dlogits_xfold, float *loss_partial, int N, int Hi, int Wi, int Ho, int Wo,
+                                   int C, void *stream);
+int dl3_resize_bilinear_bwd_rows(const float *xfold, float *dx, int lddx, int N, int Hi, int Wi, int Ho, int C,
+                                 int accumulate, void *stream);
 /* out[i] = sum_p partial[p][i]  (fixed order) */
 int dl3_reduce_partials(const float *partial, int P, int n, float *out, void *stream);
 int dl3_fill(float *p, float value, size_t n, void *stream);

@@ -323,6 +323,90 @@ __global__ __launch_bounds__(256) void xent32_kernel(const float *__restrict__ x
   if (threadIdx.x == 0) loss_part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
+// The training tail in one pass per output ROW: a workgroup owns output row (n, oy); phase 1 interpolates the
+// low-resolution logits, evaluates softmax / loss / dlogits for the Wo pixels of the row and leaves dlogits in LDS;
+// phase 2 folds the row onto the Wi input columns (the x half of the transposed bilinear resize, fixed summation
+// order).  The full-resolution dlogits [N,Ho,Wo,C] (704 MB at 32x512x512x21) never exist: the kernel writes the
+// x-folded rows [N,Ho,Wi,C] (8x smaller) and dl3_resize_bilinear_bwd_rows finishes with the y half.
+__global__ __launch_bounds__(256) void xent32_fold_kernel(const float *__restrict__ x, const float *__restrict__ labels,
+                                                          const float *__restrict__ weights,
+                                                          const float *__restrict__ nnz, float *__restrict__ xfold,
+                                                          float *__restrict__ loss_part, int N, int C, int Hi, int Wi,
+                                                          int Ho, int Wo, float sy, float sx) {
+  constexpr int MAXC = 32;
+  extern __shared__ float fold_tile[];  // [Wo][C]
+  __shared__ float red[4];
+  const float inv_nnz = 1.f / fmaxf(*nnz, 1.f);
+  float lsum = 0.f;
+  for (int row = blockIdx.x; row < N * Ho; row += gridDim.x) {
+    const int n = row / Ho, oy = row - n * Ho;
+    const Lerp ly = tf1_lerp(oy, sy, Hi);
+    const float *b = x + (size_t)n * Hi * Wi * C;
+    for (int ox = threadIdx.x; ox < Wo; ox += 256) {
+      const Lerp lx = tf1_lerp(ox, sx, Wi);
+      const float *tl = b + ((size_t)ly.lo * Wi + lx.lo) * C, *tr = b + ((size_t)ly.lo * Wi + lx.hi) * C;
+      const float *bl = b + ((size_t)ly.hi * Wi + lx.lo) * C, *br = b + ((size_t)ly.hi * Wi + lx.hi) * C;
+      float z[MAXC];
+#pragma unroll
+      for (int c = 0; c < MAXC; c++) {
+        const int cc = min(c, C - 1);
+        const float top = tl[cc] + (tr[cc] - tl[cc]) * lx.w;
+        const float bot = bl[cc] + (br[cc] - bl[cc]) * lx.w;
+        z[c] = top + (bot - top) * ly.w;
+      }
+      float mx = z[0];
+#pragma unroll
+      for (int c = 1; c < MAXC; c++) mx = fmaxf(mx, (c < C) ? z[c] : z[0]);
+      float ssum = 0.f;
+#pragma unroll
+      for (int c = 0; c < MAXC; c++) {
+        z[c] = (c < C) ? expf(z[c] - mx) : 0.f;
+        ssum += z[c];
+      }
+      const float inv = 1.f / ssum;
+      const size_t m = (size_t)row * Wo + ox;
+      const int t = (int)labels[m];
+      const float w = weights ? weights[m] : 1.f;
+      float psum = 0.f, pt = 0.f;
+#pragma unroll
+      for (int c = 0; c < MAXC; c++) {
+        z[c] *= inv;
+        psum += z[c];
+        pt = (c == t) ? z[c] : pt;
+      }
+      if (t >= 0 && t < C) {
+        float q = pt / psum;
+        q = fminf(fmaxf(q, 1e-7f), 1.f - 1e-7f);
+        lsum += -logf(q) * w * inv_nnz;
+      }
+      const float gs = w * inv_nnz;
+#pragma unroll
+      for (int c = 0; c < MAXC; c++)
+        if (c < C) fold_tile[ox * C + c] = (z[c] - (c == t ? 1.f : 0.f)) * gs;
+    }
+    __syncthreads();
+    float *orow = xfold + (size_t)row * Wi * C;
+    for (int i = threadIdx.x; i < Wi * C; i += 256) {
+      const int ix = i / C, c = i - ix * C;
+      int ox0 = (int)floorf((float)(ix - 1) / sx) - 1, ox1 = (int)ceilf((float)(ix + 1) / sx) + 1;
+      ox0 = max(ox0, 0);
+      ox1 = min(ox1, Wo - 1);
+      float acc = 0.f;
+      for (int ox = ox0; ox <= ox1; ++ox) {
+        const Lerp lx = tf1_lerp(ox, sx, Wi);
+        const float wx = (lx.lo == ix ? 1.f - lx.w : 0.f) + (lx.hi == ix ? lx.w : 0.f);
+        acc += wx * fold_tile[ox * C + c];
+      }
+      orow[i] = acc;
+    }
+    __syncthreads();
+  }
+  lsum = wave_sum(lsum);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) loss_part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
 inline int ew_blocks(size_t n) {
   size_t b = (n + 255) / 256;
   if (b > 8192) b = 8192;
@@ -374,6 +458,19 @@ extern "C" int dl3_resize_bilinear_bwd(const float *dy, int lddy, float *dx, int
   hipLaunchKernelGGL(resize_bwd_kernel, dim3(gx, N * Hi), dim3(256), 0, (hipStream_t)stream, dy, lddy, dx, lddx, N,
                      Hi, Wi, Ho, Wo, C, sy, sx, accumulate);
   DL3_LAUNCH_CHECK("resize_bwd");
+  return DL3_OK;
+}
+
+extern "C" int dl3_resize_bilinear_bwd_rows(const float *xfold, float *dx, int lddx, int N, int Hi, int Wi, int Ho,
+                                            int C, int accumulate, void *stream) {
+  DL3_CHECK_ARG(xfold && dx && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && C > 0, "resize_bwd_rows: bad argument");
+  DL3_CHECK_ARG(lddx >= C, "resize_bwd_rows: leading dimension too small");
+  const float sy = (float)Hi / (float)Ho;
+  int gx = dl3_cdiv(Wi * C, 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(resize_bwd_y_kernel, dim3(gx, N * Hi), dim3(256), 0, (hipStream_t)stream, xfold, dx, lddx, Hi, Wi,
+                     Ho, C, sy, accumulate);
+  DL3_LAUNCH_CHECK("resize_bwd_rows");
   return DL3_OK;
 }
 
@@ -438,5 +535,27 @@ extern "C" int dl3_upsample_softmax_xent(const float *logits_lo, const float *la
   hipLaunchKernelGGL((xent32_kernel<true>), dim3(dl3_rows_partials((int)M)), dim3(256), 0, (hipStream_t)stream,
                      logits_lo, labels, weights, nnz, probs, dlogits, loss_partial, M, C, Hi, Wi, Ho, Wo, sy, sx);
   DL3_LAUNCH_CHECK("upsample_softmax_xent");
+  return DL3_OK;
+}
+
+extern "C" int dl3_xent_fold_partials(int N, int Ho) {
+  const long rows = (long)N * Ho;
+  if (rows <= 0) return 0;
+  return (int)(rows < 4096 ? rows : 4096);
+}
+
+extern "C" int dl3_upsample_softmax_xent_fold(const float *logits_lo, const float *labels, const float *weights,
+                                              const float *nnz, float *dlogits_xfold, float *loss_partial, int N,
+                                              int Hi, int Wi, int Ho, int Wo, int C, void *stream) {
+  DL3_CHECK_ARG(logits_lo && labels && nnz && dlogits_xfold && loss_partial && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 &&
+                    Wo > 0 && C > 0,
+                "upsample_softmax_xent_fold: bad argument");
+  DL3_UNSUPPORTED(C > 32, "upsample_softmax_xent_fold: C=%d > 32", C);
+  const size_t lds = (size_t)Wo * C * sizeof(float);
+  DL3_UNSUPPORTED(lds > 64 * 1024, "upsample_softmax_xent_fold: output row of %d x %d floats exceeds 64 KB of LDS", Wo, C);
+  const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+  hipLaunchKernelGGL(xent32_fold_kernel, dim3(dl3_xent_fold_partials(N, Ho)), dim3(256), lds, (hipStream_t)stream,
+                     logits_lo, labels, weights, nnz, dlogits_xfold, loss_partial, N, C, Hi, Wi, Ho, Wo, sy, sx);
+  DL3_LAUNCH_CHECK("upsample_softmax_xent_fold");
   return DL3_OK;
 }

@@ -14,6 +14,7 @@ Design (MI355X-first):
 Reference call stack being replaced: Keras Model.predict / train_on_batch -> TF Session.run.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -95,6 +96,7 @@ class Engine:
         self.seed = int(seed)
         self.device = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
         self.use_graph = use_graph
+        self.fold_tail = os.environ.get("DL3_FOLD_TAIL", "1") != "0"  # 0: keep the full-resolution dlogits (test aid)
         self.dw_impl = dw_impl
         self.ops_prep, self.ops_fwd, self.ops_bwd = [], [], []
         self.units = []
@@ -507,13 +509,24 @@ class Engine:
         buf = v.buf
         M, C = buf.M, v.C
         # loss + dlogits (first and only contribution to the logits buffer)
-        buf.grad = self.empty(M * buf.ld)
         self.op(self.ops_fwd, "dl3_count_nonzero", ptr(self.sweights), M, ptr(self.nnz))
-        if self.fused_tail is not None:
+        if self.fused_tail is not None and buf.W * C * 4 <= 65536 and self.fold_tail:
+            # the full-resolution gradient never exists: the loss kernel folds each output row onto the low-resolution
+            # columns, the resize unit's backward folds the rows
+            lo = self.fused_tail.inv
+            self.lossP = self.lib.dl3_xent_fold_partials(self.B, buf.H)
+            self.loss_part = self.zeros(self.lossP)
+            self.fused_tail.xfold = self.empty(self.B * buf.H * lo.buf.W * C)
+            self.op(self.ops_fwd, "dl3_upsample_softmax_xent_fold", lo.p(), ptr(self.labels), ptr(self.sweights),
+                    ptr(self.nnz), ptr(self.fused_tail.xfold), ptr(self.loss_part), self.B, lo.buf.H, lo.buf.W, buf.H,
+                    buf.W, C)
+        elif self.fused_tail is not None:
+            buf.grad = self.empty(M * buf.ld)
             lo = self.fused_tail.inv
             self.op(self.ops_fwd, "dl3_upsample_softmax_xent", lo.p(), ptr(self.labels), ptr(self.sweights),
                     ptr(self.nnz), None, ptr(buf.grad), ptr(self.loss_part), self.B, lo.buf.H, lo.buf.W, buf.H, buf.W, C)
         else:
+            buf.grad = self.empty(M * buf.ld)
             self.op(self.ops_fwd, "dl3_softmax_xent", ptr(buf.t), ptr(self.labels), ptr(self.sweights), ptr(self.nnz),
                     None, ptr(buf.grad), ptr(self.loss_part), M, C)
         self.op(self.ops_fwd, "dl3_reduce_partials", ptr(self.loss_part), self.lossP, 1, ptr(self.loss))
@@ -992,6 +1005,15 @@ class ResizeUnit:
         if not ibuf.requires_grad:
             return
         B, Hi, Wi, Ho, Wo, C = self.dims
+        xfold = getattr(self, "xfold", None)
+        if xfold is not None:
+            # fused training tail: the loss kernel already folded the output columns (dl3_upsample_softmax_xent_fold)
+            gout, add, last = eng.contrib_kernel(ibuf)
+            eng.op(eng.ops_bwd, "dl3_resize_bilinear_bwd_rows", ptr(xfold), ptr(gout), ibuf.ld, B, Hi, Wi, Ho, C,
+                   1 if add is not None else 0)
+            if add is not None and add is not gout:
+                raise NotImplementedError("resize backward with a foreign addend")
+            return
         g = outv.buf.grad.data_ptr() + 4 * outv.off
         plain = inv.act == ACT_NONE and not ibuf.bns and inv.off == 0 and inv.C == ibuf.ld
         if Hi == 1 and Wi == 1:

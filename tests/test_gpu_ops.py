@@ -535,6 +535,41 @@ def test_fused_upsample_xent(L):
     assert abs(host(lp).astype(np.float64).sum() - loss_ref) < 1e-5 * abs(loss_ref)
 
 
+@pytest.mark.parametrize("dims", [(2, 8, 8, 64, 64, 21), (1, 5, 7, 17, 23, 3), (3, 16, 16, 64, 64, 32), (2, 4, 4, 4, 4, 2)])
+def test_xent_fold_and_rows(L, dims):
+    """dl3_upsample_softmax_xent_fold + dl3_resize_bilinear_bwd_rows == the oracle's loss and the gradient it sends
+    through the transposed legacy-bilinear resize, without the full-resolution dlogits"""
+    N, Hi, Wi, Ho, Wo, C = dims
+    rng = np.random.default_rng(26)
+    lo = rng.normal(0, 2, (N, Hi, Wi, C))
+    M = N * Ho * Wo
+    labels = rng.integers(0, C + 1, M).astype(np.float32)
+    w = ((labels < C) * rng.uniform(0.5, 2, M)).astype(np.float32)
+    tape = O.Tape()
+    up = O.resize_bilinear_tf1(lo, Ho, Wo, tape=tape)
+    loss_ref, dl_ref, _ = O.loss_sparse_xent_ignoring_last_label(up.reshape(1, M, C), labels[None], w.astype(np.float64)[None])
+    dlo_ref = tape.backward(up, dl_ref.reshape(up.shape))[id(lo)]
+    nnz = empty(1)
+    call("dl3_count_nonzero", ptr(dev(w)), M, ptr(nnz))
+    P = L.dl3_xent_fold_partials(N, Ho)
+    xfold, lp, dlo = empty(N, Ho, Wi, C), empty(P), empty(N, Hi, Wi, C)
+    call("dl3_upsample_softmax_xent_fold", ptr(dev(lo)), ptr(dev(labels)), ptr(dev(w)), ptr(nnz), ptr(xfold), ptr(lp), N, Hi,
+         Wi, Ho, Wo, C)
+    call("dl3_resize_bilinear_bwd_rows", ptr(xfold), ptr(dlo), C, N, Hi, Wi, Ho, C, 0)
+    assert abs(host(lp).astype(np.float64).sum() - loss_ref) < 1e-5 * abs(loss_ref)
+    assert relerr(host(dlo), dlo_ref) < 1e-4
+    # accumulate form, and agreement with the unfused pair of ops
+    base = rng.normal(0, 1, (N, Hi, Wi, C)).astype(np.float32)
+    acc = dev(base)
+    call("dl3_resize_bilinear_bwd_rows", ptr(xfold), ptr(acc), C, N, Hi, Wi, Ho, C, 1)
+    assert relerr(host(acc), base + dlo_ref) < 1e-4
+    dl, lp2, dlo2 = empty(M, C), empty(L.dl3_rows_partials(M)), empty(N, Hi, Wi, C)
+    call("dl3_upsample_softmax_xent", ptr(dev(lo)), ptr(dev(labels)), ptr(dev(w)), ptr(nnz), None, ptr(dl), ptr(lp2),
+         N, Hi, Wi, Ho, Wo, C)
+    call("dl3_resize_bilinear_bwd", ptr(dl), C, ptr(dlo2), C, N, Hi, Wi, Ho, Wo, C, 0, None, 0)
+    assert relerr(host(dlo), host(dlo2)) < 1e-5
+
+
 def test_adam_fill(L):
     rng = np.random.default_rng(14)
     n = 10001
