@@ -206,7 +206,8 @@ int dl3_upsample_softmax_xent(const float *logits_lo, const float *labels, const
 /* the training tail without the full-resolution gradient: loss as above, and the x half of the transposed resize
  * applied on chip — dlogits_xfold [N,Ho,Wi,C] = sum over the output columns of each output row (fixed order);
  * dl3_resize_bilinear_bwd_rows folds the rows (the y half) into dx [N,Hi,Wi,C].  loss_partial has
- * P = dl3_xent_fold_partials(N, Ho) entries.  C <= 32 and Wo*C*4 <= 64 KB (one output row lives in LDS). */
+ * P = dl3_xent_fold_partials(N, Ho) entries.  C <= 32 and (Wo + 2*Wi)*C*4 <= 64 KB (an output row and its two
+ * source rows live in LDS). */
 int dl3_xent_fold_partials(int N, int Ho);
 int dl3_upsample_softmax_xent_fold(const float *logits_lo, const float *labels, const float *weights, const float *nnz,
                                    float *dlogits_xfold, float *loss_partial, int N, int Hi, int Wi, int Ho, int Wo,

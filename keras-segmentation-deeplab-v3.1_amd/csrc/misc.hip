@@ -328,24 +328,39 @@ __global__ __launch_bounds__(256) void xent32_kernel(const float *__restrict__ x
 // phase 2 folds the row onto the Wi input columns (the x half of the transposed bilinear resize, fixed summation
 // order).  The full-resolution dlogits [N,Ho,Wo,C] (704 MB at 32x512x512x21) never exist: the kernel writes the
 // x-folded rows [N,Ho,Wi,C] (8x smaller) and dl3_resize_bilinear_bwd_rows finishes with the y half.
+// The two low-resolution logit rows an output row interpolates between are staged in LDS first: the 4 x C neighbour
+// reads per pixel then come from LDS instead of the texture-address path (8 neighbouring pixels share them).
+template <int MAXC>
 __global__ __launch_bounds__(256) void xent32_fold_kernel(const float *__restrict__ x, const float *__restrict__ labels,
                                                           const float *__restrict__ weights,
                                                           const float *__restrict__ nnz, float *__restrict__ xfold,
                                                           float *__restrict__ loss_part, int N, int C, int Hi, int Wi,
                                                           int Ho, int Wo, float sy, float sx) {
-  constexpr int MAXC = 32;
-  extern __shared__ float fold_tile[];  // [Wo][C]
+  extern __shared__ float fold_tile[];  // [Wo][C] dlogits of the row, [2][Wi][C] source rows, [Wo] x lerp table
   __shared__ float red[4];
+  float *src = fold_tile + (size_t)Wo * C;
+  float *xw = src + 2 * (size_t)Wi * C;  // fractional x weight of every output column
+  int *xlo = (int *)(xw + Wo);           // its lower source column
+  for (int ox = threadIdx.x; ox < Wo; ox += 256) {
+    const Lerp lx = tf1_lerp(ox, sx, Wi);
+    xw[ox] = lx.w;
+    xlo[ox] = lx.lo;
+  }
   const float inv_nnz = 1.f / fmaxf(*nnz, 1.f);
   float lsum = 0.f;
   for (int row = blockIdx.x; row < N * Ho; row += gridDim.x) {
     const int n = row / Ho, oy = row - n * Ho;
     const Lerp ly = tf1_lerp(oy, sy, Hi);
     const float *b = x + (size_t)n * Hi * Wi * C;
+    for (int i = threadIdx.x; i < Wi * C; i += 256) {
+      src[i] = b[(size_t)ly.lo * Wi * C + i];
+      src[Wi * C + i] = b[(size_t)ly.hi * Wi * C + i];
+    }
+    __syncthreads();
     for (int ox = threadIdx.x; ox < Wo; ox += 256) {
       const Lerp lx = tf1_lerp(ox, sx, Wi);
-      const float *tl = b + ((size_t)ly.lo * Wi + lx.lo) * C, *tr = b + ((size_t)ly.lo * Wi + lx.hi) * C;
-      const float *bl = b + ((size_t)ly.hi * Wi + lx.lo) * C, *br = b + ((size_t)ly.hi * Wi + lx.hi) * C;
+      const float *tl = src + lx.lo * C, *tr = src + lx.hi * C;
+      const float *bl = src + (Wi + lx.lo) * C, *br = src + (Wi + lx.hi) * C;
       float z[MAXC];
 #pragma unroll
       for (int c = 0; c < MAXC; c++) {
@@ -360,7 +375,7 @@ __global__ __launch_bounds__(256) void xent32_fold_kernel(const float *__restric
       float ssum = 0.f;
 #pragma unroll
       for (int c = 0; c < MAXC; c++) {
-        z[c] = (c < C) ? expf(z[c] - mx) : 0.f;
+        z[c] = (c < C) ? __expf(z[c] - mx) : 0.f;
         ssum += z[c];
       }
       const float inv = 1.f / ssum;
@@ -385,19 +400,28 @@ __global__ __launch_bounds__(256) void xent32_fold_kernel(const float *__restric
         if (c < C) fold_tile[ox * C + c] = (z[c] - (c == t ? 1.f : 0.f)) * gs;
     }
     __syncthreads();
+    // x fold: work item = (input column, group of 3 channels); the lerp of an output column comes from the table
     float *orow = xfold + (size_t)row * Wi * C;
-    for (int i = threadIdx.x; i < Wi * C; i += 256) {
-      const int ix = i / C, c = i - ix * C;
+    const int CG = (C + 2) / 3;
+    for (int i = threadIdx.x; i < Wi * CG; i += 256) {
+      const int ix = i / CG, c0 = (i - ix * CG) * 3;
       int ox0 = (int)floorf((float)(ix - 1) / sx) - 1, ox1 = (int)ceilf((float)(ix + 1) / sx) + 1;
       ox0 = max(ox0, 0);
       ox1 = min(ox1, Wo - 1);
-      float acc = 0.f;
+      const int c1 = min(c0 + 1, C - 1), c2 = min(c0 + 2, C - 1);
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
       for (int ox = ox0; ox <= ox1; ++ox) {
-        const Lerp lx = tf1_lerp(ox, sx, Wi);
-        const float wx = (lx.lo == ix ? 1.f - lx.w : 0.f) + (lx.hi == ix ? lx.w : 0.f);
-        acc += wx * fold_tile[ox * C + c];
+        const int lo = xlo[ox], hi = min(lo + 1, Wi - 1);
+        const float w = xw[ox];
+        const float wx = (lo == ix ? 1.f - w : 0.f) + (hi == ix ? w : 0.f);
+        const float *t = fold_tile + ox * C;
+        a0 += wx * t[c0];
+        a1 += wx * t[c1];
+        a2 += wx * t[c2];
       }
-      orow[i] = acc;
+      orow[ix * C + c0] = a0;
+      if (c0 + 1 < C) orow[ix * C + c0 + 1] = a1;
+      if (c0 + 2 < C) orow[ix * C + c0 + 2] = a2;
     }
     __syncthreads();
   }
@@ -551,11 +575,16 @@ extern "C" int dl3_upsample_softmax_xent_fold(const float *logits_lo, const floa
                     Wo > 0 && C > 0,
                 "upsample_softmax_xent_fold: bad argument");
   DL3_UNSUPPORTED(C > 32, "upsample_softmax_xent_fold: C=%d > 32", C);
-  const size_t lds = (size_t)Wo * C * sizeof(float);
-  DL3_UNSUPPORTED(lds > 64 * 1024, "upsample_softmax_xent_fold: output row of %d x %d floats exceeds 64 KB of LDS", Wo, C);
+  const size_t lds = (((size_t)Wo + 2 * (size_t)Wi) * C + 2 * (size_t)Wo) * sizeof(float);
+  DL3_UNSUPPORTED(lds > 64 * 1024, "upsample_softmax_xent_fold: (%d + 2*%d) x %d floats exceed 64 KB of LDS", Wo, Wi, C);
   const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
-  hipLaunchKernelGGL(xent32_fold_kernel, dim3(dl3_xent_fold_partials(N, Ho)), dim3(256), lds, (hipStream_t)stream,
-                     logits_lo, labels, weights, nnz, dlogits_xfold, loss_partial, N, C, Hi, Wi, Ho, Wo, sy, sx);
+  const dim3 grid(dl3_xent_fold_partials(N, Ho));
+  if (C <= 24)
+    hipLaunchKernelGGL(xent32_fold_kernel<24>, grid, dim3(256), lds, (hipStream_t)stream, logits_lo, labels, weights, nnz,
+                       dlogits_xfold, loss_partial, N, C, Hi, Wi, Ho, Wo, sy, sx);
+  else
+    hipLaunchKernelGGL(xent32_fold_kernel<32>, grid, dim3(256), lds, (hipStream_t)stream, logits_lo, labels, weights, nnz,
+                       dlogits_xfold, loss_partial, N, C, Hi, Wi, Ho, Wo, sy, sx);
   DL3_LAUNCH_CHECK("upsample_softmax_xent_fold");
   return DL3_OK;
 }

@@ -510,7 +510,7 @@ class Engine:
         M, C = buf.M, v.C
         # loss + dlogits (first and only contribution to the logits buffer)
         self.op(self.ops_fwd, "dl3_count_nonzero", ptr(self.sweights), M, ptr(self.nnz))
-        if self.fused_tail is not None and buf.W * C * 4 <= 65536 and self.fold_tail:
+        if self.fused_tail is not None and ((buf.W + 2 * self.fused_tail.inv.buf.W) * C + 2 * buf.W) * 4 <= 65536 and self.fold_tail:
             # the full-resolution gradient never exists: the loss kernel folds each output row onto the low-resolution
             # columns, the resize unit's backward folds the rows
             lo = self.fused_tail.inv
