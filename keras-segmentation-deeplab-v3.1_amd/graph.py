@@ -540,4 +540,6 @@ class Model:
                 if isinstance(SW, dict):
                     SW = list(SW.values())[0]
                 hist.append(self.train_on_batch(X, Y, SW))
+            if hasattr(generator, "on_epoch_end"):
+                generator.on_epoch_end()
         return hist

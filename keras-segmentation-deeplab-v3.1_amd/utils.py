@@ -99,6 +99,41 @@ def prepare_targets(labels, n_classes=21):
     return Y, SW
 
 
+class SegmentationGenerator:
+    """The tensor contract of the reference's `SegmentationGenerator` (utils.py:257-409) over IN-MEMORY arrays:
+    `gen[i]` -> `(X [B,H,W,3] float32, Y [B,HW,1], {'pred_mask': SW [B,HW]})`, `len(gen)` batches, `on_epoch_end()`
+    reshuffles.  File I/O and the cv2 augmentation chain of the reference (utils.py:314-369) are out of scope: the caller
+    hands over decoded images (raw 0-255, as `self.X[n] = image`, utils.py:387) and raw label maps; the label half
+    (utils.py:371-400) runs on the device through dl3_prepare_targets, so Y and SW are cuda tensors that
+    `Model.fit_generator` / `train_on_batch` consume without a host round trip."""
+
+    def __init__(self, images, labels, n_classes=21, batch_size=1, seed=7, shuffle=True):
+        self.images = np.asarray(images)
+        self.labels = np.asarray(labels)
+        if self.images.ndim != 4 or self.images.shape[-1] != 3 or len(self.images) != len(self.labels):
+            raise Exception("images must be [N,H,W,3] and labels [N,H,W]")
+        self.n_classes = int(n_classes)
+        self.batch_size = int(batch_size)
+        self.shuffle = shuffle
+        self._rng = np.random.RandomState(seed)
+        self.order = np.arange(len(self.images))
+
+    def __len__(self):
+        return len(self.images) // self.batch_size
+
+    def __getitem__(self, i):
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        idx = self.order[i * self.batch_size:(i + 1) * self.batch_size]
+        X = np.ascontiguousarray(self.images[idx], dtype=np.float32)
+        Y, SW = prepare_targets(self.labels[idx], self.n_classes)
+        return X, Y, {"pred_mask": SW}
+
+    def on_epoch_end(self):
+        if self.shuffle:
+            self._rng.shuffle(self.order)
+
+
 class SegModel:
     """utils.py:160-254 — only model construction is on the path."""
     epochs = 20

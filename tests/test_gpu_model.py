@@ -365,3 +365,36 @@ def test_inference_graph_replay_matches_eager():
     q2 = model.predict(x2, batch_size=2)
     assert not np.array_equal(q2, q)
     assert np.array_equal(model._engine(2, False, use_graph=False).predict(x2), q2)
+
+
+def test_fit_generator_with_device_targets():
+    """SegmentationGenerator tensor contract (utils.py:257-409) over in-memory arrays: labels prepared on the device,
+    fit_generator consumes (X, Y, {'pred_mask': SW}); the batch content equals the oracle's label preparation."""
+    from dl3_amd import utils as U
+    C = 3
+    rng = np.random.default_rng(21)
+    imgs = rng.integers(0, 256, (6, 64, 64, 3)).astype(np.uint8)
+    labs = rng.choice([0, 1, 2, 255], (6, 64, 64), p=[0.5, 0.3, 0.15, 0.05]).astype(np.uint8)
+    gen = U.SegmentationGenerator(imgs, labs, n_classes=C, batch_size=2, shuffle=False)
+    assert len(gen) == 3
+    X, Y, sw = gen[1]
+    Yr, SWr, _ = O.prepare_targets(labs[2:4].reshape(2, -1), C)
+    assert X.dtype == np.float32 and X.shape == (2, 64, 64, 3) and np.array_equal(X, imgs[2:4])
+    assert np.array_equal(Y.cpu().numpy(), Yr) and np.array_equal(sw["pred_mask"].cpu().numpy(), SWr)
+    with pytest.raises(IndexError):
+        gen[3]
+    model, params = _build(input_shape=(64, 64, 3), classes=C)
+    _load(model, params)
+    model.compile(optimizer=dict(lr=7e-4, epsilon=1e-8, decay=1e-6))
+    hist = model.fit_generator(gen, epochs=2)
+    assert len(hist) == 6 and all(np.isfinite(hist)) and hist[-1] < hist[0]
+    # same losses as feeding the host-prepared tensors batch by batch
+    model2, _ = _build(input_shape=(64, 64, 3), classes=C)
+    _load(model2, params)
+    model2.compile(optimizer=dict(lr=7e-4, epsilon=1e-8, decay=1e-6))
+    ref = []
+    for _ in range(2):
+        for i in range(3):
+            Yh, SWh, _ = O.prepare_targets(labs[2 * i:2 * i + 2].reshape(2, -1), C)
+            ref.append(model2.train_on_batch(imgs[2 * i:2 * i + 2].astype(np.float32), Yh, SWh))
+    assert hist == ref
