@@ -352,13 +352,16 @@ __device__ __forceinline__ void stream_epilogue_full(const GemmArgs &P, const f3
 
 // FWD: the launch has no masked epilogue (no ep_x, stat_mode != 2, no per-image broadcast residual) — the forward
 // GEMMs; their interior tiles take the straight-line epilogue and the masked code is not compiled in at all.
-template <int TM, int TN, bool TWO, int KT, int EPI>
+// WN: waves side by side along N (4/WN stacked along M).  WN = 4 gives 32-row tiles for small M (batch 1-4: a
+// 128-row tile leaves most CUs idle and every workgroup a long serial K loop).
+template <int TM, int TN, bool TWO, int KT, int EPI, int WN = 1>
 __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
   // EPI: 0 generic epilogue only, 1 forward (see above).  A straight-line MASKED bwd-data variant was measured too:
   // on top of 80 accumulators its operand registers push long-lived values into scratch and it came out slower.
   constexpr bool FWD = (EPI == 1);
   // KT = depth of one K-tile: each half-wave walks KT/2 consecutive k (KT/8 float4 loads per lane and tensor)
-  constexpr int BM = 128 * TM, BN = 32 * TN, KH = KT / 2, NJ = KT / 8;
+  constexpr int WM = 4 / WN;
+  constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, KH = KT / 2, NJ = KT / 8;
   constexpr int LDB = BN;
   constexpr int NB = (KT * BN / 4 + 255) / 256;  // float4 B loads per thread per K-tile
   constexpr int KC = DL3_STREAM_KMAX + KT;       // per-k operand-transform coefficients live in LDS
@@ -374,8 +377,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
   const int n0 = bx * BN;
   const int ktiles = (P.K + KT - 1) / KT;
   const bool xform = (P.ka != nullptr);
-  constexpr int WM = 4;
-  const int wm = wave;
+  const int wm = wave / WN, wn = wave % WN;
+  const int nw0 = n0 + wn * TN * 32;  // first column of this wave's sub-tile
 
   float st1[TN], st2[TN];
 #pragma unroll
@@ -477,13 +480,13 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
       }
       float bf[2][TN];
 #pragma unroll
-      for (int j = 0; j < TN; j++) bf[0][j] = Bs[(KH * lhi) * LDB + j * 32 + l31];
+      for (int j = 0; j < TN; j++) bf[0][j] = Bs[(KH * lhi) * LDB + (wn * TN + j) * 32 + l31];
 #pragma unroll
       for (int s_ = 0; s_ < KH; ++s_) {
         const int cur = s_ & 1, nxt = cur ^ 1;
         if (s_ + 1 < KH) {
 #pragma unroll
-          for (int j = 0; j < TN; j++) bf[nxt][j] = Bs[(KH * lhi + s_ + 1) * LDB + j * 32 + l31];
+          for (int j = 0; j < TN; j++) bf[nxt][j] = Bs[(KH * lhi + s_ + 1) * LDB + (wn * TN + j) * 32 + l31];
         }
 #pragma unroll
         for (int i = 0; i < TM; i++)
@@ -504,14 +507,14 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
     // ---------------- epilogue (same C/D layout as the LDS-staged kernel)
     const bool full = (m0 + BM <= P.M) && (n0 + BN <= P.N);
     if (FWD && full) {
-      if (!P.ep_add) stream_epilogue_full<TM, TN, false, false, false>(P, acc, m0, n0, wm, l31, lhi, st1, st2);
-      else stream_epilogue_full<TM, TN, false, true, false>(P, acc, m0, n0, wm, l31, lhi, st1, st2);
+      if (!P.ep_add) stream_epilogue_full<TM, TN, false, false, false>(P, acc, m0, nw0, wm, l31, lhi, st1, st2);
+      else stream_epilogue_full<TM, TN, false, true, false>(P, acc, m0, nw0, wm, l31, lhi, st1, st2);
       continue;
     }
     // everything else: generic path, every element predicated
 #pragma unroll
     for (int j = 0; j < TN; j++) {
-      const int col = n0 + j * 32 + l31;
+      const int col = nw0 + j * 32 + l31;
       const bool cok = col < P.N;
       const int colc = min(col, P.N - 1);
       float bias = 0.f, es = 1.f, et = 0.f, mu = 0.f, is = 0.f;
@@ -568,8 +571,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
       float a1 = st1[j] + __shfl_xor(st1[j], 32, 64);
       float a2 = st2[j] + __shfl_xor(st2[j], 32, 64);
       if (lhi == 0) {
-        sred[(wm * BN + j * 32 + l31) * 2 + 0] = a1;
-        sred[(wm * BN + j * 32 + l31) * 2 + 1] = a2;
+        sred[(wm * BN + (wn * TN + j) * 32 + l31) * 2 + 0] = a1;
+        sred[(wm * BN + (wn * TN + j) * 32 + l31) * 2 + 1] = a2;
       }
     }
     __syncthreads();
@@ -807,23 +810,31 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
 
 // ---- configuration choice -------------------------------------------------------------
 struct GemmCfg { int id, BM, BN; };
-const GemmCfg kGemmCfgs[] = {{0, 128, 128}, {1, 256, 64}, {2, 256, 32}, {3, 128, 160}, {4, 128, 96}};
+const GemmCfg kGemmCfgs[] = {{0, 128, 128}, {1, 256, 64}, {2, 256, 32}, {3, 128, 160}, {4, 128, 96},
+                             {5, 32, 256},  {6, 32, 128}};  // 5, 6: four waves side by side, for small M
+constexpr int kNumGemmCfgs = 7;
 
 int env_int(const char *name) {
   const char *e = getenv(name);
   return e ? atoi(e) : -1;
 }
 
-GemmCfg pick_gemm(int M, int K, int N, bool two) {
+// small: the 32-row configurations may be chosen (they exist for the stream kernel only)
+GemmCfg pick_gemm(int M, int K, int N, bool two, bool small) {
   const int forced = env_int("DL3_GEMM_CFG");  // tuning aid (tools/gemm_tune.py)
-  if (forced >= 0 && forced < 5) return kGemmCfgs[forced];
+  if (forced >= 0 && forced < kNumGemmCfgs && (small || kGemmCfgs[forced].BM != 32)) return kGemmCfgs[forced];
   double best = 1e30;
   GemmCfg bc = kGemmCfgs[0];
   for (const GemmCfg &c : kGemmCfgs) {
+    if (c.BM == 32 && !small) continue;
     // measured on MI355X (tools/gemm_tune.py): ~80 TFLOP/s sustained fp32 MFMA, ~3 TB/s streaming; re-reads of A by
     // the other column tiles of a row tile are L2 hits thanks to the XCD remap (charged at 1/4)
     const double ntn = dl3_cdiv(N, c.BN), mp = (double)dl3_cdiv(M, c.BM) * c.BM;
-    const double t_mfma = 2.0 * mp * K * ntn * c.BN / 80e12;
+    // fewer workgroups than the chip holds (2 per CU) leave matrix pipes idle; the 32-row configs pay ~15 % more
+    // per MFMA (every wave re-reads the shared A rows through L1) and are for exactly that case
+    const double blocks = (double)dl3_cdiv(M, c.BM) * ntn;
+    const double util = blocks < 512.0 ? blocks / 512.0 : 1.0;
+    const double t_mfma = 2.0 * mp * K * ntn * c.BN / 80e12 / util * (c.BM == 32 ? 1.15 : 1.0);
     const double t_mem = 4.0 * ((double)M * K * (1.0 + 0.25 * (ntn - 1)) * (two ? 2 : 1) + (double)M * N) / 3e12;
     const double cost = (t_mfma > t_mem ? t_mfma : t_mem) + 0.25 * (t_mfma + t_mem);
     if (cost < best) { best = cost; bc = c; }
@@ -850,36 +861,39 @@ void launch_gemm(const GemmArgs &A, dim3 grid, hipStream_t st, bool vec) {
 
 inline bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
+// returns the number of stat partial rows the launch writes (= grid.y)
 int run_gemm(GemmArgs A, hipStream_t st) {
   const bool two = A.a2 != nullptr;
-  const GemmCfg c = pick_gemm(A.M, A.K, A.N, two);
-  A.mtiles = dl3_cdiv(A.M, c.BM);
-  dim3 grid(dl3_cdiv(A.N, c.BN), gemm_grid_y(A.M, A.N, c));
   const bool avec = (A.K % 4 == 0) && (A.lda % 4 == 0) && al16(A.a) && (!two || ((A.lda2 % 4 == 0) && al16(A.a2)));
   const bool bvec = (A.N % 4 == 0) && (A.ldb % 4 == 0) && al16(A.b);
   const bool vec = avec && bvec;
+  const bool stream = vec && env_int("DL3_GEMM_IMPL") != 0 && A.K <= DL3_STREAM_KMAX;
+  const GemmCfg c = pick_gemm(A.M, A.K, A.N, two, stream);
+  A.mtiles = dl3_cdiv(A.M, c.BM);
+  dim3 grid(dl3_cdiv(A.N, c.BN), gemm_grid_y(A.M, A.N, c));
   // stream-A kernel: 10-25 % faster than the LDS-staged kernel on every layer shape, forward and bwd-data
   // (tools/gemm_tune.py).  The two-tensor bwd-data operand uses 16-deep K-tiles so that its register budget does not
   // spill.  DL3_GEMM_IMPL=0 forces the staged kernel (which also serves unaligned operands).
-  const int impl = env_int("DL3_GEMM_IMPL");
-  if (vec && impl != 0 && A.K <= DL3_STREAM_KMAX) {
+  if (stream) {
     dim3 blk(256);
     const bool fwd = !two && !A.ep_x && A.stat_mode != 2 && !(A.ep_add && A.add_div > 1);
-#define DL3_STREAM(TM_, TN_)                                                                                    \
-  do {                                                                                                          \
-    if (two) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, true, 16, 0>), grid, blk, 0, st, A);      \
-    else if (fwd) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, 16, 1>), grid, blk, 0, st, A);     \
-    else hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, 16, 0>), grid, blk, 0, st, A);              \
+#define DL3_STREAM(TM_, TN_, WN_)                                                                                    \
+  do {                                                                                                               \
+    if (two) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, true, 16, 0, WN_>), grid, blk, 0, st, A);           \
+    else if (fwd) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, 16, 1, WN_>), grid, blk, 0, st, A);     \
+    else hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, 16, 0, WN_>), grid, blk, 0, st, A);              \
   } while (0)
     switch (c.id) {
-      case 0: DL3_STREAM(1, 4); break;
-      case 1: DL3_STREAM(2, 2); break;
-      case 2: DL3_STREAM(2, 1); break;
-      case 3: DL3_STREAM(1, 5); break;
-      default: DL3_STREAM(1, 3); break;
+      case 0: DL3_STREAM(1, 4, 1); break;
+      case 1: DL3_STREAM(2, 2, 1); break;
+      case 2: DL3_STREAM(2, 1, 1); break;
+      case 3: DL3_STREAM(1, 5, 1); break;
+      case 5: DL3_STREAM(1, 2, 4); break;
+      case 6: DL3_STREAM(1, 1, 4); break;
+      default: DL3_STREAM(1, 3, 1); break;
     }
 #undef DL3_STREAM
-    return DL3_OK;
+    return (int)grid.y;
   }
   switch (c.id) {
     case 0: launch_gemm<2, 2, 2, 2>(A, grid, st, vec); break;
@@ -888,7 +902,7 @@ int run_gemm(GemmArgs A, hipStream_t st) {
     case 3: launch_gemm<1, 5, 4, 1>(A, grid, st, vec); break;
     default: launch_gemm<1, 3, 4, 1>(A, grid, st, vec); break;
   }
-  return DL3_OK;
+  return (int)grid.y;
 }
 
 struct WgCfg { int id, BKT, BNT; };
@@ -947,9 +961,13 @@ extern "C" int dl3_reduce_partials(const float *partial, int P, int n, float *ou
 extern "C" int dl3_pwconv_partials(int M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0) return 0;
   // the stat partial row count must not depend on which operand form is used: take the max
-  const GemmCfg c1 = pick_gemm(M, K, N, false), c2 = pick_gemm(M, K, N, true);
-  const int p1 = gemm_grid_y(M, N, c1), p2 = gemm_grid_y(M, N, c2);
-  return p1 > p2 ? p1 : p2;
+  int p = 0;
+  for (int two = 0; two < 2; two++)
+    for (int small = 0; small < 2; small++) {
+      const int q = gemm_grid_y(M, N, pick_gemm(M, K, N, two != 0, small != 0));
+      p = q > p ? q : p;
+    }
+  return p;
 }
 
 static int gemm_common_check(const char *name, int M, int K, int N) {
@@ -981,11 +999,8 @@ extern "C" int dl3_pwconv_fwd(const float *x, int ldx, const float *in_scale, co
   A.stat_mode = stat_partial ? 1 : 0;
   A.part = stat_partial;
   hipStream_t st = (hipStream_t)stream;
-  run_gemm(A, st);
-  if (stat_partial) {
-    const GemmCfg c = pick_gemm(M, K, N, false);
-    pad_partials(stat_partial, M, K, N, gemm_grid_y(M, N, c), st);
-  }
+  const int written = run_gemm(A, st);
+  if (stat_partial) pad_partials(stat_partial, M, K, N, written, st);
   DL3_LAUNCH_CHECK("pwconv_fwd");
   return DL3_OK;
 }
@@ -1018,11 +1033,8 @@ extern "C" int dl3_pwconv_bwd_data(const float *g, int ldg, const float *yraw, i
   A.ep_mean = x_mean; A.ep_invstd = x_invstd;
   A.part = dstat_partial;
   hipStream_t st = (hipStream_t)stream;
-  run_gemm(A, st);
-  if (dstat_partial) {
-    const GemmCfg c = pick_gemm(M, N, K, A.a2 != nullptr);
-    pad_partials(dstat_partial, M, N, K, gemm_grid_y(M, K, c), st);
-  }
+  const int written = run_gemm(A, st);
+  if (dstat_partial) pad_partials(dstat_partial, M, N, K, written, st);
   DL3_LAUNCH_CHECK("pwconv_bwd_data");
   return DL3_OK;
 }

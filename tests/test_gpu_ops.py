@@ -186,6 +186,17 @@ def test_pwconv_fwd(L, case):
     assert relerr(s2, (ref ** 2).sum(0)) < 1e-3
 
 
+@pytest.mark.parametrize("cfg", range(7))
+def test_pwconv_every_tile_configuration(L, cfg, monkeypatch):
+    """the automatic choice depends on the shape (32-row tiles for small M, 128/256-row tiles otherwise): force every
+    tile configuration of the stream kernel over the same forward and bwd-data cases"""
+    monkeypatch.setenv("DL3_GEMM_CFG", str(cfg))
+    test_pwconv_fwd(L, (1000, 160, 960, 0, 0, False, 2))
+    test_pwconv_fwd(L, (96, 64, 384, 64, 0, True, None))
+    test_pwconv_bwd_data(L, (520, 160, 960, 2, True, 1, True))
+    test_pwconv_bwd_data(L, (256, 320, 256, None, True, 2, True))
+
+
 BD_CASES = [
     # M, K, N, act, two-tensor, add mode (0 none, 1 tensor, 2 broadcast), stats
     (256, 16, 96, 2, True, 1, True),
