@@ -909,27 +909,6 @@ struct WgCfg { int id, BKT, BNT; };
 const WgCfg kWgCfgs[] = {{0, 64, 64},  {1, 128, 128}, {2, 160, 128}, {3, 128, 160}, {4, 64, 128},
                          {5, 128, 64}, {6, 32, 128},  {7, 128, 32},  {8, 96, 128},  {9, 128, 96}};
 
-WgCfg pick_wgrad(int M, int K, int N, bool two) {
-  const int forced = env_int("DL3_WGRAD_CFG");
-  if (forced >= 0 && forced < 10) return kWgCfgs[forced];
-  // measured shortcuts (tools/gemm_tune.py, MI355X): small weight matrices want the 64x64 tile (more workgroups per
-  // M split), 160-multiples want the 160-wide tiles so the big operand is read once
-  if (K >= 32 && N >= 32 && (long)K * N <= 32768) return kWgCfgs[0];
-  if (N % 160 == 0 && K >= 128 && K % 160 != 0) return kWgCfgs[3];
-  if (K % 160 == 0 && K % 128 != 0 && N >= 128 && N % 160 != 0) return kWgCfgs[2];
-  double best = 1e30;
-  WgCfg bc = kWgCfgs[0];
-  for (const WgCfg &c : kWgCfgs) {
-    const double ntk = dl3_cdiv(K, c.BKT), ntn = dl3_cdiv(N, c.BNT);
-    const double t_mfma = 2.0 * M * ntk * c.BKT * ntn * c.BNT / 80e12;
-    const double t_mem = 4.0 * ((double)M * K * (1.0 + 0.25 * (ntn - 1)) +
-                                (double)M * N * (1.0 + 0.25 * (ntk - 1)) * (two ? 2 : 1)) / 3e12;
-    const double cost = (t_mfma > t_mem ? t_mfma : t_mem) + 0.25 * (t_mfma + t_mem);
-    if (cost < best) { best = cost; bc = c; }
-  }
-  return bc;
-}
-
 int wgrad_splits(int M, int K, int N, const WgCfg &c) {
   const long tiles = (long)dl3_cdiv(K, c.BKT) * dl3_cdiv(N, c.BNT);
   long S = 1024 / tiles;
@@ -939,6 +918,32 @@ int wgrad_splits(int M, int K, int N, const WgCfg &c) {
   if (S > cap_rows) S = cap_rows;
   if (S < 1) S = 1;
   return (int)S;
+}
+
+WgCfg pick_wgrad(int M, int K, int N, bool two) {
+  const int forced = env_int("DL3_WGRAD_CFG");
+  if (forced >= 0 && forced < 10) return kWgCfgs[forced];
+  // measured shortcuts (tools/gemm_tune.py, MI355X, M >= 32k rows): small weight matrices want the 64x64 tile (more
+  // workgroups per M split), 160-multiples want the 160-wide tiles so the big operand is read once
+  if (M >= 32768) {
+    if (K >= 32 && N >= 32 && (long)K * N <= 32768) return kWgCfgs[0];
+    if (N % 160 == 0 && K >= 128 && K % 160 != 0) return kWgCfgs[3];
+    if (K % 160 == 0 && K % 128 != 0 && N >= 128 && N % 160 != 0) return kWgCfgs[2];
+  }
+  double best = 1e30;
+  WgCfg bc = kWgCfgs[0];
+  for (const WgCfg &c : kWgCfgs) {
+    const double ntk = dl3_cdiv(K, c.BKT), ntn = dl3_cdiv(N, c.BNT);
+    // few rows: the M split is capped (partial-slab traffic), so small tiles are what fills the chip
+    const double blocks = ntk * ntn * wgrad_splits(M, K, N, c);
+    const double util = blocks < 512.0 ? blocks / 512.0 : 1.0;
+    const double t_mfma = 2.0 * M * ntk * c.BKT * ntn * c.BNT / 80e12 / util;
+    const double t_mem = 4.0 * ((double)M * K * (1.0 + 0.25 * (ntn - 1)) +
+                                (double)M * N * (1.0 + 0.25 * (ntk - 1)) * (two ? 2 : 1)) / 3e12;
+    const double cost = (t_mfma > t_mem ? t_mfma : t_mem) + 0.25 * (t_mfma + t_mem);
+    if (cost < best) { best = cost; bc = c; }
+  }
+  return bc;
 }
 
 int colsum_rows(int M) {
