@@ -398,3 +398,34 @@ def test_fit_generator_with_device_targets():
             Yh, SWh, _ = O.prepare_targets(labs[2 * i:2 * i + 2].reshape(2, -1), C)
             ref.append(model2.train_on_batch(imgs[2 * i:2 * i + 2].astype(np.float32), Yh, SWh))
     assert hist == ref
+
+
+@pytest.mark.parametrize("shape", [(65, 49, 3), (72, 56, 3)])
+def test_odd_and_non_square_inputs(shape):
+    """input sizes that are not multiples of the output stride (DeepLab's classic 513 = 8k+1) and non-square maps:
+    SAME padding with an odd extent, ceil-mode feature sizes, legacy bilinear between arbitrary sizes"""
+    classes, B = 3, 2
+    model, params = _build("mobilenetv2", shape, classes, "deeplab")
+    rng = np.random.default_rng(shape[0])
+    x = rng.integers(0, 256, (B,) + shape).astype(np.float32)
+    kw = dict(backbone="mobilenetv2", input_shape=shape, classes=classes, OS=16, head="deeplab")
+    params = O.calibrate_bn(params, x, **kw)
+    _load(model, params)
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    ref, _ = O.forward(p64, x.astype(np.float64), **kw)
+    probs = model.predict(x, batch_size=B)
+    assert probs.shape == (B, shape[0] * shape[1], classes)
+    assert relerr(model._active.logits(), ref) < 1e-3
+    _assert_argmax_parity(model._active.argmax(), ref)
+    labels = rng.integers(0, classes + 1, (B, shape[0] * shape[1])).astype(np.float32)
+    sw = (labels < classes).astype(np.float32)
+    eng = model._engine(B, True, dropout=False, use_graph=False)
+    eng.set_input(x)
+    eng.set_targets(labels, sw)
+    eng.fwd_bwd()
+    torch.cuda.synchronize()
+    loss, grads, logits, _ = O.train_grads(p64, x.astype(np.float64), labels.astype(np.float64), sw.astype(np.float64), **kw)
+    assert relerr(eng.logits(), logits) < 1e-3
+    assert abs(float(eng.loss[0].item()) - loss) < 1e-4 * abs(loss)
+    for name in ("concat_projection/kernel:0", "custom_logits_semantic/kernel:0", "aspp0/kernel:0"):
+        assert _l2(eng.grad_of(name), grads[name]) < 5e-3, name
