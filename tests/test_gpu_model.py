@@ -429,3 +429,27 @@ def test_odd_and_non_square_inputs(shape):
     assert abs(float(eng.loss[0].item()) - loss) < 1e-4 * abs(loss)
     for name in ("concat_projection/kernel:0", "custom_logits_semantic/kernel:0", "aspp0/kernel:0"):
         assert _l2(eng.grad_of(name), grads[name]) < 5e-3, name
+
+
+def test_width_multiplier_alpha():
+    """Deeplabv3(alpha=0.5): `_make_divisible` channel rounding (deeplabv3p.py:157-170) through the engine"""
+    import dl3_amd  # noqa: F401
+    from dl3_amd import graph as G
+    from dl3_amd.deeplabv3p import Deeplabv3
+    shape, classes, B, alpha = (64, 64, 3), 3, 2, 0.5
+    G.clear_session()
+    model = Deeplabv3(weights=None, input_shape=shape, classes=classes, backbone="mobilenetv2", alpha=alpha)
+    kw = dict(backbone="mobilenetv2", input_shape=shape, classes=classes, OS=16, alpha=alpha)
+    params = O.init_params(O.param_shapes("mobilenetv2", classes, alpha=alpha), seed=3)
+    rng = np.random.default_rng(12)
+    x = rng.integers(0, 256, (B,) + shape).astype(np.float32)
+    params = O.calibrate_bn(params, x, **kw)
+    _load(model, params)
+    assert model.get_layer("expanded_conv_project").get_weights()[0].shape[-1] == 8
+    ref, _ = O.forward({k: v.astype(np.float64) for k, v in params.items()}, x.astype(np.float64), **kw)
+    model.predict(x, batch_size=B)
+    assert relerr(model._active.logits(), ref) < 1e-3
+    _assert_argmax_parity(model._active.argmax(), ref)
+    y = rng.integers(0, classes + 1, (B, shape[0] * shape[1], 1)).astype(np.float32)
+    l0 = model.train_on_batch(x, y)
+    assert np.isfinite(l0)
