@@ -46,6 +46,12 @@ def test_constructor_contract():
     G.clear_session()
     m = Deeplabv3(weights=None, input_shape=(64, 64, 3), classes=5)
     assert m.output.shape == (64 * 64, 5)
+    # input_tensor path (deeplabv3p.py:260-266, :447-450): the model is built on the caller's Input; like the reference, pooling
+    # and resize sizes still come from input_shape (deeplabv3p.py:375,:382), so the two must agree
+    G.clear_session()
+    inp = G.Input(shape=(96, 64, 3))
+    m = Deeplabv3(weights=None, input_tensor=inp, input_shape=(96, 64, 3), classes=4, backbone="xception", OS=8)
+    assert m.input is inp and m.output.shape == (96 * 64, 4)
 
 
 def test_mobilenetv2_structure_goldens():
