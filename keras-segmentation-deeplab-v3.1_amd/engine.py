@@ -618,7 +618,14 @@ class Engine:
             self.dirty = False
 
     def set_input(self, x):
-        xt = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        """raw 0-255 pixels [B,H,W,3]: float32 (the reference's arrays), or uint8 (decoded images as they come from
+        cv2.imread) — those cross PCIe as bytes and are widened on the device"""
+        if torch.is_tensor(x):
+            xt = x
+        elif isinstance(x, np.ndarray) and x.dtype == np.uint8:
+            xt = torch.from_numpy(np.ascontiguousarray(x))
+        else:
+            xt = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
         self.xbuf.t.copy_(xt.reshape(-1).to(self.device, non_blocking=True))
 
     def forward(self):

@@ -476,7 +476,8 @@ class Model:
         return eng
 
     def predict(self, x, batch_size=32, verbose=0):
-        x = np.asarray(x, np.float32) if not hasattr(x, "data_ptr") else x
+        if not hasattr(x, "data_ptr") and not (isinstance(x, np.ndarray) and x.dtype == np.uint8):
+            x = np.asarray(x, np.float32)
         n = x.shape[0]
         bs = min(int(batch_size), n)
         outs = []
@@ -492,7 +493,8 @@ class Model:
         the device (dl3_argmax, dl3_seg_counts); the metric ratios (utils.py:132-157) and the loss (utils.py:127-130,
         Keras weighted mean) are evaluated on the host from those counts / the probabilities."""
         from . import utils as U
-        x = np.asarray(x, np.float32) if not hasattr(x, "data_ptr") else x
+        if not hasattr(x, "data_ptr") and not (isinstance(x, np.ndarray) and x.dtype == np.uint8):
+            x = np.asarray(x, np.float32)
         y = np.asarray(y)
         n = x.shape[0]
         bs = min(int(batch_size), n)
