@@ -487,6 +487,23 @@ class Model:
             outs.append(eng.predict(xb))
         return np.concatenate(outs, axis=0)
 
+    def predict_mask(self, x, batch_size=32):
+        """np.argmax(model.predict(x), -1) (notebook cell 9) without shipping the probabilities to the host: the argmax
+        runs on the device (dl3_argmax) and only the int32 masks [B,H,W] cross PCIe — 1 MB instead of 22 MB per
+        512x512x21 image.  Not part of the reference's Model API."""
+        if not hasattr(x, "data_ptr") and not (isinstance(x, np.ndarray) and x.dtype == np.uint8):
+            x = np.asarray(x, np.float32)
+        n = x.shape[0]
+        bs = min(int(batch_size), n)
+        outs = []
+        for i in range(0, n, bs):
+            xb = x[i:i + bs]
+            eng = self._engine(xb.shape[0], False)
+            eng.set_input(xb)
+            eng.forward()
+            outs.append(eng.argmax())
+        return np.concatenate(outs, axis=0)
+
     def evaluate(self, x, y, batch_size=32, sample_weight=None, verbose=0):
         """keras Model.evaluate for the notebook's metrics (cell 2: metrics=[Jaccard, sparse_accuracy_ignoring_last_label]):
         returns [loss, Jaccard, accuracy].  The argmax mask and the per-image/per-class pixel counts are produced on

@@ -388,6 +388,9 @@ def test_fit_generator_with_device_targets():
     model.compile(optimizer=dict(lr=7e-4, epsilon=1e-8, decay=1e-6))
     hist = model.fit_generator(gen, epochs=2)
     assert len(hist) == 6 and all(np.isfinite(hist)) and hist[-1] < hist[0]
+    masks = model.predict_mask(imgs[:4], batch_size=2)
+    assert masks.shape == (4, 64, 64) and masks.dtype == np.int32
+    assert np.array_equal(masks.reshape(4, -1), model.predict(imgs[:4], batch_size=2).argmax(-1))
     # uint8 images cross PCIe as bytes and are widened on the device: same result as the float32 array
     assert np.array_equal(model.predict(imgs[:2], batch_size=2), model.predict(imgs[:2].astype(np.float32), batch_size=2))
     # same losses as feeding the host-prepared tensors batch by batch
