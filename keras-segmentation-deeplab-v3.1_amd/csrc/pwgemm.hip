@@ -823,6 +823,9 @@ int env_int(const char *name) {
 GemmCfg pick_gemm(int M, int K, int N, bool two, bool small) {
   const int forced = env_int("DL3_GEMM_CFG");  // tuning aid (tools/gemm_tune.py)
   if (forced >= 0 && forced < kNumGemmCfgs && (small || kGemmCfgs[forced].BM != 32)) return kGemmCfgs[forced];
+  // measured exception (tools/gemm_tune.py): a forward GEMM with a very short reduction and a wide output
+  // (24 -> 144 at 128x128) is a pure streaming kernel and wants the tall 256x64 tile
+  if (!two && K < 32 && N > 128 && M >= 65536) return kGemmCfgs[1];
   double best = 1e30;
   GemmCfg bc = kGemmCfgs[0];
   for (const GemmCfg &c : kGemmCfgs) {
@@ -929,6 +932,7 @@ WgCfg pick_wgrad(int M, int K, int N, bool two) {
     if (K >= 32 && N >= 32 && (long)K * N <= 32768) return kWgCfgs[0];
     if (N % 160 == 0 && K >= 128 && K % 160 != 0) return kWgCfgs[3];
     if (K % 160 == 0 && K % 128 != 0 && N >= 128 && N % 160 != 0) return kWgCfgs[2];
+    if (K % 160 == 0 && N % 160 == 0 && K >= 320 && N >= 320) return kWgCfgs[3];
   }
   double best = 1e30;
   WgCfg bc = kWgCfgs[0];
