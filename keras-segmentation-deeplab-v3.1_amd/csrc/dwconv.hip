@@ -175,6 +175,104 @@ __global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x,
 }
 
 // ======================================================================================
+// march forward, two pixels per lane (rates that divide 32: 1, 2, 4, 8, 16, 32).  A lane owns the pixel pair
+// (xa, xa + r) of a 64-pixel segment (pair index j -> xa = (j / r) * 2r + j % r), so the right tap of xa and the left
+// tap of xb are the lane's own centre values: four loads per row serve two outputs (xa - r, xa, xb, xb + r) instead of
+// six, and a 64-wide feature map is ONE segment — no tap crosses a workgroup boundary.  Measured on the rate-4 layer:
+// the side-tap loads of the one-pixel kernel cost 12 % (4.70 -> 5.26 TB/s with them removed).
+// Same grid decode / row-phase walk / partial layout as dw_march_fwd with 64-pixel segments.
+// ======================================================================================
+__global__ __launch_bounds__(256) void dw_march2_fwd(const float *__restrict__ x, const float *__restrict__ sc,
+                                                     const float *__restrict__ sh, int act,
+                                                     const float *__restrict__ w, float *__restrict__ y,
+                                                     int H, int W, int C, int r, int nchunk, int TK, int nxseg,
+                                                     int nphase, int ppb, int nslab, int ny, int N, int xcd,
+                                                     float *__restrict__ part) {
+  __shared__ float red[4 * 8 * 8];
+  const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
+  DwTile tile;
+  if (!dw_tile(nxseg, nslab, ny, N, xcd, tile)) return;
+  const int xs = tile.xs, slab = tile.slab, pc = tile.pc, n = tile.n;
+  const int c = slab * 32 + cq * 4;
+  const int xa = xs * 64 + (pl / r) * 2 * r + pl % r, xb = xa + r;
+  const bool ca = c < C;
+  const bool act_a = ca && xa < W, act_b = ca && xb < W;
+
+  f32x4 wv[9], s = splat4(1.f), t = splat4(0.f);
+#pragma unroll
+  for (int i = 0; i < 9; i++) wv[i] = ld4(w + (size_t)i * C + min(c, C - 4));
+  if (sc) { s = ld4(sc + min(c, C - 4)); t = ld4(sh + min(c, C - 4)); }
+  f32x4 s1 = splat4(0.f), s2 = splat4(0.f);
+  const int cc = min(c, C - 4);
+  // clamped columns (loads are always in bounds) and 0/1 validity of the four column positions
+  const int x0c = min(max(xa - r, 0), W - 1), x1c = min(xa, W - 1), x2c = min(xb, W - 1), x3c = min(xb + r, W - 1);
+  const float v0 = (ca && xa - r >= 0 && xa - r < W) ? 1.f : 0.f, v1 = act_a ? 1.f : 0.f, v2 = act_b ? 1.f : 0.f,
+              v3 = (ca && xb + r < W) ? 1.f : 0.f;
+  const float *xbase = x + ((size_t)n * H * W) * C + cc;
+  float *ybase = y + ((size_t)n * H * W) * C + c;
+  for (int pi = 0; pi < ppb; ++pi) {
+    const int a = (ppb > 1) ? pc * ppb + pi : pc / nchunk;
+    const int ch = (ppb > 1) ? 0 : pc % nchunk;
+    if (a >= nphase) break;
+    const int Ka = (a < H) ? (H - a + r - 1) / r : 0;
+    const int k0 = ch * TK;
+    const int k1 = min(k0 + TK, Ka);
+    const int Kc = max(Ka - 1, 0);
+    auto ldrow = [&](int k, f32x4 (&p)[4]) {
+      const float rok = (k >= 0 && k < Ka) ? 1.f : 0.f;
+      const float *row = xbase + (size_t)(a + min(max(k, 0), Kc) * r) * W * C;
+      p[0] = dl3_act4(s * ld4(row + (size_t)x0c * C) + t, act) * splat4(rok * v0);
+      p[1] = dl3_act4(s * ld4(row + (size_t)x1c * C) + t, act) * splat4(rok * v1);
+      p[2] = dl3_act4(s * ld4(row + (size_t)x2c * C) + t, act) * splat4(rok * v2);
+      p[3] = dl3_act4(s * ld4(row + (size_t)x3c * C) + t, act) * splat4(rok * v3);
+    };
+    f32x4 aA = splat4(0.f), aB = splat4(0.f), bA = splat4(0.f), bB = splat4(0.f);
+    constexpr int R = 3;
+    const bool bot_halo = k1 < Ka;
+    const int ks = (k0 > 0) ? k0 - 1 : k0, ke = bot_halo ? k1 : k1 - 1;
+    for (int kg = ks; kg <= ke && k0 < k1; kg += R) {
+      f32x4 p[R][4];
+#pragma unroll
+      for (int j = 0; j < R; j++) ldrow((kg + j <= ke) ? kg + j : -1, p[j]);
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+        const int k = kg + j;
+        if (k > ke) break;
+        // pixel a: taps (p0, p1, p2); pixel b: taps (p1, p2, p3)
+        const f32x4 a0 = wv[0] * p[j][0] + wv[1] * p[j][1] + wv[2] * p[j][2];
+        const f32x4 a1 = wv[3] * p[j][0] + wv[4] * p[j][1] + wv[5] * p[j][2];
+        const f32x4 a2 = wv[6] * p[j][0] + wv[7] * p[j][1] + wv[8] * p[j][2];
+        const f32x4 b0 = wv[0] * p[j][1] + wv[1] * p[j][2] + wv[2] * p[j][3];
+        const f32x4 b1 = wv[3] * p[j][1] + wv[4] * p[j][2] + wv[5] * p[j][3];
+        const f32x4 b2 = wv[6] * p[j][1] + wv[7] * p[j][2] + wv[8] * p[j][3];
+        const f32x4 oa = aA + a2, ob = bA + b2;
+        if (k - 1 >= k0 && k - 1 < k1) {
+          float *orow = ybase + (size_t)(a + (k - 1) * r) * W * C;
+          if (act_a) { st4_nt(orow + (size_t)xa * C, oa); s1 += oa; s2 += oa * oa; }
+          if (act_b) { st4_nt(orow + (size_t)xb * C, ob); s1 += ob; s2 += ob * ob; }
+        }
+        aA = aB + a1; aB = a0;
+        bA = bB + b1; bB = b0;
+      }
+    }
+    if (!bot_halo && k0 < k1) {  // last row of the phase: no row below contributes
+      float *orow = ybase + (size_t)(a + (k1 - 1) * r) * W * C;
+      if (act_a) { st4_nt(orow + (size_t)xa * C, aA); s1 += aA; s2 += aA * aA; }
+      if (act_b) { st4_nt(orow + (size_t)xb * C, bA); s1 += bA; s2 += bA * bA; }
+    }
+  }
+  if (part) {
+    float v[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
+    reduce_px<8>(v, red);
+    if (tid < 8 && c < C) {
+      const int p = (n * ny + pc) * nxseg + xs;
+      f32x4 r1 = {v[0], v[1], v[2], v[3]}, r2 = {v[4], v[5], v[6], v[7]};
+      write_stat_partial(part, p, C, c, r1, r2);
+    }
+  }
+}
+
+// ======================================================================================
 // march backward (fused bwd-data + bwd-weight): same decomposition as the forward
 // ======================================================================================
 __global__ __launch_bounds__(256) void dw_march_bwd(
@@ -599,6 +697,7 @@ struct DwPlan {
   int impl;                      // DL3_IMPL_MARCH / DL3_IMPL_GATHER
   int nslab, nxseg, nphase, nchunk, TK;  // march
   int ppb, ny;                           // march: row phases per workgroup, grid.y
+  int two;                               // march forward: two pixels per lane (64-pixel segments)
   int PB;                        // gather
   int P;
 };
@@ -621,7 +720,9 @@ DwPlan dw_plan(int N, int H, int W, int C, int stride, int rate, int Ho, int Wo,
   p.nslab = dl3_cdiv(C, 32);
   p.impl = impl;
   if (impl == DL3_IMPL_MARCH) {
-    p.nxseg = dl3_cdiv(W, 32);
+    const char *e2 = getenv("DL3_DW_TWO");  // 0 = one pixel per lane everywhere (tuning / test aid)
+    p.two = (!bwd && 32 % rate == 0 && W >= 32 && !(e2 && atoi(e2) == 0)) ? 1 : 0;
+    p.nxseg = dl3_cdiv(W, p.two ? 64 : 32);
     p.nphase = rate < H ? rate : H;
     const int Kmax = dl3_cdiv(H, rate);
     // rows per block: as long as possible (halo re-read = 2/TK) while keeping >= ~2048 blocks
@@ -696,8 +797,16 @@ extern "C" int dl3_dwconv3x3_fwd(const float *x, const float *in_scale, const fl
   hipStream_t st = (hipStream_t)stream;
   if (im == DL3_IMPL_MARCH) {
     dim3 grid(march_grid(p, N));
-    hipLaunchKernelGGL(dw_march_fwd, grid, dim3(256), 0, st, x, in_scale, in_shift, in_act, w, y, H, W, C, rate,
-                       p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial);
+    if (p.two)
+      hipLaunchKernelGGL(dw_march2_fwd, grid, dim3(256), 0, st, x, in_scale, in_shift, in_act, w, y, H, W, C, rate,
+                         p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial);
+    else
+      hipLaunchKernelGGL(dw_march_fwd, grid, dim3(256), 0, st, x, in_scale, in_shift, in_act, w, y, H, W, C, rate,
+                         p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial);
+    // the two-pixel forward writes fewer partial rows than the backward's decomposition: zero the rest
+    const int Pmax = dl3_dwconv3x3_partials(N, H, W, C, stride, rate, Ho, Wo, im);
+    if (stat_partial && Pmax > p.P)
+      (void)hipMemsetAsync(stat_partial + (size_t)p.P * C * 2, 0, (size_t)(Pmax - p.P) * C * 2 * sizeof(float), st);
   } else {
     DwGeom G{N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo};
     dim3 grid(p.nslab, p.PB);

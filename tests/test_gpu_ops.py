@@ -41,6 +41,10 @@ DW_CASES = [
     (2, 8, 8, 64, 1, 2, None, 0, 2),     # map narrower than the 32 pixel lanes (idle lanes must stay in bounds)
     (1, 4, 4, 32, 1, 1, None, 0, 1),
     (16, 36, 36, 512, 1, 18, None, 0, 2),  # large rate: several row phases per workgroup (ASPP rates 12/24/36)
+    (2, 24, 64, 96, 1, 4, None, 0, 2),     # forward with two pixels per lane: one 64-pixel segment, rate 4
+    (1, 20, 96, 40, 1, 2, None, 0, 1),     # ... one and a half segments, C not a multiple of 32
+    (2, 9, 33, 32, 1, 1, None, 0, 2),      # ... odd width
+    (1, 40, 80, 64, 1, 8, None, 0, None),  # ... rate 8
 ]
 
 
