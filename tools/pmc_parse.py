@@ -12,7 +12,7 @@ for d in sys.argv[1:]:
             k = r["Kernel_Name"]
             if "dw_march" not in k:
                 continue
-            name = "dw_march_fwd" if "dw_march_fwd" in k else "dw_march_bwd"
+            name = "dw_march_fwd" if ("dw_march_fwd" in k or "dw_march2_fwd" in k) else "dw_march_bwd"
             acc.setdefault((name, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
         for (name, ctr), vals in acc.items():
             vals = vals[3:] if len(vals) > 6 else vals  # drop warm-up launches
