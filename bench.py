@@ -232,7 +232,7 @@ def main():
                 pj = json.load(open(pmc))
                 if pj.get("batch") == args.batch:
                     traffic = pj["dw_march_fwd"]["traffic_bytes"]
-            rec["roofline"] = {"bound": "hbm", "kernel": "dw_march_fwd (DepthwiseConv2D 3x3 rate 4, %dx64x64x960)" % args.batch,
+            rec["roofline"] = {"bound": "hbm", "kernel": "dw_march2_fwd (DepthwiseConv2D 3x3 rate 4, %dx64x64x960)" % args.batch,
                                "achieved": k["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["gbs"] / HBM_PEAK_GBS,
                                "traffic": traffic, "avg_ms": k["ms"], "algorithmic_bytes": k["bytes"]}
             # the kernel family with the largest share of the step is the fp32-MFMA 1x1-conv GEMM (forward shown:
