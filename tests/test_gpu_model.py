@@ -458,3 +458,44 @@ def test_width_multiplier_alpha():
     y = rng.integers(0, classes + 1, (B, shape[0] * shape[1], 1)).astype(np.float32)
     l0 = model.train_on_batch(x, y)
     assert np.isfinite(l0)
+
+
+def test_learns_a_toy_segmentation_task():
+    """the whole stack as a user drives it (Deeplabv3 -> compile -> fit_generator on SegmentationGenerator batches ->
+    evaluate): bright squares on a dark, noisy background; a few dozen Adam steps must lift Jaccard and accuracy well
+    above the untrained model's"""
+    from dl3_amd import utils as U
+    rng = np.random.default_rng(33)
+    n, H, W = 16, 64, 64
+    imgs = rng.integers(0, 60, (n, H, W, 3)).astype(np.uint8)
+    labs = np.zeros((n, H, W), np.uint8)
+    for i in range(n):
+        y0, x0 = rng.integers(4, 32, 2)
+        s = rng.integers(16, 28)
+        imgs[i, y0:y0 + s, x0:x0 + s] = rng.integers(180, 256, 3)
+        labs[i, y0:y0 + s, x0:x0 + s] = 1
+        labs[i, :2] = 255  # a void border
+    model, params = _build(input_shape=(H, W, 3), classes=2)
+    _load(model, params)
+    model.compile(optimizer=dict(lr=3e-3, epsilon=1e-8, decay=1e-6))
+    Yall, SWall, _ = O.prepare_targets(labs.reshape(n, -1), 2)
+
+    def batch_stat_metrics():
+        # metrics of the TRAINING-mode forward (batch statistics): with the reference's BatchNorm momentum of 0.999 the
+        # moving statistics that predict()/evaluate() use have barely moved after a few dozen steps
+        eng = model._engine(8, True)
+        eng.set_input(imgs[:8])
+        eng.set_targets(Yall[:8], SWall[:8])
+        eng.forward()
+        probs = O.softmax(eng.logits().astype(np.float64)).reshape(8, -1, 2)
+        return U.Jaccard(Yall[:8], probs), U.sparse_accuracy_ignoring_last_label(Yall[:8], probs)
+
+    before = batch_stat_metrics()
+    gen = U.SegmentationGenerator(imgs, labs, n_classes=2, batch_size=8, seed=1)
+    hist = model.fit_generator(gen, epochs=20)
+    after = batch_stat_metrics()
+    assert np.isfinite(hist).all() and np.mean(hist[-4:]) < 0.5 * np.mean(hist[:4]), (hist[:4], hist[-4:])
+    assert after[0] > max(0.7, before[0] + 0.2), (before, after)    # Jaccard
+    assert after[1] > 0.9, (before, after)                          # pixel accuracy
+    loss, jac, acc = model.evaluate(imgs.astype(np.float32), Yall, batch_size=8)   # inference path stays consistent
+    assert np.isfinite(loss) and 0.0 <= jac <= 1.0 and 0.0 <= acc <= 1.0
