@@ -96,6 +96,10 @@ int dl3_pwconv_bwd_weight(const float *x, int ldx, const float *in_scale, const 
                           void *workspace, size_t workspace_bytes, void *stream);
 /* out[cols][rows] = in[rows][cols]^T  (W[K,N] -> WT[N,K] for bwd_data) */
 int dl3_transpose(const float *in, float *out, int rows, int cols, void *stream);
+/* n transposes in one launch (all W -> WT of a backward pass).  desc (device, int64 [n][6]): in pointer, out pointer,
+ * rows, cols, index of the matrix's first 32x32 tile, tiles per tile-row (= ceil(cols/32)); matrices in ascending
+ * first-tile order; total_tiles = sum of ceil(rows/32)*ceil(cols/32). */
+int dl3_transpose_batched(const long long *desc, int n, int total_tiles, void *stream);
 
 /* ---- dense Conv2D 3x3 (stem convs: deeplabv3p.py:283,:289,:318) ----------------------- */
 int dl3_conv3x3_partials(int N, int Ho, int Wo, int Cout);

@@ -25,6 +25,7 @@ _CTYPES = {
     "const int *": ctypes.c_void_p,
     "void *": ctypes.c_void_p,
     "const void *": ctypes.c_void_p,
+    "const long long *": ctypes.c_void_p,
     "const char *": ctypes.c_char_p,
     "int": ctypes.c_int,
     "float": ctypes.c_float,

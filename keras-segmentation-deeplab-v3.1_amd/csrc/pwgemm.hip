@@ -808,6 +808,24 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
     if (c0 + i < cols && r0 + tx < rows) out[(size_t)(c0 + i) * rows + r0 + tx] = tile[tx][i];
 }
 
+// all weight transposes of a backward pass in one launch: desc[m] = {in, out, rows, cols, first tile, tiles per row}
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const long long *__restrict__ desc, int n) {
+  __shared__ float tile[32][33];
+  int m = 0;
+  while (m + 1 < n && (long long)blockIdx.x >= desc[(m + 1) * 6 + 4]) ++m;  // n is a few dozen
+  const float *in = (const float *)desc[m * 6 + 0];
+  float *out = (float *)desc[m * 6 + 1];
+  const int rows = (int)desc[m * 6 + 2], cols = (int)desc[m * 6 + 3];
+  const int t = blockIdx.x - (int)desc[m * 6 + 4], tx_ = (int)desc[m * 6 + 5];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c0 = (t % tx_) * 32, r0 = (t / tx_) * 32;
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = in[(size_t)(r0 + i) * cols + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < cols && r0 + tx < rows) out[(size_t)(c0 + i) * rows + r0 + tx] = tile[tx][i];
+}
+
 // ---- configuration choice -------------------------------------------------------------
 struct GemmCfg { int id, BM, BN; };
 const GemmCfg kGemmCfgs[] = {{0, 128, 128}, {1, 256, 64}, {2, 256, 32}, {3, 128, 160}, {4, 128, 96},
@@ -1117,5 +1135,12 @@ extern "C" int dl3_transpose(const float *in, float *out, int rows, int cols, vo
   dim3 grid(dl3_cdiv(cols, 32), dl3_cdiv(rows, 32));
   hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out, rows, cols);
   DL3_LAUNCH_CHECK("transpose");
+  return DL3_OK;
+}
+
+extern "C" int dl3_transpose_batched(const long long *desc, int n, int total_tiles, void *stream) {
+  DL3_CHECK_ARG(desc && n > 0 && total_tiles > 0, "transpose_batched: bad argument");
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, desc, n);
+  DL3_LAUNCH_CHECK("transpose_batched");
   return DL3_OK;
 }

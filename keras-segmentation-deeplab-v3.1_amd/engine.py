@@ -221,6 +221,10 @@ class Engine:
         self._scratch_users.append(rec)
         return rec
 
+    def transpose(self, src_ptr, dst, rows, cols):
+        """queue dst[cols][rows] = src[rows][cols]^T for the batched transpose at the head of the backward pass"""
+        self._transposes.append((int(src_ptr), dst, int(rows), int(cols)))
+
     def run_ops(self, lst):
         st = torch.cuda.current_stream().cuda_stream
         for name, fn, args, _ in lst:
@@ -533,8 +537,22 @@ class Engine:
         buf.done = 1
         assert buf.expected == 1
         # weight transposes for bwd-data, then the units in reverse
+        self._transposes = []
+        first_bwd = len(self.ops_bwd)
         for u in reversed(self.units):
             u.bwd()
+        if self._transposes:
+            # every W -> WT of the backward pass in ONE launch at its start (54 tiny launches otherwise)
+            rows, t0 = [], 0
+            for src, dst, r, c in self._transposes:
+                tx = (c + 31) // 32
+                rows.append([src, dst.data_ptr(), r, c, t0, tx])
+                t0 += tx * ((r + 31) // 32)
+            self._tdesc = torch.tensor(rows, dtype=torch.int64, device=self.device)
+            self._keep.append(self._tdesc)
+            rec = ("dl3_transpose_batched", getattr(self.lib, "dl3_transpose_batched"),
+                   [self._tdesc.data_ptr(), len(rows), t0], None)
+            self.ops_bwd.insert(first_bwd, rec)
         for b in self.bufs:
             if b.requires_grad and b.expected and b.done != b.expected:
                 raise RuntimeError("gradient accounting broken for buffer %s (%d/%d)" % (b.name, b.done, b.expected))
@@ -806,7 +824,7 @@ class PwUnit(_ConvBase):
         if not ibuf.requires_grad:
             return
         wT = eng.empty(K * N)
-        eng.op(eng.ops_bwd, "dl3_transpose", eng.wptr(self.wname()), ptr(wT), K, N)
+        eng.transpose(eng.wptr(self.wname()), wT, K, N)
         gout, add, last = eng.contrib_kernel(ibuf)
         need_stat = last and bool(ibuf.bns)
         P = eng.lib.dl3_pwconv_partials(M, N, K)
@@ -905,7 +923,7 @@ class Conv3Unit(_ConvBase):
         if not ibuf.requires_grad:
             return
         wT = eng.empty(9 * Cin * Cout)
-        eng.op(eng.ops_bwd, "dl3_transpose", eng.wptr(self.wname()), ptr(wT), 9 * Cin, Cout)
+        eng.transpose(eng.wptr(self.wname()), wT, 9 * Cin, Cout)
         gout, add, last = eng.contrib_kernel(ibuf)
         need_stat = last and bool(ibuf.bns)
         P = eng.lib.dl3_conv3x3_partials(B, H, W, Cin)

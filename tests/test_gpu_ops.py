@@ -585,6 +585,25 @@ def test_xent_fold_and_rows(L, dims):
     assert relerr(host(dlo), host(dlo2)) < 1e-5
 
 
+def test_transpose_batched(L):
+    rng = np.random.default_rng(31)
+    shapes = [(16, 96), (960, 160), (33, 7), (1, 40), (288, 64)]
+    src = [dev(rng.normal(0, 1, sh).astype(np.float32)) for sh in shapes]
+    dst = [empty(sh[1], sh[0]) for sh in shapes]
+    rows, t0 = [], 0
+    for a, b, (r, c) in zip(src, dst, shapes):
+        tx = (c + 31) // 32
+        rows.append([a.data_ptr(), b.data_ptr(), r, c, t0, tx])
+        t0 += tx * ((r + 31) // 32)
+    desc = torch.tensor(rows, dtype=torch.int64, device="cuda")
+    call("dl3_transpose_batched", desc.data_ptr(), len(rows), t0)
+    for a, b in zip(src, dst):
+        assert np.array_equal(host(b), host(a).T)
+    one = empty(160, 960)
+    call("dl3_transpose", ptr(src[1]), ptr(one), 960, 160)
+    assert np.array_equal(host(one), host(dst[1]))
+
+
 def test_adam_fill(L):
     rng = np.random.default_rng(14)
     n = 10001
