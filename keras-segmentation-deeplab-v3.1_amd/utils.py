@@ -5,7 +5,8 @@ dl3_softmax_xent — and host restatements of the metrics that the north star le
 (`Jaccard` utils.py:139-157, `sparse_accuracy_ignoring_last_label` utils.py:132-138).
 Next-ring rows of SURVEY §8(f): `prepare_targets` (N2, the label half of SegmentationGenerator.__getitem__ on the
 device) and `Jaccard_from_counts` / `accuracy_from_counts` (N3, metrics from dl3_seg_counts).
-Out of scope by the SURVEY §8 contract: image file I/O + cv2 augmentation, do_crf, plotting.
+`do_crf` (N4) is the host hook with the reference's parameters; it needs the optional pydensecrf package.
+Out of scope by the SURVEY §8 contract: image file I/O + cv2 augmentation, plotting.
 """
 import numpy as np
 
@@ -97,6 +98,33 @@ def prepare_targets(labels, n_classes=21):
     capi.call("dl3_prepare_targets", capi.ptr(labels), capi.LABEL_U8 if labels.dtype == torch.uint8 else capi.LABEL_I32,
               B, HW, n_classes, capi.ptr(Y), capi.ptr(SW), capi.ptr(hist), torch.cuda.current_stream().cuda_stream)
     return Y, SW
+
+
+# Dense-CRF post-processing stays on the host (north star): the hook and the reference's parameter set
+# (utils.py:74-91).  pydensecrf is not a dependency of this package: the hook imports it on first use.
+CRF_PARAMS = dict(gt_prob=0.7, gaussian_sxy=(3, 3), gaussian_compat=3, bilateral_sxy=80, bilateral_srgb=13,
+                  bilateral_compat=10, iterations=5)
+
+
+def do_crf(im, mask, zero_unsure=True):
+    """Fully connected CRF refinement of a label mask given the image (reference utils.py:74-91): unary energies from
+    the labels with CRF_PARAMS['gt_prob'], a Gaussian (position) and a bilateral (position + colour) pairwise term,
+    five mean-field iterations, MAP labels mapped back to the mask's original values."""
+    try:
+        import pydensecrf.densecrf as dcrf
+        from pydensecrf.utils import unary_from_labels
+    except ImportError as e:  # pragma: no cover - optional host dependency
+        raise ImportError("do_crf needs the optional host package pydensecrf (not installed)") from e
+    values, labels = np.unique(mask, return_inverse=True)
+    h, w = mask.shape[:2]
+    n = len(values)
+    crf = dcrf.DenseCRF2D(w, h, n)
+    crf.setUnaryEnergy(unary_from_labels(labels, n, gt_prob=CRF_PARAMS["gt_prob"], zero_unsure=zero_unsure))
+    crf.addPairwiseGaussian(sxy=CRF_PARAMS["gaussian_sxy"], compat=CRF_PARAMS["gaussian_compat"])
+    crf.addPairwiseBilateral(sxy=CRF_PARAMS["bilateral_sxy"], srgb=CRF_PARAMS["bilateral_srgb"],
+                             rgbim=np.ascontiguousarray(im, dtype=np.uint8), compat=CRF_PARAMS["bilateral_compat"])
+    q = np.asarray(crf.inference(CRF_PARAMS["iterations"]))
+    return values[np.argmax(q, axis=0)].reshape(h, w)
 
 
 class SegmentationGenerator:

@@ -216,3 +216,15 @@ def test_h5_weight_roundtrip_through_h5lite(tmp_path, monkeypatch):
         bad = tmp_path / "bad.h5"
         bad.write_bytes(b"not hdf5 at all")
         h5lite.read_keras_weights(str(bad))
+
+
+def test_crf_hook_parameters():
+    """the Dense-CRF post-process is a host hook; its parameters are the reference's (utils.py:78-86)"""
+    from dl3_amd import utils as U
+    assert U.CRF_PARAMS == dict(gt_prob=0.7, gaussian_sxy=(3, 3), gaussian_compat=3, bilateral_sxy=80, bilateral_srgb=13,
+                                bilateral_compat=10, iterations=5)
+    try:
+        import pydensecrf  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match="pydensecrf"):
+            U.do_crf(np.zeros((8, 8, 3), np.uint8), np.zeros((8, 8), np.int32))
