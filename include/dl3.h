@@ -140,10 +140,16 @@ int dl3_conv3x3_gemm_bwd_data(const float *g, const float *yraw, const float *cA
 /* ---- BatchNormalization (54 layers mnv2 / 146 xception; eps 1e-3 or 1e-5) -------------- */
 /* training mode: fold stat partials [P][ldc][2] (channels c0..c0+C-1 at partial + 2*c0) into
  * scale = gamma*invstd, shift = beta - mean*scale, mean, invstd (biased batch variance) and
- * update the moving statistics (moving = m*moving + (1-m)*batch).  count = N*H*W. */
+ * update the moving statistics: moving_mean = m*moving_mean + (1-m)*mean,
+ * moving_var = m*moving_var + (1-m)*var_unbias*biased_var.  count = n = N*H*W.  var_unbias is the framework's
+ * sample-variance factor, chosen by the host: Keras 2.2.4 on TF 1.13 (the reference's environment) multiplies
+ * FusedBatchNorm's already Bessel-corrected batch variance by n/(n-(1+eps)) once more (keras/layers/normalization.py
+ * `variance *= sample_size / (sample_size - (1.0 + self.epsilon))`), i.e. var_unbias = n/(n-1) * n/(n-(1+eps));
+ * tf.keras uses n/(n-1).  moving_mean/moving_var NULL (together): a non-trainable layer, whose moving statistics
+ * Keras 2.2.x leaves untouched. */
 int dl3_bn_finalize(const float *stat_partial, int P, int ldc, int C, double count, const float *gamma,
-                    const float *beta, float eps, float momentum, float *scale, float *shift, float *mean,
-                    float *invstd, float *moving_mean, float *moving_var, void *stream);
+                    const float *beta, float eps, float momentum, double var_unbias, float *scale, float *shift,
+                    float *mean, float *invstd, float *moving_mean, float *moving_var, void *stream);
 /* inference / frozen mode: scale, shift, mean, invstd from the moving statistics */
 int dl3_bn_frozen(const float *gamma, const float *beta, const float *moving_mean, const float *moving_var,
                   float eps, int C, float *scale, float *shift, float *mean, float *invstd, void *stream);
@@ -157,17 +163,21 @@ int dl3_bn_bwd_finalize(const float *dstat_partial, int P, int ldc, int C, doubl
 int dl3_rows_partials(int M); /* P for row-wise reducing kernels over M rows */
 /* out = act_a(sa*a+ta) + act_b(sb*b+tb)  (b nullable): Add (deeplabv3p.py:147-149,:201) and
  * materialisation of a BN(+act) output.  Optional Dropout (deeplabv3p.py:410): if drop_rate>0,
- * out *= keep_mask(seed, element index)/(1-drop_rate). */
+ * out *= keep_mask(seed, step, element index)/(1-drop_rate). */
 int dl3_affine_add(const float *a, int lda, const float *sa, const float *ta, int act_a, const float *b,
                    int ldb, const float *sb, const float *tb, int act_b, float *out, int ldo, int M, int C,
-                   float drop_rate, unsigned long long drop_seed, void *stream);
+                   float drop_rate, unsigned long long drop_seed, const unsigned long long *drop_step, void *stream);
+/* *counter += inc (device memory).  The dropout step number: launch arguments are frozen inside a captured hipGraph,
+ * so kernels read the step from *drop_step (nullable) and use the seed drop_seed + step * 0xD1B54A32D192ED03. */
+int dl3_counter_add(unsigned long long *counter, unsigned long long inc, void *stream);
 /* gout = mask_{act}(gin_scale * gin[m / gin_div] * dropmask/(1-rate)) + add ; gin_div = H*W broadcasts a
  * per-image gradient vector (backward of the global average pool); dstat partials [P][C][2] (nullable),
  * P = dl3_rows_partials(M).  gout may alias gin (gin_div == 1) and/or add. */
 int dl3_grad_finish(const float *gin, int ldgin, int gin_div, float gin_scale, float *gout, int ldgout,
                     const float *add, int ldadd, const float *xraw, int ldx, const float *scale,
                     const float *shift, int act, const float *mean, const float *invstd, float *dstat_partial,
-                    int M, int C, float drop_rate, unsigned long long drop_seed, void *stream);
+                    int M, int C, float drop_rate, unsigned long long drop_seed, const unsigned long long *drop_step,
+                    void *stream);
 /* strided 1x1 convolutions (Xception shortcuts, _conv2d_same(kernel_size=1, stride=2), deeplabv3p.py:143-145) sample
  * rows/cols 0, s, 2s, ...: y[n,oy,ox,c] = T(x)[n, oy*s, ox*s, c] compacts the sampled pixels for the GEMM;
  * the backward scatters the compact gradient back (zeros elsewhere). */
@@ -243,6 +253,18 @@ int dl3_prepare_targets(const void *labels, int label_dtype, int B, int HW, int 
  * pred = dl3_argmax output (int32), y_true as fed to the loss (float, void = C).  The ratios stay on the host
  * (utils.Jaccard_from_counts): union = true + pred - inter, exactly the reference's inter/union sums. */
 int dl3_seg_counts(const int *pred, const float *y_true, int B, int HW, int C, int *counts, void *stream);
+
+/* ---- data-parallel gradient exchange over RCCL / xGMI (replaces keras.utils.multi_gpu_model, utils.py:209-211) ----
+ * One process per GPU.  Rank 0 draws a 128-byte id (dl3_comm_unique_id) and hands it to the other ranks over any host
+ * channel; every rank then calls dl3_comm_init with its HIP device current.  The collectives are enqueued on the
+ * caller's stream (no sync): ONE all-reduce(sum) of the flat fp32 gradient arena per step, the 1/world factor goes
+ * into dl3_adam_step(grad_scale).  RCCL is bound with dlopen at the first call: -4 (DL3_EUNSUPPORTED) if absent. */
+#define DL3_COMM_ID_BYTES 128
+int dl3_comm_unique_id(void *id128);
+int dl3_comm_init(void **comm, const void *id128, int rank, int world);
+int dl3_comm_allreduce_f32(void *comm, const float *send, float *recv, size_t n, void *stream);
+int dl3_comm_broadcast_f32(void *comm, float *buf, size_t n, int root, void *stream);
+int dl3_comm_destroy(void *comm);
 
 #ifdef __cplusplus
 }

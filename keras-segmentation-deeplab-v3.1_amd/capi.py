@@ -25,7 +25,10 @@ _CTYPES = {
     "const int *": ctypes.c_void_p,
     "void *": ctypes.c_void_p,
     "const void *": ctypes.c_void_p,
+    "void * *": ctypes.POINTER(ctypes.c_void_p),
     "const long long *": ctypes.c_void_p,
+    "unsigned long long *": ctypes.c_void_p,
+    "const unsigned long long *": ctypes.c_void_p,
     "const char *": ctypes.c_char_p,
     "int": ctypes.c_int,
     "float": ctypes.c_float,

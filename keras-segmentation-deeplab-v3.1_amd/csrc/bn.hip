@@ -41,8 +41,8 @@ __device__ __forceinline__ void fold2(const float *part, int P, int ldc, int c, 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ part, int P, int ldc, int C,
                                                           double count, const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, float eps,
-                                                          float momentum, float *scale, float *shift, float *mean,
-                                                          float *invstd, float *mmean, float *mvar) {
+                                                          float momentum, double unbias, float *scale, float *shift,
+                                                          float *mean, float *invstd, float *mmean, float *mvar) {
   __shared__ double red[32 * 8 * 2];
   const int c = blockIdx.x * 8 + (threadIdx.x & 7);
   const bool cok = c < C;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
     mean[c] = (float)m;
     invstd[c] = (float)is;
     if (mmean) {
-      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      const double unb = var * unbias;  // the framework's sample-variance factor (see dl3_bn_finalize in dl3.h)
       mmean[c] = (float)((double)momentum * mmean[c] + (1.0 - (double)momentum) * m);
       mvar[c] = (float)((double)momentum * mvar[c] + (1.0 - (double)momentum) * unb);
     }
@@ -140,8 +140,10 @@ __global__ __launch_bounds__(256) void affine_add_kernel(const float *__restrict
                                                          const float *__restrict__ sb,
                                                          const float *__restrict__ tb, int act_b,
                                                          float *__restrict__ out, int ldo, long M, int C,
-                                                         float drop_rate, unsigned long long seed) {
+                                                         float drop_rate, unsigned long long seed,
+                                                         const unsigned long long *__restrict__ step) {
   const long total = M * C;
+  seed = dl3_step_seed(seed, step);
   const float keep_scale = drop_rate > 0.f ? 1.f / (1.f - drop_rate) : 1.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long m = i / C;
@@ -169,8 +171,10 @@ __global__ __launch_bounds__(256) void grad_finish_kernel(const float *gin, int 
                                                           const float *__restrict__ mean,
                                                           const float *__restrict__ invstd,
                                                           float *__restrict__ part, long M, int C, float drop_rate,
-                                                          unsigned long long seed) {
+                                                          unsigned long long seed,
+                                                          const unsigned long long *__restrict__ step) {
   __shared__ float red[256 * 2];
+  seed = dl3_step_seed(seed, step);
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   const bool cok = c < C;
@@ -308,7 +312,9 @@ __global__ __launch_bounds__(256) void affine_add4_kernel(const float *__restric
                                                           const float *__restrict__ sb,
                                                           const float *__restrict__ tb, int act_b,
                                                           float *__restrict__ out, int ldo, unsigned total4,
-                                                          unsigned C4, float drop_rate, unsigned long long seed) {
+                                                          unsigned C4, float drop_rate, unsigned long long seed,
+                                                          const unsigned long long *__restrict__ step) {
+  seed = dl3_step_seed(seed, step);
   const float keep_scale = drop_rate > 0.f ? 1.f / (1.f - drop_rate) : 1.f;
   for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total4; i += gridDim.x * 256) {
     const unsigned m = i / C4, c = (i - m * C4) * 4;
@@ -329,6 +335,8 @@ __global__ __launch_bounds__(256) void affine_add4_kernel(const float *__restric
   }
 }
 
+__global__ void counter_add_kernel(unsigned long long *c, unsigned long long inc) { *c += inc; }
+
 inline int ew_blocks(size_t n) {
   size_t b = (n + 255) / 256;
   if (b > 4096) b = 4096;
@@ -346,13 +354,15 @@ extern "C" int dl3_rows_partials(int M) {
 }
 
 extern "C" int dl3_bn_finalize(const float *stat_partial, int P, int ldc, int C, double count, const float *gamma,
-                               const float *beta, float eps, float momentum, float *scale, float *shift,
-                               float *mean, float *invstd, float *moving_mean, float *moving_var, void *stream) {
+                               const float *beta, float eps, float momentum, double var_unbias, float *scale,
+                               float *shift, float *mean, float *invstd, float *moving_mean, float *moving_var,
+                               void *stream) {
   DL3_CHECK_ARG(stat_partial && gamma && beta && scale && shift && mean && invstd, "bn_finalize: null pointer");
   DL3_CHECK_ARG(P > 0 && C > 0 && ldc >= C && count > 0, "bn_finalize: bad dimension");
   DL3_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "bn_finalize: moving stats come together");
+  DL3_CHECK_ARG(var_unbias > 0.0, "bn_finalize: var_unbias must be positive");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(dl3_cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, stat_partial, P,
-                     ldc, C, count, gamma, beta, eps, momentum, scale, shift, mean, invstd, moving_mean,
+                     ldc, C, count, gamma, beta, eps, momentum, var_unbias, scale, shift, mean, invstd, moving_mean,
                      moving_var);
   DL3_LAUNCH_CHECK("bn_finalize");
   return DL3_OK;
@@ -394,7 +404,8 @@ extern "C" int dl3_reduce_partials(const float *partial, int P, int n, float *ou
 
 extern "C" int dl3_affine_add(const float *a, int lda, const float *sa, const float *ta, int act_a,
                               const float *b, int ldb, const float *sb, const float *tb, int act_b, float *out,
-                              int ldo, int M, int C, float drop_rate, unsigned long long drop_seed, void *stream) {
+                              int ldo, int M, int C, float drop_rate, unsigned long long drop_seed,
+                              const unsigned long long *drop_step, void *stream) {
   DL3_CHECK_ARG(a && out && M > 0 && C > 0, "affine_add: bad argument");
   DL3_CHECK_ARG((sa == nullptr) == (ta == nullptr) && (sb == nullptr) == (tb == nullptr),
                 "affine_add: scale/shift must come together");
@@ -405,10 +416,10 @@ extern "C" int dl3_affine_add(const float *a, int lda, const float *sa, const fl
   if (v4)
     hipLaunchKernelGGL(affine_add4_kernel, dim3(ew_blocks((size_t)M * C / 4)), dim3(256), 0, (hipStream_t)stream, a,
                        lda, sa, ta, act_a, b, ldb, sb, tb, act_b, out, ldo, (unsigned)((size_t)M * C / 4),
-                       (unsigned)(C / 4), drop_rate, drop_seed);
+                       (unsigned)(C / 4), drop_rate, drop_seed, drop_step);
   else
     hipLaunchKernelGGL(affine_add_kernel, dim3(ew_blocks((size_t)M * C)), dim3(256), 0, (hipStream_t)stream, a, lda,
-                       sa, ta, act_a, b, ldb, sb, tb, act_b, out, ldo, (long)M, C, drop_rate, drop_seed);
+                       sa, ta, act_a, b, ldb, sb, tb, act_b, out, ldo, (long)M, C, drop_rate, drop_seed, drop_step);
   DL3_LAUNCH_CHECK("affine_add");
   return DL3_OK;
 }
@@ -417,7 +428,8 @@ extern "C" int dl3_grad_finish(const float *gin, int ldgin, int gin_div, float g
                                const float *add, int ldadd,
                                const float *xraw, int ldx, const float *scale, const float *shift, int act,
                                const float *mean, const float *invstd, float *dstat_partial, int M, int C,
-                               float drop_rate, unsigned long long drop_seed, void *stream) {
+                               float drop_rate, unsigned long long drop_seed, const unsigned long long *drop_step,
+                               void *stream) {
   DL3_CHECK_ARG(gin && gout && M > 0 && C > 0, "grad_finish: bad argument");
   DL3_CHECK_ARG(act == DL3_ACT_NONE || xraw, "grad_finish: activation mask needs xraw");
   DL3_CHECK_ARG(!dstat_partial || (xraw && mean && invstd), "grad_finish: dstat needs xraw, mean, invstd");
@@ -426,7 +438,7 @@ extern "C" int dl3_grad_finish(const float *gin, int ldgin, int gin_div, float g
   hipLaunchKernelGGL(grad_finish_kernel, grid, dim3(256), 0, (hipStream_t)stream, gin, ldgin, gin_div, gin_scale,
                      gout, ldgout, add,
                      ldadd, xraw, ldx, scale, shift, act, mean, invstd, dstat_partial, (long)M, C, drop_rate,
-                     drop_seed);
+                     drop_seed, drop_step);
   DL3_LAUNCH_CHECK("grad_finish");
   return DL3_OK;
 }
@@ -446,6 +458,13 @@ extern "C" int dl3_fill(float *p, float value, size_t n, void *stream) {
   DL3_CHECK_ARG(p && n > 0, "fill: bad argument");
   hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, value, n);
   DL3_LAUNCH_CHECK("fill");
+  return DL3_OK;
+}
+
+extern "C" int dl3_counter_add(unsigned long long *counter, unsigned long long inc, void *stream) {
+  DL3_CHECK_ARG(counter, "counter_add: null pointer");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, inc);
+  DL3_LAUNCH_CHECK("counter_add");
   return DL3_OK;
 }
 

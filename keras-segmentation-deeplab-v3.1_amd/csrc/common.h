@@ -88,6 +88,12 @@ __device__ __forceinline__ float dl3_uniform(unsigned long long seed, unsigned l
   return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
 
+// Dropout draws a fresh mask every training step: the launch arguments are frozen inside a captured hipGraph, so the
+// step number lives in device memory (dl3_counter_add bumps it inside the graph) and is mixed into the seed here.
+__device__ __forceinline__ unsigned long long dl3_step_seed(unsigned long long seed, const unsigned long long *step) {
+  return step ? seed + step[0] * 0xD1B54A32D192ED03ull : seed;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
   // 64-lane butterfly
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -188,8 +188,8 @@ __global__ void count_to_float_kernel(unsigned int *cnt) {
 }
 
 // loss_partial[blockIdx.x] = sum over the block's rows of w*(-log clip(p_label))/nnz;
-// dlogits = (p - onehot) * w / nnz ; label == C (void) -> onehot = 0 and, by the generator's
-// contract (utils.py:388-399), w = 0.
+// dlogits = (p - onehot) * w / nnz ; label == C (void) -> the one-hot row is all zero (utils.py:129), so the row
+// contributes neither loss nor gradient whatever its sample weight.
 __global__ __launch_bounds__(256) void softmax_xent_kernel(const float *__restrict__ x,
                                                            const float *__restrict__ labels,
                                                            const float *__restrict__ weights,
@@ -207,7 +207,9 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float *__restri
     for (int c = 0; c < C; c++) s += expf(r[c] - mx);
     const float inv = 1.f / s;
     const int t = (int)labels[m];
-    const float w = weights ? weights[m] : 1.f;
+    // void rows (label == C or out of range): the one-hot row is all zero, so loss AND gradient are zero whatever the
+    // sample weight (utils.py:129 drops the last one-hot column)
+    const float w = (t >= 0 && t < C) ? (weights ? weights[m] : 1.f) : 0.f;
     float psum = 0.f, pt = 0.f;
     for (int c = 0; c < C; c++) {
       const float pc = expf(r[c] - mx) * inv;
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256) void xent32_kernel(const float *__restrict__ x
     }
     const float inv = 1.f / ssum;
     const int t = (int)labels[mc];
-    const float w = weights ? weights[mc] : 1.f;
+    const float w = (t >= 0 && t < C) ? (weights ? weights[mc] : 1.f) : 0.f;  // void rows: zero loss and gradient
     float psum = 0.f, pt = 0.f;
 #pragma unroll
     for (int c = 0; c < MAXC; c++) {
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256) void xent32_fold_kernel(const float *__restric
       const float inv = 1.f / ssum;
       const size_t m = (size_t)row * Wo + ox;
       const int t = (int)labels[m];
-      const float w = weights ? weights[m] : 1.f;
+      const float w = (t >= 0 && t < C) ? (weights ? weights[m] : 1.f) : 0.f;  // void rows: zero loss and gradient
       float psum = 0.f, pt = 0.f;
 #pragma unroll
       for (int c = 0; c < MAXC; c++) {

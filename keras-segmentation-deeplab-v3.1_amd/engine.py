@@ -26,6 +26,21 @@ _ACT = {"relu": ACT_RELU, "relu6": ACT_RELU6}
 V_SCALE, V_SHIFT, V_MEAN, V_INVSTD, V_CA, V_CB, V_CC = range(7)
 
 
+def _unbias_keras224(n, eps):
+    """Keras 2.2.4 BatchNormalization.call on the TF 1.13 backend (the reference's environment):
+    tf.nn.fused_batch_norm hands back the Bessel-corrected batch variance (n/(n-1)) and the layer multiplies it by
+    sample_size / (sample_size - (1.0 + epsilon)) once more before the moving-average update."""
+    return (n / (n - 1.0) if n > 1 else 1.0) * (n / (n - (1.0 + eps)) if n > 1.0 + eps else 1.0)
+
+
+# moving_variance update factor on the biased batch variance (dl3_bn_finalize var_unbias), as a function of (n, eps)
+BN_VARIANCE = {
+    "keras224": _unbias_keras224,
+    "bessel": lambda n, eps: n / (n - 1.0) if n > 1 else 1.0,   # tf.keras / plain FusedBatchNorm
+    "biased": lambda n, eps: 1.0,
+}
+
+
 def _same_pads(size, k, stride, rate):
     out = -(-size // stride)
     total = max((out - 1) * stride + (k - 1) * rate + 1 - size, 0)
@@ -86,14 +101,19 @@ class View:
 
 class Engine:
     def __init__(self, model, batch, training, bn_mode="batch", dropout=True, seed=2, device=None, use_graph=True,
-                 dw_impl=IMPL_AUTO):
+                 dw_impl=IMPL_AUTO, rank=None, bn_variance="keras224"):
         if not torch.cuda.is_available():
             raise capi.DL3Error("the dl3 engine needs a GPU (HIP device); there is no CPU fallback")
         self.lib = capi.lib()
         self.model, self.B, self.training = model, int(batch), bool(training)
         self.bn_batch = self.training and bn_mode == "batch"
         self.dropout = bool(dropout) and self.training
-        self.seed = int(seed)
+        # Dropout mask = f(seed, step, element): every data-parallel rank draws its own masks, every step a new one
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        self.seed = (int(seed) + 0x632BE59BD9B4E019 * self.rank) & 0xFFFFFFFFFFFFFFFF
+        if bn_variance not in BN_VARIANCE:
+            raise ValueError("bn_variance must be one of %s" % sorted(BN_VARIANCE))
+        self.bn_variance = bn_variance
         self.device = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
         self.use_graph = use_graph
         self.fold_tail = os.environ.get("DL3_FOLD_TAIL", "1") != "0"  # 0: keep the full-resolution dlogits (test aid)
@@ -107,10 +127,13 @@ class Engine:
         self.graph = None
         self._calls = 0
         self._keep = []
+        self.drop_step = torch.zeros(1, dtype=torch.int64, device=self.device)  # device-side step number (dropout)
         self._build_params()
         self._lower()
         if self.training:
             self._lower_backward()
+            if self.dropout:
+                self.op(self.ops_bwd, "dl3_counter_add", self.drop_step.data_ptr(), 1)
         self.scratch = self.empty(max(self.scratch_bytes // 4, 4))
         for op in self._scratch_users:
             op[2][op[3]] = self.scratch.data_ptr()
@@ -343,10 +366,15 @@ class Engine:
         n = l.name
         v.buf.bns.append((l, v.off, C))
         if self.bn_batch:
+            # Keras 2.2.x collects no updates from a non-trainable layer: a frozen BatchNormalization still normalises
+            # with the batch statistics in the training phase, but its moving statistics stay as loaded
+            upd = l.trainable
             self.op(self.ops_fwd, "dl3_bn_finalize", ptr(unit.stat), unit.P, C, C, float(v.buf.M),
                     self.wptr(n + "/gamma:0"), self.wptr(n + "/beta:0"), l.cfg["eps"], l.cfg["momentum"],
+                    BN_VARIANCE[self.bn_variance](float(v.buf.M), float(l.cfg["eps"])),
                     v.buf.vptr(V_SCALE, v.off), v.buf.vptr(V_SHIFT, v.off), v.buf.vptr(V_MEAN, v.off),
-                    v.buf.vptr(V_INVSTD, v.off), self.wptr(n + "/moving_mean:0"), self.wptr(n + "/moving_variance:0"))
+                    v.buf.vptr(V_INVSTD, v.off), self.wptr(n + "/moving_mean:0") if upd else None,
+                    self.wptr(n + "/moving_variance:0") if upd else None)
         else:
             self.op(self.ops_prep, "dl3_bn_frozen", self.wptr(n + "/gamma:0"), self.wptr(n + "/beta:0"),
                     self.wptr(n + "/moving_mean:0"), self.wptr(n + "/moving_variance:0"), l.cfg["eps"], C,
@@ -593,7 +621,7 @@ class Engine:
                 ptr(add), buf.ld, ptr(buf.t) if need_x else None, buf.ld,
                 view.scale() if masked else None, view.shift() if masked else None, view.act,
                 buf.vptr(V_MEAN) if need_stat else None, buf.vptr(V_INVSTD) if need_stat else None, ptr(dpart),
-                buf.M, buf.ld, drop[0], drop[1])
+                buf.M, buf.ld, drop[0], drop[1], self.drop_step.data_ptr() if drop[0] > 0 else None)
         if need_stat:
             self.finish_bn_bwd(buf, dpart, P, buf.ld)
 
@@ -612,7 +640,7 @@ class Engine:
                     dpart = self.empty(P * buf.ld * 2)
                     self.op(self.ops_bwd, "dl3_grad_finish", ptr(g), buf.ld, 1, 1.0, ptr(g), buf.ld, None, 0,
                             ptr(buf.t), buf.ld, None, None, ACT_NONE, buf.vptr(V_MEAN), buf.vptr(V_INVSTD),
-                            ptr(dpart), buf.M, buf.ld, 0.0, 0)
+                            ptr(dpart), buf.M, buf.ld, 0.0, 0, None)
                     self.finish_bn_bwd(buf, dpart, P, buf.ld)
             else:
                 buf.addend = g
@@ -704,7 +732,9 @@ class Engine:
         assert yt.numel() == M, (yt.numel(), M)
         self.labels.copy_(yt.to(self.device, non_blocking=True))
         if sw is None:
-            self.sweights.copy_((self.labels != float(self.logits_view.C)).to(torch.float32))
+            # Keras without sample weights: plain mean over all B*HW pixels; void rows contribute zero loss and zero
+            # gradient through the one-hot (utils.py:129), not through a weight
+            capi.call("dl3_fill", ptr(self.sweights), 1.0, M, torch.cuda.current_stream().cuda_stream)
         elif torch.is_tensor(sw):
             self.sweights.copy_(sw.reshape(-1).to(self.device, torch.float32, non_blocking=True))
         else:
@@ -763,6 +793,18 @@ class Engine:
                   torch.cuda.current_stream().cuda_stream)
         self.iteration += 1
         self.dirty = True
+
+    def adopt_optimizer_state(self, other):
+        """continue another training engine's optimizer (same model, other batch size): Adam moments, iteration count
+        and the dropout step move device-to-device; the flat layouts are identical by construction"""
+        if other is self or not (self.training and other.training):
+            return
+        if other.adam_m.numel() != self.adam_m.numel() or other.n_param != self.n_param:
+            raise RuntimeError("optimizer state layouts differ (trainable flags changed between engines?)")
+        self.adam_m.copy_(other.adam_m)
+        self.adam_v.copy_(other.adam_v)
+        self.drop_step.copy_(other.drop_step)
+        self.iteration = other.iteration
 
     def train_step(self, x, y, sw=None, opt=None, comm=None):
         self.set_input(x)
@@ -973,7 +1015,7 @@ class AddUnit:
         sa, ta, aa = a.xform()
         sb, tb, ab = b.xform()
         eng.op(eng.ops_fwd, "dl3_affine_add", a.p(), a.ld, sa, ta, aa, b.p(), b.ld, sb, tb, ab, outv.p(), outv.ld,
-               outv.buf.M, outv.C, 0.0, 0)
+               outv.buf.M, outv.C, 0.0, 0, None)
 
     def bwd(self):
         g = self.outv.buf.grad
@@ -989,7 +1031,7 @@ class MaterializeUnit:
         eng._consume(inv)
         s, t, a = inv.xform()
         eng.op(eng.ops_fwd, "dl3_affine_add", inv.p(), inv.ld, s, t, a, None, 0, None, None, ACT_NONE, outv.p(),
-               outv.ld, outv.buf.M, outv.C, rate, seed)
+               outv.ld, outv.buf.M, outv.C, rate, seed, eng.drop_step.data_ptr())
 
     def bwd(self):
         g = self.outv.buf.grad

@@ -9,6 +9,7 @@ What callers of the reference touch is reproduced: `Model.input/.output/.layers/
 """
 import collections
 import math
+import os
 
 import numpy as np
 
@@ -340,6 +341,9 @@ class Model:
         self._collect()
         self._engines = {}
         self._compiled = None
+        self._dp = None          # parallel.DataParallel once distribute() was called
+        self._dp_synced = False
+        self._train_eng = None   # the engine that holds the live Adam moments / iteration / dropout step
 
     # -- graph -----------------------------------------------------------------------
     def _collect(self):
@@ -458,19 +462,47 @@ class Model:
         with temporal sample weights (utils.py:127-130)."""
         self._compiled = dict(optimizer=optimizer, loss=loss, metrics=metrics, sample_weight_mode=sample_weight_mode)
 
+    def distribute(self, dp=None):
+        """Per-image data parallelism for train_on_batch / fit: this process is one of WORLD_SIZE (one per GPU, launched
+        by torch.distributed.run); every call hands over the GLOBAL batch, each rank trains on its contiguous shard and
+        the gradients are averaged with one RCCL all-reduce (parallel.DataParallel).  Stands in for
+        keras.utils.multi_gpu_model (utils.py:209-211), whose towers likewise keep per-replica BatchNorm statistics."""
+        from .parallel import DataParallel
+        self._dp = dp if dp is not None else DataParallel()
+        self._dp_synced = False
+        return self
+
+    MAX_ENGINES = int(os.environ.get("DL3_MAX_ENGINES", "4"))
+
     def _engine(self, batch, training, **kw):
-        """engine for (batch, mode); weights travel through the host master copies when the active engine changes"""
+        """engine for (batch, mode); weights travel through the host master copies when the active engine changes, the
+        optimizer state (Adam moments, iteration, dropout step) moves device-to-device between training engines, and
+        the least recently used engines beyond MAX_ENGINES are dropped (each one owns a full activation arena)."""
         from .engine import Engine
         key = (int(batch), bool(training), tuple(sorted(kw.items())))
-        eng = self._engines.get(key)
+        eng = self._engines.pop(key, None)
         active = getattr(self, "_active", None)
         if eng is not active and active is not None:
             active.sync_all_to_host()
         if eng is None:
             eng = Engine(self, batch=int(batch), training=training, **kw)
-            self._engines[key] = eng
         elif eng is not active:
             eng.sync_all_to_device()
+        self._engines[key] = eng  # most recently used last
+        if training:
+            prev = self._train_eng
+            if prev is not None and prev is not eng:
+                eng.adopt_optimizer_state(prev)  # e.g. the last, smaller batch of an epoch keeps the same Adam
+            self._train_eng = eng
+        while len(self._engines) > self.MAX_ENGINES:
+            k0 = next(iter(self._engines))
+            old = self._engines[k0]
+            if old is eng or old is self._train_eng:
+                self._engines[k0] = self._engines.pop(k0)  # keep; move to the young end
+                if all(e is eng or e is self._train_eng for e in self._engines.values()):
+                    break
+                continue
+            del self._engines[k0]
         self._active = eng
         eng.activate()
         return eng
@@ -524,7 +556,9 @@ class Model:
             C = probs.shape[-1]
             probs = probs.reshape(xb.shape[0], -1, C)
             yb = yb.reshape(xb.shape[0], -1, 1)
-            w = (yb[:, :, 0] != C).astype(np.float64) if sample_weight is None else \
+            # no sample weights: Keras takes the plain mean over all B*HW pixels (void rows contribute 0 through the
+            # one-hot, utils.py:129); with weights: sum(l*w) / count(w != 0)
+            w = np.ones(yb.shape[:2], np.float64) if sample_weight is None else \
                 np.asarray(sample_weight[i:i + bs], np.float64).reshape(xb.shape[0], -1)
             ell = U.sparse_crossentropy_ignoring_last_label(yb, probs)
             num += float((ell * w).sum() / max((w != 0).mean(), 1e-30) / w.size) * xb.shape[0]
@@ -533,12 +567,42 @@ class Model:
         return [num / den, U.Jaccard_from_counts(counts), U.accuracy_from_counts(counts)]
 
     def train_on_batch(self, x, y, sample_weight=None, **engine_kw):
+        dp = self._dp
+        if dp is not None and dp.world > 1:
+            n = x.shape[0]
+            if n % dp.world:
+                raise ValueError("global batch %d does not split over %d ranks" % (n, dp.world))
+            lo, hi = dp.shard(n)
+            x, y = x[lo:hi], y[lo:hi]
+            if sample_weight is not None:
+                sample_weight = sample_weight[lo:hi]
         eng = self._engine(x.shape[0], True, **engine_kw)
         opt = (self._compiled or {}).get("optimizer") or {}
-        return eng.train_step(x, y, sample_weight, opt)
+        if dp is None or dp.world == 1:
+            return eng.train_step(x, y, sample_weight, opt)
+        if not self._dp_synced:  # identical weights and moving statistics on every rank before the first step
+            dp.broadcast(eng.params)
+            dp.broadcast(eng.state)
+            eng.dirty = True
+            self._dp_synced = True
+        loss = eng.train_step(x, y, sample_weight, opt, comm=dp)
+        return dp.mean_over_ranks(loss)
+
+    _IGNORED_FIT_KW = ("workers", "use_multiprocessing", "max_queue_size", "shuffle", "initial_epoch")
+
+    def _check_fit_kw(self, kw):
+        import warnings
+        for k, v in kw.items():
+            if k in self._IGNORED_FIT_KW or v is None or (isinstance(v, (list, tuple)) and not v):
+                continue
+            warnings.warn("dl3: Model.fit/fit_generator does not implement %r (the training loop of the reference, "
+                          "utils.py:216-254, is host-side control plane outside this package): it is IGNORED — drive "
+                          "callbacks / validation from your own loop around train_on_batch / evaluate" % k,
+                          RuntimeWarning, stacklevel=3)
 
     def fit(self, x, y, batch_size=16, epochs=1, sample_weight=None, verbose=0, **kw):
         """Minimal Model.fit (utils.py:244): plain epochs over (x, y) without shuffling or callbacks."""
+        self._check_fit_kw(kw)
         hist = []
         n = x.shape[0]
         for _ in range(epochs):
@@ -549,6 +613,7 @@ class Model:
 
     def fit_generator(self, generator, steps_per_epoch=None, epochs=1, verbose=0, **kw):
         """Minimal Model.fit_generator (utils.py:233): generator yields (X, Y, {'pred_mask': SW}) or (X, Y, SW)."""
+        self._check_fit_kw(kw)
         hist = []
         steps = steps_per_epoch or len(generator)
         for _ in range(epochs):

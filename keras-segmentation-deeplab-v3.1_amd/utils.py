@@ -176,8 +176,10 @@ class SegModel:
         """net='original': DeepLabV3+ body + conv_upsample 1x1 + bilinear (utils.py:188-193);
         net='subpixel': body + Subpixel(n, 1, scale) with ICNR init (utils.py:194-204).
         The body is Deeplabv3(weights=None, classes=21, OS=16) cut at model.layers[-5] (utils.py:177-181).
-        multi_gpu: the reference's in-graph keras.utils.multi_gpu_model (utils.py:209-211) is replaced by
-        one process per GPU + RCCL gradient all-reduce (parallel.py); the flag is accepted and ignored here."""
+        multi_gpu: the reference's in-graph keras.utils.multi_gpu_model (utils.py:209-211) becomes one process per
+        GPU + one RCCL all-reduce of the gradients per step: Model.distribute() attaches parallel.DataParallel, which
+        reads RANK / WORLD_SIZE (launch with `python -m torch.distributed.run --nproc-per-node <gpus> ...`); every
+        train_on_batch then takes the global batch and trains on this rank's shard."""
         model = Deeplabv3(weights=None, input_tensor=None, infer=False, input_shape=self.sz + (3,), classes=21,
                           backbone=backbone, OS=16, alpha=1)
         base_model = Model(model.input, model.layers[-5].output)
@@ -203,6 +205,13 @@ class SegModel:
                 layer.set_weights([icnr_weights(scale=scale, shape=c.shape), b])
         if load_weights:
             model.load_weights(self.modelpath)
+        if multi_gpu:
+            model.distribute()
+            if model._dp.world == 1:
+                import warnings
+                warnings.warn("multi_gpu=True in a single process: this package runs one process per GPU — launch the "
+                              "script with `python -m torch.distributed.run --nproc-per-node <gpus>` to use them",
+                              RuntimeWarning, stacklevel=2)
         self.model = model
         return model
 

@@ -171,7 +171,11 @@ def batchnorm(x, gamma, beta, mmean, mvar, eps, training, momentum=0.99, tape=No
     """BatchNormalization over the last axis.
     inference: gamma*(x-mm)/sqrt(mv+eps)+beta.
     training [TF-semantics FusedBatchNorm]: biased batch variance over (N,H,W) for the
-    normalisation; moving = m*moving + (1-m)*batch with the Bessel-corrected variance.
+    normalisation; moving = m*moving + (1-m)*batch.  The variance that enters the moving average, in the reference's
+    environment (Keras 2.2.4 on TF 1.13): tf.nn.fused_batch_norm returns the Bessel-corrected batch
+    variance (n/(n-1)) and keras/layers/normalization.py BatchNormalization.call then applies
+    `variance *= sample_size / (sample_size - (1.0 + self.epsilon))` on top of it — both factors are restated here
+    (from memory of those two sources; neither package is installable in this container).
     `stats_out` (dict) receives the updated moving statistics (side output, no gradient)."""
     axes = tuple(range(x.ndim - 1))
     if training:
@@ -183,6 +187,8 @@ def batchnorm(x, gamma, beta, mmean, mvar, eps, training, momentum=0.99, tape=No
         y = (xhat * gamma + beta).astype(x.dtype)
         if stats_out is not None:
             unb = var * M / (M - 1) if M > 1 else var
+            if M > 1.0 + eps:
+                unb = unb * (M / (M - (1.0 + eps)))
             stats_out["mean"] = (momentum * mmean + (1 - momentum) * mean).astype(x.dtype)
             stats_out["var"] = (momentum * mvar + (1 - momentum) * unb).astype(x.dtype)
             stats_out["batch_mean"] = mean
@@ -309,7 +315,9 @@ def loss_sparse_xent_ignoring_last_label(logits, labels, weights):
     l = -sum(y*log p); weighted: score = l*w; score /= mean(w != 0); loss = mean(score)
       => loss = sum(l*w)/count(w != 0).
     Returns (loss, dlogits) with dlogits = (p - onehot)*w/nnz (clip ignored, as TF's gradient of
-    softmax+log away from the clip)."""
+    softmax+log away from the clip).  A void row (label == C) has an all-zero one-hot row (utils.py:129 drops the last
+    column), so it contributes neither loss nor gradient — whatever its sample weight; a non-zero weight there still
+    counts in nnz, exactly as Keras' mean(w != 0) does."""
     C = logits.shape[-1]
     p = softmax(logits)
     t = labels.astype(np.int64)
@@ -322,7 +330,7 @@ def loss_sparse_xent_ignoring_last_label(logits, labels, weights):
     l = -(onehot * np.log(q)).sum(axis=-1)
     nnz = max(float((weights != 0).sum()), 1.0)
     loss = float((l * weights).sum(dtype=np.float64) / nnz)
-    dlogits = (p - onehot) * (weights / p.dtype.type(nnz))[..., None]
+    dlogits = (p - onehot) * (weights * valid / p.dtype.type(nnz))[..., None]
     return loss, dlogits.astype(logits.dtype), p
 
 

@@ -3,9 +3,12 @@
 Written against the same reference lines as oracle/dl3_oracle.py but with different machinery
 (NCHW torch.nn.functional convolutions with explicit F.pad, F.batch_norm, autograd for every
 gradient), so that an error in the hand-written numpy forward/backward formulas shows up as a
-disagreement (tests/test_oracle.py).  It also serves as the labelled "framework CPU path" proxy
-(torch/oneDNN on the host cores) in bench.py's cpu_baseline leg, because the reference's own
-Keras/TensorFlow CPU path cannot be installed here.
+disagreement (tests/test_oracle.py).  It shares NO code with dl3_oracle: the TF padding rule, the
+legacy bilinear resize (here: dense interpolation matrices built pixel by pixel) and the MobileNetV2
+block table are restated a second time below, so a slip in one restatement cannot hide in the other.
+It also serves as the labelled "framework CPU path" proxy (torch/oneDNN on the host cores) in
+bench.py's cpu_baseline leg, because the reference's own Keras/TensorFlow CPU path cannot be
+installed here.
 """
 import math
 
@@ -13,17 +16,57 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import dl3_oracle as O
 
 
 def _same(size, k, s, r):
-    out, beg, end = O.same_pads(size, k, s, r)
-    return beg, end
+    """[TF-semantics] padding='SAME' (tensorflow/core/framework/common_shape_fns.cc GetWindowedOutputSize):
+    the output has ceil(size/s) positions, the input is padded just enough for the last window to fit and the
+    extra pixel of an odd total goes AFTER the data."""
+    n_out = math.ceil(size / s)
+    span = (n_out - 1) * s + (k - 1) * r + 1   # extent covered by all windows (dilated kernel extent k + (k-1)(r-1))
+    need = span - size
+    if need < 0:
+        need = 0
+    before = need >> 1
+    return before, need - before
 
 
 def _explicit(size, k, s, r):
-    out, beg, end = O.explicit_pads(size, k, s, r)
-    return beg, end
+    """deeplabv3p.py:63-69 / :105-116 (stride != 1): kernel_size_effective = k + (k-1)(rate-1); pad_total =
+    effective - 1; pad_beg = pad_total // 2; pad_end = pad_total - pad_beg; ZeroPadding2D then a VALID conv."""
+    eff = k + (k - 1) * (r - 1)
+    tot = eff - 1
+    return tot // 2, tot - tot // 2
+
+
+def _resize_matrix(n_out, n_in, dtype):
+    """[TF-semantics] tf.image.resize_bilinear of TF 1.x (align_corners=False, no half-pixel centres,
+    tensorflow/core/kernels/resize_bilinear_op.cc compute_interpolation_weights): for output index i the source
+    coordinate is i * (n_in / n_out) evaluated in float32; it blends floor(coord) and min(floor+1, n_in-1) with
+    weight coord - floor.  Returned as a dense [n_out, n_in] matrix, one row per output pixel."""
+    R = np.zeros((n_out, n_in), np.float64)
+    ratio = np.float32(n_in) / np.float32(n_out)
+    for i in range(n_out):
+        coord = np.float32(i) * ratio
+        base = int(math.floor(float(coord)))
+        nxt = base + 1 if base + 1 <= n_in - 1 else n_in - 1
+        frac = float(np.float32(coord - np.float32(base)))
+        R[i, base] += 1.0 - frac
+        R[i, nxt] += frac
+    return torch.tensor(R, dtype=dtype)
+
+
+# MobileNetV2 body as the reference calls _inverted_res_block (deeplabv3p.py:327-367): one row per call,
+# (filters, stride, expansion, block_id, skip_connection, rate); alpha = 1
+_MNV2_CALLS = (
+    (16, 1, 1, 0, False, 1),
+    (24, 2, 6, 1, False, 1), (24, 1, 6, 2, True, 1),
+    (32, 2, 6, 3, False, 1), (32, 1, 6, 4, True, 1), (32, 1, 6, 5, True, 1),
+    (64, 1, 6, 6, False, 1), (64, 1, 6, 7, True, 2), (64, 1, 6, 8, True, 2), (64, 1, 6, 9, True, 2),
+    (96, 1, 6, 10, False, 2), (96, 1, 6, 11, True, 2), (96, 1, 6, 12, True, 2),
+    (160, 1, 6, 13, False, 2), (160, 1, 6, 14, True, 4), (160, 1, 6, 15, True, 4),
+    (320, 1, 6, 16, False, 4),
+)
 
 
 class Ref:
@@ -39,6 +82,7 @@ class Ref:
         self.dropout_mask = dropout_mask
         self.bn_frozen = bn_frozen
         self.dtype = dtype
+        self.batch_stats = {}  # BN layer name -> (batch mean, biased batch variance) of the last training forward
 
     # x is NCHW throughout
     def conv(self, x, name, k=1, stride=1, same=True, bias=False):
@@ -68,22 +112,17 @@ class Ref:
         g, b = self.t[name + "/gamma:0"], self.t[name + "/beta:0"]
         mm, mv = self.t[name + "/moving_mean:0"], self.t[name + "/moving_variance:0"]
         if self.training and not self.bn_frozen:
+            with torch.no_grad():
+                self.batch_stats[name] = (x.mean(dim=(0, 2, 3)).numpy(), x.var(dim=(0, 2, 3), unbiased=False).numpy())
             return F.batch_norm(x, None, None, g, b, True, 0.0, eps)
         return F.batch_norm(x, mm, mv, g, b, False, 0.0, eps)
 
     def resize(self, x, Ho, Wo):
+        """separable form out = Ry . x . Rx^T of the legacy bilinear resize (columns first, like TF's top/bottom lerp)"""
         Hi, Wi = x.shape[2], x.shape[3]
-        ylo, yhi, wy = O._tf1_lerp(Ho, Hi)
-        xlo, xhi, wx = O._tf1_lerp(Wo, Wi)
-        ylo, yhi, xlo, xhi = [torch.as_tensor(a) for a in (ylo, yhi, xlo, xhi)]
-        wy = torch.tensor(wy, dtype=x.dtype)[None, None, :, None]
-        wx = torch.tensor(wx, dtype=x.dtype)[None, None, None, :]
-        top_rows, bot_rows = x.index_select(2, ylo), x.index_select(2, yhi)
-        tl, tr = top_rows.index_select(3, xlo), top_rows.index_select(3, xhi)
-        bl, br = bot_rows.index_select(3, xlo), bot_rows.index_select(3, xhi)
-        top = tl + (tr - tl) * wx
-        bot = bl + (br - bl) * wx
-        return top + (bot - top) * wy
+        Ry, Rx = _resize_matrix(Ho, Hi, x.dtype), _resize_matrix(Wo, Wi, x.dtype)
+        cols = torch.einsum("nchw,xw->nchx", x, Rx)
+        return torch.einsum("yh,nchx->ncyx", Ry, cols)
 
     def sepconv(self, x, prefix, stride=1, rate=1, depth_activation=False, eps=1e-3):
         if not depth_activation:
@@ -133,7 +172,7 @@ class Ref:
         else:
             OS = 8
             x = F.relu6(self.bn(self.conv(x, "Conv", 3, 2), "Conv_BN"))
-            for bid, filters, stride, expansion, skip, rate in O.MNV2_BLOCKS:
+            for filters, stride, expansion, bid, skip, rate in _MNV2_CALLS:
                 inp = x
                 prefix = "expanded_conv_%d_" % bid if bid else "expanded_conv_"
                 if bid:
@@ -211,3 +250,16 @@ def train_grads(params, x, labels, weights, dropout_mask=None, bn_frozen=False, 
 def infer_logits(params, x, dtype=torch.float32, **kw):
     with torch.no_grad():
         return Ref(params, False, dtype=dtype).logits(x, **kw).numpy()
+
+
+def calibrate_bn(params, x, dtype=torch.float64, **kw):
+    """moving statistics := batch statistics of one training-mode forward on x (keeps the activations of a randomly
+    initialised net O(1) through 50-140 layers); the full-size counterpart of dl3_oracle.calibrate_bn."""
+    with torch.no_grad():
+        ref = Ref(params, True, dtype=dtype)
+        ref.logits(x, **kw)
+    out = dict(params)
+    for name, (m, v) in ref.batch_stats.items():
+        out[name + "/moving_mean:0"] = m.astype(np.float32)
+        out[name + "/moving_variance:0"] = v.astype(np.float32)
+    return out

@@ -27,10 +27,12 @@ def release():
     del _KEEP[:]
 
 
-def dropout_keep_mask(seed, n, rate):
-    """host replica of dl3_uniform (csrc/common.h): splitmix64 of (seed, element index) -> keep mask"""
+def dropout_keep_mask(seed, n, rate, step=0):
+    """host replica of dl3_uniform / dl3_step_seed (csrc/common.h): splitmix64 of (seed + step * odd constant,
+    element index) -> keep mask"""
     idx = np.arange(n, dtype=np.uint64)
     with np.errstate(over="ignore"):
+        seed = np.uint64(seed) + np.uint64(step) * np.uint64(0xD1B54A32D192ED03)
         z = np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15) * (idx + np.uint64(1))
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)

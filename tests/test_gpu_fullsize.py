@@ -1,0 +1,153 @@
+"""-m gpu parity at the sizes BASELINE.json quotes (512x512, 21 classes): the HIP path through libdl3.so against the
+float64 run of the independent torch restatement (oracle/torch_ref.py) on the same seeded inputs.
+
+  cfg2  Deeplabv3(mobilenetv2, 512x512x3, 21)            fwd + loss + bwd, B=2   (deeplabv3p.py:315-444)
+  cfg3  SegModel heads 'original' / 'subpixel'            fwd + loss + bwd, B=2   (utils.py:169-214, subpixel.py:41-103)
+  cfg4  Deeplabv3(xception, 512x512x3, 21, OS=8)         forward, B=1            (deeplabv3p.py:272-313,:389-402)
+        + the same architecture fwd + loss + bwd at 320x320, B=2 (40x40 ASPP map: rates 12/24/36 all have live taps)
+
+Bars (north star): logits <= 1e-3 relative, loss 1e-4, late-layer gradients <= 1e-3 rel-L2, argmax masks bit-exact.
+"Bit-exact" is checked per pixel: the flip COUNT is printed next to the flip count of the oracle's own fp32 run, and a
+GPU flip is accepted only on a pixel whose float64 top-2 margin lies inside the fp32 rounding distance of the ORACLE
+itself (4 x max|oracle_fp32 - oracle_fp64|) — i.e. a tie that fp32 arithmetic cannot resolve in any summation order.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dl3_oracle as O
+from oracle import torch_ref as T
+from tests.gpu_util import relerr
+from tests.test_gpu_model import _build, _l2, _load
+
+pytestmark = pytest.mark.gpu
+
+
+def _flips(mask, ref64, ref32, what):
+    """argmax parity report + assertion (see module docstring)"""
+    want = ref64.argmax(-1)
+    diff = mask != want
+    o32 = ref32.argmax(-1) != want
+    noise = 4.0 * float(np.abs(ref32.astype(np.float64) - ref64).max())
+    srt = np.sort(ref64, axis=-1)
+    margin = srt[..., -1] - srt[..., -2]
+    worst = float(margin[diff].max()) if diff.any() else 0.0
+    print("%s: argmax flips gpu %d / oracle-fp32 %d of %d pixels; largest margin at a gpu flip %.3e, fp32 noise "
+          "yardstick %.3e (max|logit| %.3f)" % (what, int(diff.sum()), int(o32.sum()), diff.size, worst, noise,
+                                                float(np.abs(ref64).max())))
+    assert worst <= noise, "argmax flipped on a pixel fp32 can resolve: margin %.3e > %.3e" % (worst, noise)
+    return int(diff.sum())
+
+
+def _data(shape, B, classes, seed=0):
+    rng = np.random.default_rng(seed)
+    x = rng.integers(0, 256, (B,) + shape).astype(np.float32)
+    H, W = shape[:2]
+    labels = rng.integers(0, classes + 1, (B, H * W)).astype(np.float32)  # classes == void
+    sw = ((labels < classes) * rng.uniform(0.5, 2.0, labels.shape)).astype(np.float32)
+    return x, labels, sw
+
+
+LATE = {
+    "mobilenetv2": ["concat_projection/kernel:0", "aspp0/kernel:0", "image_pooling/kernel:0", "concat_projection_BN/gamma:0",
+                    "expanded_conv_16_project/kernel:0", "expanded_conv_16_depthwise/depthwise_kernel:0",
+                    "expanded_conv_14_expand/kernel:0"],
+    "xception": ["decoder_conv1_pointwise/kernel:0", "decoder_conv0_depthwise/depthwise_kernel:0",
+                 "feature_projection0/kernel:0", "concat_projection/kernel:0", "aspp1_depthwise/depthwise_kernel:0",
+                 "aspp2_depthwise/depthwise_kernel:0", "aspp3_depthwise/depthwise_kernel:0", "aspp3_pointwise/kernel:0",
+                 "aspp0/kernel:0"],
+}
+HEAD_W = {"deeplab": "logits_semantic", "original": "conv_upsample", "subpixel": "subpixel_1"}
+
+
+def _train_parity(backbone, shape, head, OS, B):
+    classes = 21
+    import dl3_amd  # noqa: F401
+    from dl3_amd import graph as G
+    from dl3_amd.deeplabv3p import Deeplabv3
+    if head == "deeplab":
+        G.clear_session()
+        model = Deeplabv3(weights=None, input_shape=shape, classes=classes, backbone=backbone, OS=OS)
+        params = O.init_params(O.param_shapes(backbone, classes), seed=1)
+    else:
+        model, params = _build(backbone, shape, classes, head)
+    _load(model, params)
+    x, labels, sw = _data(shape, B, classes)
+    kw = dict(backbone=backbone, input_shape=shape, classes=classes, OS=OS, head=head)
+    eng = model._engine(B, True, dropout=False, use_graph=False)
+    eng.set_input(x)
+    eng.set_targets(labels, sw)
+    eng.fwd_bwd()
+    torch.cuda.synchronize()
+    got_logits = eng.logits()
+    got_loss = float(eng.loss[0].item())
+    loss, grads, logits = T.train_grads(params, x, labels, sw, dtype=torch.float64, **kw)
+    loss32, grads32, logits32 = T.train_grads(params, x, labels, sw, dtype=torch.float32, **kw)
+    tag = "%s/%s OS=%d %dx%d B=%d" % (backbone, head, OS, shape[0], shape[1], B)
+    e = relerr(got_logits, logits)
+    print("%s: logits rel err %.2e (oracle fp32: %.2e) | loss gpu %.7f oracle %.7f" % (
+        tag, e, relerr(logits32, logits), got_loss, loss))
+    assert e < 1e-3
+    assert abs(got_loss - loss) < 1e-4 * abs(loss)
+    _flips(got_logits.argmax(-1), logits, logits32, tag)
+    assert np.array_equal(eng.argmax(), got_logits.argmax(-1))  # dl3_argmax == np.argmax on the same logits
+    num = den = n32 = 0.0
+    worst, wname = 0.0, None
+    for name, g in grads.items():
+        if g is None or np.abs(g).max() < 1e-9:
+            continue
+        got = eng.grad_of(name).astype(np.float64)
+        num += float(np.sum((got - g) ** 2))
+        n32 += float(np.sum((grads32[name].astype(np.float64) - g) ** 2))
+        den += float(np.sum(g ** 2))
+        el = _l2(got, g)
+        if el > worst and np.linalg.norm(g) > 1e-6 * np.sqrt(den):
+            worst, wname = el, name
+    whole, whole32 = np.sqrt(num / den), np.sqrt(n32 / den)
+    print("%s: gradient rel-L2 whole vector gpu %.2e / oracle-fp32 %.2e; worst tensor %s %.2e" % (
+        tag, whole, whole32, wname, worst))
+    late = LATE[backbone] + [HEAD_W[head] + "/kernel:0", HEAD_W[head] + "/bias:0"]
+    for name in late:
+        el = _l2(eng.grad_of(name), grads[name])
+        print("   %-52s rel-L2 %.2e (oracle fp32 %.2e)" % (name, el, _l2(grads32[name], grads[name])))
+        assert el < 1e-3, (name, el)
+    # the whole vector goes through 50-140 BatchNorm backward passes: bounded by the oracle's own fp32 distance
+    assert whole < max(2e-3, 4.0 * whole32), (whole, whole32)
+    return eng
+
+
+@pytest.mark.parametrize("head", ["deeplab", "original", "subpixel"])
+def test_cfg2_cfg3_mnv2_512_train_step(head):
+    """BASELINE.json configs[1] and [2]: MobileNetV2 512x512x21, bilinear and Subpixel(+ICNR-shaped) heads, B=2"""
+    _train_parity("mobilenetv2", (512, 512, 3), head, 16, 2)
+
+
+def test_cfg4_xception_os8_512_forward():
+    """BASELINE.json configs[3]: Xception OS=8 at 512x512x21, single-image forward (inference BN statistics)."""
+    import dl3_amd  # noqa: F401
+    from dl3_amd import graph as G
+    from dl3_amd.deeplabv3p import Deeplabv3
+    shape, classes = (512, 512, 3), 21
+    G.clear_session()
+    model = Deeplabv3(weights=None, input_shape=shape, classes=classes, backbone="xception", OS=8)
+    kw = dict(backbone="xception", input_shape=shape, classes=classes, OS=8)
+    params = O.init_params(O.param_shapes("xception", classes), seed=1)
+    x, _, _ = _data(shape, 2, classes, seed=2)
+    params = T.calibrate_bn(params, x, dtype=torch.float32, **kw)  # moving statistics from the 2-image batch
+    _load(model, params)
+    x1 = x[:1]
+    probs = model.predict(x1, batch_size=1)
+    got = model._active.logits()
+    ref = T.infer_logits(params, x1, dtype=torch.float64, **kw)
+    ref32 = T.infer_logits(params, x1, dtype=torch.float32, **kw)
+    e = relerr(got, ref)
+    print("xception OS=8 512x512 forward: logits rel err %.2e (oracle fp32: %.2e)" % (e, relerr(ref32, ref)))
+    assert e < 1e-3
+    _flips(model._active.argmax(), ref, ref32, "xception OS=8 512x512 B=1")
+    assert np.allclose(probs.reshape(ref.shape), O.softmax(ref), atol=1e-4)
+
+
+def test_cfg4_xception_os8_320_train_step():
+    """cfg4's architecture, fwd + loss + bwd, on the largest input the float64 oracle finishes in about a minute
+    (320x320, B=2: 40x40 ASPP map, so the rate-12/24/36 branches all have live side taps)."""
+    _train_parity("xception", (320, 320, 3), "deeplab", 8, 2)

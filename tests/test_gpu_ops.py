@@ -5,7 +5,8 @@ import pytest
 import torch
 
 from oracle import dl3_oracle as O
-from tests.gpu_util import (call, dev, empty, fold_partials, host, np_act, np_mask, ptr, relerr, stream)
+from tests.gpu_util import (call, dev, dropout_keep_mask, empty, fold_partials, host, np_act, np_mask, ptr, relerr,
+                            stream)
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-4
@@ -45,6 +46,13 @@ DW_CASES = [
     (1, 20, 96, 40, 1, 2, None, 0, 1),     # ... one and a half segments, C not a multiple of 32
     (2, 9, 33, 32, 1, 1, None, 0, 2),      # ... odd width
     (1, 40, 80, 64, 1, 8, None, 0, None),  # ... rate 8
+    # Xception OS=8 ASPP (deeplabv3p.py:273-277,:390-399): the 64x64x2048 map of cfg4 at rates 12 / 24 / 36 — side taps
+    # live (unlike the 8x8 map of the small model test), several row phases per workgroup
+    (1, 64, 64, 2048, 1, 12, None, 0, 1),
+    (1, 64, 64, 2048, 1, 24, None, 0, 1),
+    (1, 64, 64, 2048, 1, 36, None, 0, 1),
+    (1, 64, 64, 728, 1, 2, None, 0, 1),    # middle flow at OS=8: 728 channels (22.75 slabs of 32), rate 2
+    (1, 33, 33, 1536, 1, 4, None, 0, 1),   # exit flow rate 4, odd map
 ]
 
 
@@ -126,6 +134,16 @@ def test_dwconv_phases_per_workgroup(L, ppb, monkeypatch):
     test_dwconv_bwd(L, case)
 
 
+@pytest.mark.parametrize("rate", [12, 24, 36])
+@pytest.mark.parametrize("ppb", [1, 4, 7])
+def test_dwconv_aspp_rates_forced_phases(L, rate, ppb, monkeypatch):
+    """the large-rate multi-phase path (DL3_DW_PPB) at the ASPP rates themselves, on a 64x64 map with live side taps"""
+    monkeypatch.setenv("DL3_DW_PPB", str(ppb))
+    case = (1, 64, 64, 96, 1, rate, None, 2, 1)
+    test_dwconv_fwd(L, case)
+    test_dwconv_bwd(L, case)
+
+
 def test_dwconv_bwd_plain_operand(L):
     """cA == NULL (dY = g), no add, no stats, no dx"""
     N, H, W, C = 2, 16, 16, 32
@@ -158,6 +176,14 @@ PW_CASES = [
     (4, 320, 256, 0, 0, False, None),    # image-pooling branch: M = batch
     (256, 256, 1344, 0, 0, True, None),  # Subpixel head
     (256, 64, 384, 64, 0, False, 2),     # reads a channel slice
+    # shapes only Xception has (deeplabv3p.py:272-313,:414-429): 728 = 22.75 x 32, 1536, 2048, decoder 304 / 48
+    (520, 728, 728, 0, 0, False, 1),
+    (300, 1024, 1536, 0, 0, False, 1),
+    (260, 1536, 2048, 0, 0, False, 1),
+    (200, 2048, 256, 0, 1024, False, 1),  # aspp pointwise into a slice of the 1280-wide concat buffer
+    (384, 304, 256, 0, 0, False, 1),     # decoder_conv0_pointwise
+    (384, 256, 48, 0, 256, False, None),  # feature_projection0 into the [x, dec_skip1] concat slice
+    (128, 256, 728, 0, 0, False, 1),
 ]
 
 
@@ -210,6 +236,12 @@ BD_CASES = [
     (256, 320, 256, None, True, 2, True),    # + broadcast per-image addend (global-pool branch)
     (130, 144, 24, 2, True, 0, True),
     (256, 512, 256, 1, True, 0, True),
+    (520, 728, 728, 1, True, 1, True),       # Xception middle flow (+ residual gradient)
+    (260, 1536, 2048, 1, True, 0, True),
+    (300, 1024, 1536, 1, True, 0, True),
+    (200, 2048, 256, 1, True, 0, True),      # aspp pointwise: dX is 2048 wide
+    (384, 304, 256, 1, True, 0, True),
+    (384, 256, 48, 1, True, 0, False),
 ]
 
 
@@ -265,6 +297,12 @@ BW_CASES = [
     (4096, 96, 576, 2, True, False),
     (512, 512, 256, 1, True, False),
     (700, 24, 144, None, True, False),
+    (1040, 728, 728, 1, True, False),        # Xception-only shapes
+    (600, 1536, 2048, 1, True, False),
+    (600, 2048, 256, 1, True, False),
+    (768, 304, 256, 1, True, False),
+    (768, 256, 48, 1, True, False),
+    (520, 1024, 1536, 1, True, False),
 ]
 
 
@@ -355,13 +393,20 @@ def test_bn_finalize_and_bwd(L):
     outs = [empty(C) for _ in range(4)]
     mmd, mvd = dev(mm), dev(mv)
     pd = dev(part)
-    call("dl3_bn_finalize", ptr(pd, 2 * c0), P, ldc, C, count, ptr(dev(gamma)), ptr(dev(beta)), eps, mom,
+    # var_unbias: Keras 2.2.4 on TF 1.13 = n/(n-1) * n/(n-(1+eps)) (include/dl3.h)
+    unb = count / (count - 1) * count / (count - (1 + eps))
+    call("dl3_bn_finalize", ptr(pd, 2 * c0), P, ldc, C, count, ptr(dev(gamma)), ptr(dev(beta)), eps, mom, unb,
          *[ptr(o) for o in outs], ptr(mmd), ptr(mvd))
     sc, sh, me, isd = [host(o) for o in outs]
     assert relerr(sc, gamma * invstd) < 1e-5 and relerr(sh, beta - mean * gamma * invstd) < 1e-5
     assert relerr(me, mean) < 1e-5 and relerr(isd, invstd) < 1e-5
-    assert relerr(host(mmd), mom * mm + (1 - mom) * mean) < 1e-5
-    assert relerr(host(mvd), mom * mv + (1 - mom) * var * count / (count - 1)) < 1e-5
+    assert relerr(host(mmd), mom * mm + (1 - mom) * mean) < 1e-6
+    assert relerr(host(mvd), mom * mv + (1 - mom) * var * unb) < 1e-6
+    # a non-trainable layer: same (scale, shift), moving statistics not touched (NULL pointers)
+    outs3 = [empty(C) for _ in range(4)]
+    call("dl3_bn_finalize", ptr(pd, 2 * c0), P, ldc, C, count, ptr(dev(gamma)), ptr(dev(beta)), eps, mom, unb,
+         *[ptr(o) for o in outs3], None, None)
+    assert np.array_equal(host(outs3[0]), sc) and np.array_equal(host(outs3[1]), sh)
     # frozen
     outs2 = [empty(C) for _ in range(4)]
     call("dl3_bn_frozen", ptr(dev(gamma)), ptr(dev(beta)), ptr(dev(mm)), ptr(dev(mv)), eps, C, *[ptr(o) for o in outs2])
@@ -402,20 +447,38 @@ def test_affine_add_and_dropout(L):
     sa, ta = rng.uniform(0.5, 1.5, C).astype(np.float32), rng.normal(0, 1, C).astype(np.float32)
     out = empty(M, C)
     call("dl3_affine_add", ptr(dev(a)), C, ptr(dev(sa)), ptr(dev(ta)), 2, ptr(dev(b)), C, None, None, 0, ptr(out), C, M,
-         C, 0.0, 0)
+         C, 0.0, 0, None)
     assert relerr(host(out), np_act(sa * a + ta, 2) + b) < 1e-6
     # dropout: deterministic mask of the right density, identical between forward and gradient kernels
     M2, C2 = 4096, 256
     ones = np.ones((M2, C2), np.float32)
     o1, o2 = empty(M2, C2), empty(M2, C2)
-    call("dl3_affine_add", ptr(dev(ones)), C2, None, None, 0, None, 0, None, None, 0, ptr(o1), C2, M2, C2, 0.1, 1234)
+    call("dl3_affine_add", ptr(dev(ones)), C2, None, None, 0, None, 0, None, None, 0, ptr(o1), C2, M2, C2, 0.1, 1234, None)
     call("dl3_grad_finish", ptr(dev(ones)), C2, 1, 1.0, ptr(o2), C2, None, 0, None, 0, None, None, 0, None, None, None,
-         M2, C2, 0.1, 1234)
+         M2, C2, 0.1, 1234, None)
     h1, h2 = host(o1), host(o2)
     assert np.array_equal(h1, h2)
     keep = (h1 != 0).mean()
     assert abs(keep - 0.9) < 5e-3
     assert np.allclose(h1[h1 != 0], 1 / 0.9)
+    assert np.array_equal(h1 != 0, dropout_keep_mask(1234, M2 * C2, 0.1).reshape(M2, C2) != 0)
+    # the step number lives in device memory (dl3_counter_add): step 0 == no step pointer, every further step draws a
+    # new mask, identically in the forward and the gradient kernel, and the host replica follows
+    step = torch.zeros(1, dtype=torch.int64, device="cuda")
+    masks = []
+    for it in range(3):
+        call("dl3_affine_add", ptr(dev(ones)), C2, None, None, 0, None, 0, None, None, 0, ptr(o1), C2, M2, C2, 0.1, 1234,
+             step.data_ptr())
+        call("dl3_grad_finish", ptr(dev(ones)), C2, 1, 1.0, ptr(o2), C2, None, 0, None, 0, None, None, 0, None, None,
+             None, M2, C2, 0.1, 1234, step.data_ptr())
+        call("dl3_counter_add", step.data_ptr(), 1)
+        m1, m2 = host(o1) != 0, host(o2) != 0
+        assert np.array_equal(m1, m2)
+        assert np.array_equal(m1, dropout_keep_mask(1234, M2 * C2, 0.1, step=it).reshape(M2, C2) != 0)
+        masks.append(m1)
+    assert int(step.item()) == 3
+    assert np.array_equal(masks[0], h1 != 0)
+    assert 0.15 < (masks[0] != masks[1]).mean() < 0.21 and 0.15 < (masks[1] != masks[2]).mean() < 0.21  # 2*0.9*0.1
 
 
 def test_grad_finish_and_gap(L):
@@ -429,7 +492,7 @@ def test_grad_finish_and_gap(L):
     P = L.dl3_rows_partials(M)
     out, part = empty(M, C), empty(P, C, 2)
     call("dl3_grad_finish", ptr(dev(g)), C, 1, 1.0, ptr(out), C, ptr(dev(add)), C, ptr(dev(x)), C, ptr(dev(s)),
-         ptr(dev(t)), 1, ptr(dev(mean)), ptr(dev(invstd)), ptr(part), M, C, 0.0, 0)
+         ptr(dev(t)), 1, ptr(dev(mean)), ptr(dev(invstd)), ptr(part), M, C, 0.0, 0, None)
     ref = g * np_mask(s * x + t, 1) + add
     assert relerr(host(out), ref) < 1e-6
     s1, s2 = fold_partials(part, P, C)
@@ -439,7 +502,7 @@ def test_grad_finish_and_gap(L):
     gv = rng.normal(0, 1, (M // HW, C)).astype(np.float32)
     acc = dev(add)
     call("dl3_grad_finish", ptr(dev(gv)), C, HW, 1.0 / HW, ptr(acc), C, ptr(acc), C, None, 0, None, None, 0, None, None,
-         None, M, C, 0.0, 0)
+         None, M, C, 0.0, 0, None)
     assert relerr(host(acc), add + np.repeat(gv, HW, axis=0) / HW) < 1e-6
     # global average pool with transform, reading a channel slice
     N = M // HW

@@ -109,7 +109,10 @@ def test_batchnorm_and_loss_semantics():
     y = O.batchnorm(x, g, b, np.zeros(3), np.ones(3), 1e-3, True, momentum=0.9, stats_out=st)
     m, v = x.mean((0, 1, 2)), x.var((0, 1, 2))
     assert np.allclose(y, (x - m) / np.sqrt(v + 1e-3) * g + b)
-    assert np.allclose(st["mean"], 0.1 * m) and np.allclose(st["var"], 0.9 + 0.1 * v * 100 / 99)
+    # moving variance [Keras 2.2.4 on TF 1.13]: FusedBatchNorm's Bessel factor n/(n-1), then BatchNormalization.call's
+    # sample_size / (sample_size - (1 + epsilon)) on top (n = 4*5*5 = 100)
+    assert np.allclose(st["mean"], 0.1 * m)
+    assert np.allclose(st["var"], 0.9 + 0.1 * v * (100 / 99) * (100 / (100 - 1.001)), rtol=1e-12)
     # loss: void label (== C) contributes nothing and carries weight 0 (utils.py:127-130)
     logits = rng.normal(size=(1, 6, 3))
     labels = np.array([[0, 1, 2, 3, 3, 1]], float)
@@ -122,6 +125,14 @@ def test_batchnorm_and_loss_semantics():
     lp = logits.copy()
     lp[0, 1, 2] += eps
     assert abs((O.loss_sparse_xent_ignoring_last_label(lp, labels, w)[0] - loss) / eps - dl[0, 1, 2]) < 1e-5
+    # a void row with a NON-zero weight (uniform weights handed to fit): the one-hot row is all zero (utils.py:129), so
+    # it still has zero loss and zero gradient, but Keras counts it in mean(w != 0)
+    w2 = np.array([[1, 2, 1, 5, 0, 1]], float)
+    loss2, dl2, _ = O.loss_sparse_xent_ignoring_last_label(logits, labels, w2)
+    assert abs(loss2 - want * 4 / 5) < 1e-12 and np.all(dl2[0, 3] == 0) and np.allclose(dl2[0, :3] * 5, dl[0, :3] * 4)
+    lp = logits.copy()
+    lp[0, 3, 1] += eps
+    assert abs(O.loss_sparse_xent_ignoring_last_label(lp, labels, w2)[0] - loss2) < 1e-15
 
 
 def test_param_counts():
