@@ -567,12 +567,20 @@ def test_phase_shift(L):
     assert np.array_equal(host(back), x)
 
 
-def test_softmax_argmax_xent(L):
+def _sample_weights(rng, labels, C, void_w):
+    """temporal sample weights; void_w: NON-zero weights on the void pixels too (uniform weights handed to fit): the
+    void rows must still give zero loss and zero gradient, and count in nnz (Keras' mean(w != 0))"""
+    w = rng.uniform(0.5, 2, labels.shape)
+    return (w if void_w else (labels < C) * w).astype(np.float32)
+
+
+@pytest.mark.parametrize("C,void_w", [(21, False), (21, True), (40, False), (40, True)])
+def test_softmax_argmax_xent(L, C, void_w):
     rng = np.random.default_rng(13)
-    M, C = 5000, 21
+    M = 5000
     x = rng.normal(0, 3, (M, C)).astype(np.float32)
     labels = rng.integers(0, C + 1, M).astype(np.float32)
-    w = ((labels < C) * rng.uniform(0.5, 2, M)).astype(np.float32)
+    w = _sample_weights(rng, labels, C, void_w)
     p = empty(M, C)
     call("dl3_softmax_fwd", ptr(dev(x)), ptr(p), M, C)
     assert relerr(host(p), O.softmax(x.astype(np.float64))) < 1e-5
@@ -592,14 +600,15 @@ def test_softmax_argmax_xent(L):
     assert relerr(host(probs), p_ref[0]) < 1e-5
 
 
-def test_fused_upsample_xent(L):
+@pytest.mark.parametrize("void_w", [False, True])
+def test_fused_upsample_xent(L, void_w):
     """dl3_upsample_softmax_xent == resize_bilinear_fwd followed by softmax_xent"""
     rng = np.random.default_rng(16)
     N, Hi, Wi, Ho, Wo, C = 2, 8, 8, 64, 64, 21
     lo = rng.normal(0, 2, (N, Hi, Wi, C)).astype(np.float32)
     M = N * Ho * Wo
     labels = rng.integers(0, C + 1, M).astype(np.float32)
-    w = ((labels < C) * rng.uniform(0.5, 2, M)).astype(np.float32)
+    w = _sample_weights(rng, labels, C, void_w)
     up = O.resize_bilinear_tf1(lo.astype(np.float64), Ho, Wo).reshape(1, M, C)
     loss_ref, dl_ref, p_ref = O.loss_sparse_xent_ignoring_last_label(up, labels[None], w.astype(np.float64)[None])
     nnz = empty(1)
@@ -613,8 +622,9 @@ def test_fused_upsample_xent(L):
     assert abs(host(lp).astype(np.float64).sum() - loss_ref) < 1e-5 * abs(loss_ref)
 
 
+@pytest.mark.parametrize("void_w", [False, True])
 @pytest.mark.parametrize("dims", [(2, 8, 8, 64, 64, 21), (1, 5, 7, 17, 23, 3), (3, 16, 16, 64, 64, 32), (2, 4, 4, 4, 4, 2)])
-def test_xent_fold_and_rows(L, dims):
+def test_xent_fold_and_rows(L, dims, void_w):
     """dl3_upsample_softmax_xent_fold + dl3_resize_bilinear_bwd_rows == the oracle's loss and the gradient it sends
     through the transposed legacy-bilinear resize, without the full-resolution dlogits"""
     N, Hi, Wi, Ho, Wo, C = dims
@@ -622,7 +632,7 @@ def test_xent_fold_and_rows(L, dims):
     lo = rng.normal(0, 2, (N, Hi, Wi, C))
     M = N * Ho * Wo
     labels = rng.integers(0, C + 1, M).astype(np.float32)
-    w = ((labels < C) * rng.uniform(0.5, 2, M)).astype(np.float32)
+    w = _sample_weights(rng, labels, C, void_w)
     tape = O.Tape()
     up = O.resize_bilinear_tf1(lo, Ho, Wo, tape=tape)
     loss_ref, dl_ref, _ = O.loss_sparse_xent_ignoring_last_label(up.reshape(1, M, C), labels[None], w.astype(np.float64)[None])

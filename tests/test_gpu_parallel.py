@@ -1,0 +1,164 @@
+"""-m gpu tests of the N>1 path on a ONE-GPU box.
+
+RCCL refuses two ranks on one device, so the two-process test moves the data plane onto gloo
+(DL3_DIST_BACKEND=gloo: gradients staged through host memory); everything else — sharding, per-rank dropout
+streams, the all-reduce + 1/world + Adam logic, Model.distribute()/train_on_batch — is the code the 8-GPU run uses.
+The RCCL binding itself (include/dl3.h dl3_comm_*) is exercised as a world of one, and bench.py's self-spawn form
+(`python bench.py --gpus 2`, the form the driver uses) end to end.
+"""
+import ctypes
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import dl3_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHAPE, CLASSES, GLOBAL_B = (64, 64, 3), 3, 4
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _data():
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (GLOBAL_B,) + SHAPE).astype(np.float32)
+    y = rng.integers(0, CLASSES + 1, (GLOBAL_B, SHAPE[0] * SHAPE[1], 1)).astype(np.float32)
+    sw = ((y[:, :, 0] < CLASSES) * rng.uniform(0.5, 2.0, y.shape[:2])).astype(np.float32)
+    return x, y, sw
+
+
+def _model(seed):
+    import dl3_amd  # noqa: F401
+    from dl3_amd import graph as G
+    from dl3_amd.deeplabv3p import Deeplabv3
+    G.clear_session()
+    model = Deeplabv3(weights=None, input_shape=SHAPE, classes=CLASSES, backbone="mobilenetv2", OS=16)
+    params = O.init_params(O.param_shapes("mobilenetv2", CLASSES), seed=seed)
+    for l in model.layers:
+        if l.weights:
+            l.set_weights([params[n] for n in l.weights])
+    return model
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), DL3_DIST_BACKEND="gloo")
+    torch.cuda.set_device(0)
+    model = _model(seed=1 + rank)  # deliberately different initial weights: the first step must broadcast rank 0's
+    model.compile(optimizer=dict(lr=7e-4))
+    model.distribute()
+    dp = model._dp
+    assert dp.world == 2 and dp.backend == "gloo" and dp.comm is None
+    x, y, sw = _data()
+    losses = [model.train_on_batch(x, y, sw, use_graph=False) for _ in range(2)]
+    eng = model._active
+    assert eng.B == GLOBAL_B // world and eng.rank == rank
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), grads=eng.grads.cpu().numpy(), params=eng.params.cpu().numpy(),
+             losses=np.array(losses), seed=np.array([eng.seed], np.uint64))
+    dp.close()
+
+
+def test_two_engine_processes_allreduce_equals_mean_of_shards(tmp_path):
+    """two Engine processes on one GPU: after train_on_batch on the global batch, every rank holds the same weights,
+    and the gradient arena of the LAST step equals — bit for bit — the mean of the two single-process shard gradients
+    computed from the same weights; a second run reproduces the same bits."""
+    runs = []
+    for rep in range(2):
+        d = tmp_path / ("run%d" % rep)
+        d.mkdir()
+        mp.spawn(_worker, args=(2, _free_port(), str(d)), nprocs=2, join=True)
+        runs.append([np.load(str(d / ("rank%d.npz" % r))) for r in (0, 1)])
+    r0, r1 = runs[0]
+    assert np.array_equal(r0["grads"], r1["grads"]) and np.array_equal(r0["params"], r1["params"])
+    assert np.array_equal(r0["losses"], r1["losses"])  # the mean over ranks is what every rank reports
+    assert int(r0["seed"][0]) != int(r1["seed"][0])    # per-rank dropout streams
+    for a, b in zip(runs[0], runs[1]):
+        assert np.array_equal(a["grads"], b["grads"]) and np.array_equal(a["params"], b["params"])
+    # single-process replay of both shards: step 1 from rank 0's initial weights, then the same Adam update
+    x, y, sw = _data()
+    model = _model(seed=1)
+    engs = [model._engine(2, True, use_graph=False, rank=r) for r in (0, 1)]
+    shard = lambda r: (x[2 * r:2 * r + 2], y[2 * r:2 * r + 2], sw[2 * r:2 * r + 2])
+    p0 = engs[1].params.clone()
+    for step in range(2):
+        g = []
+        for r, e in enumerate(engs):
+            e.params.copy_(p0)   # (BatchNorm runs on batch statistics: the per-replica moving statistics do not matter)
+            xs, ys, ws = shard(r)
+            e.set_input(xs)
+            e.set_targets(ys, ws)
+            e.fwd_bwd()
+            torch.cuda.synchronize()
+            g.append(e.grads.cpu().numpy().copy())
+        mean = (g[0] + g[1]) * np.float32(0.5)
+        if step == 1:
+            assert np.array_equal(r0["grads"] * np.float32(0.5), mean), "all-reduced gradient != mean of the shard gradients"
+        # the update every rank applied: Adam on the summed gradient with grad_scale = 1/world
+        e = engs[0]
+        e.grads.copy_(torch.from_numpy(g[0] + g[1]).cuda())
+        e.adam(dict(lr=7e-4), 0.5)
+        p0 = e.params.clone()
+    assert np.array_equal(r0["params"], p0.cpu().numpy())
+
+
+def test_rccl_binding_world_of_one():
+    """include/dl3.h dl3_comm_*: librccl is found (dlopen), a communicator comes up on cuda:0 and the collectives run on
+    the caller's stream (a world of one: all-reduce and broadcast are identities)."""
+    import dl3_amd  # noqa: F401
+    from dl3_amd import capi
+    L = capi.lib()
+    raw = ctypes.create_string_buffer(128)
+    capi.check(L.dl3_comm_unique_id(raw), "dl3_comm_unique_id")
+    assert any(raw.raw)
+    h = ctypes.c_void_p()
+    capi.check(L.dl3_comm_init(ctypes.byref(h), raw.raw, 0, 1), "dl3_comm_init")
+    assert h.value
+    rng = np.random.default_rng(0)
+    a = rng.normal(0, 1, 2113557).astype(np.float32)  # the MobileNetV2 gradient arena
+    t = torch.from_numpy(a).cuda()
+    out = torch.zeros_like(t)
+    st = torch.cuda.current_stream().cuda_stream
+    capi.call("dl3_comm_allreduce_f32", h, t.data_ptr(), out.data_ptr(), t.numel(), st)
+    capi.call("dl3_comm_allreduce_f32", h, t.data_ptr(), t.data_ptr(), t.numel(), st)  # in place, as the step does
+    capi.call("dl3_comm_broadcast_f32", h, t.data_ptr(), t.numel(), 0, st)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), a) and np.array_equal(t.cpu().numpy(), a)
+    assert L.dl3_comm_init(ctypes.byref(ctypes.c_void_p()), raw.raw, 3, 2) != 0  # rank outside the world: refused
+    capi.check(L.dl3_comm_destroy(h), "dl3_comm_destroy")
+
+
+def test_bench_self_spawns_its_ranks():
+    """`python bench.py --gpus 2` without a launcher (the driver's form) re-executes itself under torch.distributed.run
+    and prints ONE JSON line with n_gpus = 2 and the whole-job rate; here two ranks share the GPU over gloo."""
+    env = dict(os.environ, DL3_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "2",
+           "--size", "128", "--no-cpu-baseline", "--no-roofline"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["config"]["global_batch"] == 4
+    assert rec["config"]["hipgraph"] is True and rec["config"]["parallelism"] == "dp2"
+    assert abs(rec["value"] - 4 * 3 / (rec["ms_per_step"] * 3e-3)) < 1e-6 * rec["value"]
+    # a launcher environment that disagrees with --gpus is refused, not silently reinterpreted
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run(cmd, env=env2, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "WORLD_SIZE" in res.stderr
