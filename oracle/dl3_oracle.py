@@ -377,6 +377,10 @@ MNV2_BLOCKS = [
 ]
 
 
+# OS -> (entry_block3_stride, middle_block_rate, exit_block_rates, atrous_rates)      deeplabv3p.py:272-282
+XCEPTION_OS = {8: (1, 2, (2, 4), (12, 24, 36)), 16: (2, 1, (1, 2), (6, 12, 18))}
+
+
 class _Net:
     """Carries params/tape/mode through the functional model and collects BN side outputs."""
 
@@ -478,10 +482,7 @@ def deeplab_features(net, x, backbone, input_shape, OS, alpha, classes_head=True
     _rec(tape, x, (xin,), lambda g: (g / xin.dtype.type(127.5),))
     skip1 = None
     if backbone == "xception":
-        if OS == 8:
-            entry3_stride, middle_rate, exit_rates, atrous = 1, 2, (2, 4), (12, 24, 36)
-        else:
-            entry3_stride, middle_rate, exit_rates, atrous = 2, 1, (1, 2), (6, 12, 18)
+        entry3_stride, middle_rate, exit_rates, atrous = XCEPTION_OS[8 if OS == 8 else 16]
         x = net.conv(x, "entry_flow_conv1_1", k=3, stride=2)
         x = relu(net.bn(x, "entry_flow_conv1_1_BN"), tape)
         x = net.conv(x, "entry_flow_conv1_2", k=3, stride=1)

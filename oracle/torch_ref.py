@@ -56,6 +56,10 @@ def _resize_matrix(n_out, n_in, dtype):
     return torch.tensor(R, dtype=dtype)
 
 
+# the `if OS == 8 ... else ...` of deeplabv3p.py:273-282: (entry_block3_stride, middle_block_rate, exit_block_rates,
+# atrous_rates)
+_XCEPTION_OS = {8: (1, 2, (2, 4), (12, 24, 36)), 16: (2, 1, (1, 2), (6, 12, 18))}
+
 # MobileNetV2 body as the reference calls _inverted_res_block (deeplabv3p.py:327-367): one row per call,
 # (filters, stride, expansion, block_id, skip_connection, rate); alpha = 1
 _MNV2_CALLS = (
@@ -156,10 +160,7 @@ class Ref:
         x = x / 127.5 - 1.0
         skip1 = None
         if backbone == "xception":
-            if OS == 8:
-                e3, mr, er, atrous = 1, 2, (2, 4), (12, 24, 36)
-            else:
-                e3, mr, er, atrous = 2, 1, (1, 2), (6, 12, 18)
+            e3, mr, er, atrous = _XCEPTION_OS[8 if OS == 8 else 16]
             x = F.relu(self.bn(self.conv(x, "entry_flow_conv1_1", 3, 2), "entry_flow_conv1_1_BN"))
             x = F.relu(self.bn(self.conv(x, "entry_flow_conv1_2", 3, 1), "entry_flow_conv1_2_BN"))
             x = self.xblock(x, "entry_flow_block1", "conv", 2)
