@@ -194,13 +194,15 @@ def test_xception_train_step_gradients(OS):
 
 
 def test_graph_replay_and_determinism():
-    """hipGraph replay == eager launch sequence, and two runs are bit-identical (no float atomics)."""
+    """hipGraph replay == eager launch sequence, and two runs are bit-identical (no float atomics).  With Dropout on, the
+    mask changes every step (device-side step counter), so the replayed graph must walk the same mask sequence as eager
+    launches do."""
     model, params = _build(input_shape=(64, 64, 3), classes=3)
     rng = np.random.default_rng(3)
     x = rng.integers(0, 256, (2, 64, 64, 3)).astype(np.float32)
     labels = rng.integers(0, 4, (2, 64 * 64)).astype(np.float32)
     _load(model, params)
-    eng = model._engine(2, True, dropout=True, use_graph=True)
+    eng = model._engine(2, True, dropout=False, use_graph=True)
     eng.set_input(x)
     eng.set_targets(labels)
     eng.fwd_bwd()  # eager
@@ -213,6 +215,21 @@ def test_graph_replay_and_determinism():
     g2 = eng.grads.clone()
     assert torch.equal(g0, g1) and torch.equal(g1, g2)
     assert float(eng.loss[0].item()) == l0
+    # dropout on: eager steps 0..3 against (eager step 0 + replayed steps 1..3), same seed
+    seq = {}
+    for use_graph in (False, True):
+        e = model._engine(2, True, dropout=True, use_graph=use_graph)
+        e.drop_step.zero_()
+        e.set_input(x)
+        e.set_targets(labels)
+        seq[use_graph] = []
+        for _ in range(4):
+            e.fwd_bwd()
+            seq[use_graph].append(e.grads.clone())
+        assert (e.graph is not None) == use_graph
+    for a_, b_ in zip(seq[False], seq[True]):
+        assert torch.equal(a_, b_)
+    assert not torch.equal(seq[True][1], seq[True][2])  # a new mask every step
 
 
 def test_dropout_mask_changes_every_step():
@@ -268,7 +285,7 @@ def test_optimizer_state_survives_a_batch_size_change():
     assert e2 is not e4 and e2.iteration == 3 and e4.iteration == 2
     # the moments were carried over and then updated once: m = 0.9*m4 + 0.1*g
     g = e2.grads
-    assert torch.allclose(e2.adam_m, 0.9 * m4 + 0.1 * g, rtol=1e-5, atol=1e-9)
+    assert torch.allclose(e2.adam_m, 0.9 * m4 + 0.1 * g, rtol=1e-4, atol=1e-6 * float(g.abs().max()))
 
 
 def test_training_reduces_loss_and_weights_roundtrip(tmp_path):
@@ -318,7 +335,8 @@ def test_keras_h5_weights_into_the_engine(tmp_path, head):
     ref, _ = O.forward({k: v.astype(np.float64) for k, v in params.items()}, x.astype(np.float64), **kw)
     assert relerr(dst._active.logits(), ref) < 1e-3
     assert np.array_equal(dst._active.argmax(), ref.argmax(-1))
-    assert np.allclose(probs.reshape(ref.shape), O.softmax(ref), atol=1e-4)
+    # logits agree to 1e-3 of max|logit|: probabilities to a quarter of that absolute logit error
+    assert np.allclose(probs.reshape(ref.shape), O.softmax(ref), atol=1e-3 * float(np.abs(ref).max()))
 
 
 def test_full_size_properties():
@@ -475,8 +493,9 @@ def test_fit_generator_with_device_targets():
     model, params = _build(input_shape=(64, 64, 3), classes=C)
     _load(model, params)
     model.compile(optimizer=dict(lr=7e-4, epsilon=1e-8, decay=1e-6))
-    hist = model.fit_generator(gen, epochs=2)
-    assert len(hist) == 6 and all(np.isfinite(hist)) and hist[-1] < hist[0]
+    hist = model.fit_generator(gen, epochs=5)
+    # (three different batches per epoch, a fresh dropout mask every step: compare epoch means, not single steps)
+    assert len(hist) == 15 and all(np.isfinite(hist)) and np.mean(hist[-3:]) < np.mean(hist[:3]), hist
     masks = model.predict_mask(imgs[:4], batch_size=2)
     assert masks.shape == (4, 64, 64) and masks.dtype == np.int32
     assert np.array_equal(masks.reshape(4, -1), model.predict(imgs[:4], batch_size=2).argmax(-1))
