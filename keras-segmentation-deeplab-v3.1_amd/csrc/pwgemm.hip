@@ -35,6 +35,7 @@ struct GemmArgs {
   const float *ep_mean, *ep_invstd;
   float *part;
   int mtiles;
+  dl3_tail tail;  // BatchNorm finalize by the last-arriving workgroup of a column tile (ticket == nullptr: none)
 };
 
 constexpr int BK = 16;
@@ -290,10 +291,13 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmArgs P) {
           a1 += sred[(w * BN + cl) * 2 + 0];
           a2 += sred[(w * BN + cl) * 2 + 1];
         }
-        P.part[((size_t)by * P.N + col) * 2 + 0] = a1;
-        P.part[((size_t)by * P.N + col) * 2 + 1] = a2;
+        dl3_pub(P.part + ((size_t)by * P.N + col) * 2 + 0, a1);
+        dl3_pub(P.part + ((size_t)by * P.N + col) * 2 + 1, a2);
       }
     }
+    // every workgroup of column tile bx has published its row `by`: the last one to arrive finalises the BatchNorm
+    if (P.tail.ticket && dl3_last_arrival(P.tail.ticket + bx, gridDim.y))
+      dl3_tail_bn(P.tail, P.part, (int)gridDim.y, P.N, n0, min(BN, P.N - n0));
   }
 }
 
@@ -585,10 +589,13 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
           a1 += sred[(w * BN + cl) * 2 + 0];
           a2 += sred[(w * BN + cl) * 2 + 1];
         }
-        P.part[((size_t)by * P.N + col) * 2 + 0] = a1;
-        P.part[((size_t)by * P.N + col) * 2 + 1] = a2;
+        dl3_pub(P.part + ((size_t)by * P.N + col) * 2 + 0, a1);
+        dl3_pub(P.part + ((size_t)by * P.N + col) * 2 + 1, a2);
       }
     }
+    // every workgroup of column tile bx has published its row `by`: the last one to arrive finalises the BatchNorm
+    if (P.tail.ticket && dl3_last_arrival(P.tail.ticket + bx, gridDim.y))
+      dl3_tail_bn(P.tail, P.part, (int)gridDim.y, P.N, n0, min(BN, P.N - n0));
   }
 }
 
@@ -603,6 +610,8 @@ struct WgradArgs {
   const float *cA, *cB, *cC;
   float *ws;  // [S][K][N]
   int M, K, N, Mper;
+  float *dw;              // with tickets: the finished gradient [K][N], written by each tile's last-arriving workgroup
+  unsigned int *ticket;   // one word per (k tile, n tile), zero between launches; nullptr: slabs only (caller reduces)
 };
 
 template <int TA, int TB, int WA, int WB, bool VEC>
@@ -776,7 +785,11 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
       __syncthreads();
     }
   }
-  float *out = P.ws + (size_t)bz * P.K * P.N;
+  // one split: the tile IS the gradient.  Several splits: every workgroup publishes its slab tile; with tickets the
+  // last one to arrive for this (k tile, n tile) sums the S slabs in slab order (fixed, whoever is last) — the
+  // dl3_reduce_partials launch that used to follow is gone
+  const bool direct = P.ticket && gridDim.z == 1;
+  float *out = direct ? P.dw : P.ws + (size_t)bz * P.K * P.N;
 #pragma unroll
   for (int i = 0; i < TA; i++)
 #pragma unroll
@@ -785,9 +798,25 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int krow = kbase + (wa * TA + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (krow < P.K && col < P.N) out[(size_t)krow * P.N + col] = acc[i][j][r];
+        if (krow < P.K && col < P.N) {
+          if (P.ticket && !direct) dl3_pub(out + (size_t)krow * P.N + col, acc[i][j][r]);
+          else out[(size_t)krow * P.N + col] = acc[i][j][r];
+        }
       }
     }
+  if (P.ticket && !direct && dl3_last_arrival(P.ticket + by_ * gridDim.x + bx, gridDim.z)) {
+    const int S = gridDim.z;
+    const size_t slab = (size_t)P.K * P.N;
+    for (int e = tid; e < BKT * BNT; e += 256) {
+      const int krow = kbase + e / BNT, col = nbase + e % BNT;
+      if (krow < P.K && col < P.N) {
+        const float *q = P.ws + (size_t)krow * P.N + col;
+        float a = 0.f;
+        for (int z = 0; z < S; z++) a += dl3_sub(q + z * slab);
+        P.dw[(size_t)krow * P.N + col] = a;
+      }
+    }
+  }
 }
 
 // column sums of dY over row ranges: partial [PR][N]; block = 64 columns x 4 row lanes
@@ -994,6 +1023,8 @@ void launch_wgrad(const WgradArgs &A, dim3 grid, hipStream_t st, bool vec) {
 
 extern "C" int dl3_reduce_partials(const float *partial, int P, int n, float *out, void *stream);
 
+extern "C" int dl3_pwconv_tail_groups(int N) { return N > 0 ? dl3_cdiv(N, 32) : 0; }
+
 extern "C" int dl3_pwconv_partials(int M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0) return 0;
   // the stat partial row count must not depend on which operand form is used: take the max
@@ -1020,7 +1051,7 @@ static void pad_partials(float *part, int M, int K, int N, int written, hipStrea
 
 extern "C" int dl3_pwconv_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
                               const float *w, const float *bias, float *y, int ldy, int M, int K, int N,
-                              float *stat_partial, void *stream) {
+                              float *stat_partial, const dl3_tail *tail, void *stream) {
   int rc = gemm_common_check("pwconv_fwd", M, K, N);
   if (rc) return rc;
   DL3_CHECK_ARG(x && w && y, "pwconv_fwd: null pointer");
@@ -1034,9 +1065,14 @@ extern "C" int dl3_pwconv_fwd(const float *x, int ldx, const float *in_scale, co
   A.add_div = 1; A.add_scale = 1.f;
   A.stat_mode = stat_partial ? 1 : 0;
   A.part = stat_partial;
+  if (tail) {
+    DL3_CHECK_ARG(stat_partial && tail->ticket && tail->kind == DL3_TAIL_BN_FWD && !tail->wsum,
+                  "pwconv_fwd: the tail needs stat_partial, a ticket buffer and kind BN_FWD");
+    A.tail = *tail;
+  }
   hipStream_t st = (hipStream_t)stream;
   const int written = run_gemm(A, st);
-  if (stat_partial) pad_partials(stat_partial, M, K, N, written, st);
+  if (stat_partial && !tail) pad_partials(stat_partial, M, K, N, written, st);
   DL3_LAUNCH_CHECK("pwconv_fwd");
   return DL3_OK;
 }
@@ -1046,7 +1082,7 @@ extern "C" int dl3_pwconv_bwd_data(const float *g, int ldg, const float *yraw, i
                                    const float *x, int ldx, const float *in_scale, const float *in_shift,
                                    int in_act, const float *dx_add, int ldadd, int add_div, float add_scale,
                                    const float *x_mean, const float *x_invstd, float *dstat_partial, int M,
-                                   int K, int N, void *stream) {
+                                   int K, int N, const dl3_tail *tail, void *stream) {
   int rc = gemm_common_check("pwconv_bwd_data", M, K, N);
   if (rc) return rc;
   DL3_CHECK_ARG(g && wT && dx, "pwconv_bwd_data: null pointer");
@@ -1068,11 +1104,20 @@ extern "C" int dl3_pwconv_bwd_data(const float *g, int ldg, const float *yraw, i
   A.stat_mode = dstat_partial ? 2 : 0;
   A.ep_mean = x_mean; A.ep_invstd = x_invstd;
   A.part = dstat_partial;
+  if (tail) {
+    DL3_CHECK_ARG(dstat_partial && tail->ticket && tail->kind == DL3_TAIL_BN_BWD && !tail->wsum,
+                  "pwconv_bwd_data: the tail needs dstat_partial, a ticket buffer and kind BN_BWD");
+    A.tail = *tail;
+  }
   hipStream_t st = (hipStream_t)stream;
   const int written = run_gemm(A, st);
-  if (dstat_partial) pad_partials(dstat_partial, M, N, K, written, st);
+  if (dstat_partial && !tail) pad_partials(dstat_partial, M, N, K, written, st);
   DL3_LAUNCH_CHECK("pwconv_bwd_data");
   return DL3_OK;
+}
+
+extern "C" int dl3_pwconv_bwd_weight_tickets(int K, int N) {
+  return (K > 0 && N > 0) ? dl3_cdiv(K, 32) * dl3_cdiv(N, 32) : 0;  // an upper bound over every tile shape
 }
 
 extern "C" size_t dl3_pwconv_bwd_weight_workspace(int M, int K, int N) {
@@ -1087,7 +1132,8 @@ extern "C" size_t dl3_pwconv_bwd_weight_workspace(int M, int K, int N) {
 extern "C" int dl3_pwconv_bwd_weight(const float *x, int ldx, const float *in_scale, const float *in_shift,
                                      int in_act, const float *g, int ldg, const float *yraw, int ldyraw,
                                      const float *cA, const float *cB, const float *cC, float *dw, float *dbias,
-                                     int M, int K, int N, void *workspace, size_t workspace_bytes, void *stream) {
+                                     int M, int K, int N, void *workspace, size_t workspace_bytes,
+                                     unsigned int *ticket, void *stream) {
   int rc = gemm_common_check("pwconv_bwd_weight", M, K, N);
   if (rc) return rc;
   DL3_CHECK_ARG(x && g && dw && workspace, "pwconv_bwd_weight: null pointer");
@@ -1107,6 +1153,8 @@ extern "C" int dl3_pwconv_bwd_weight(const float *x, int ldx, const float *in_sc
   A.g = g; A.ldg = ldg; A.y = two ? yraw : nullptr; A.ldy = ldyraw;
   A.cA = cA; A.cB = cB; A.cC = cC;
   A.ws = (float *)workspace;
+  A.dw = dw;
+  A.ticket = ticket;
   A.M = M; A.K = K; A.N = N;
   A.Mper = dl3_cdiv(dl3_cdiv(M, S), DL3_WGRAD_MS) * DL3_WGRAD_MS;
   hipStream_t st = (hipStream_t)stream;
@@ -1126,8 +1174,10 @@ extern "C" int dl3_pwconv_bwd_weight(const float *x, int ldx, const float *in_sc
     default: launch_wgrad<1, 3, 4, 1>(A, grid, st, xvec && dvec); break;
   }
   DL3_LAUNCH_CHECK("pwconv_bwd_weight");
-  rc = dl3_reduce_partials(A.ws, S, K * N, dw, stream);
-  if (rc) return rc;
+  if (!ticket) {
+    rc = dl3_reduce_partials(A.ws, S, K * N, dw, stream);
+    if (rc) return rc;
+  }
   if (dbias) {
     float *cpart = A.ws + (size_t)S * K * N;
     const int pr = colsum_rows(M);
