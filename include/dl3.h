@@ -134,15 +134,11 @@ int dl3_pwconv_bwd_data(const float *g, int ldg, const float *yraw, int ldyraw, 
                         const float *x_invstd, float *dstat_partial, int M, int K, int N, const dl3_tail *tail,
                         void *stream);
 size_t dl3_pwconv_bwd_weight_workspace(int M, int K, int N);
-/* dw[K,N] = T(x)^T . dY ; dbias[N] (nullable) = colsum(dY).  The reduction over M is split over workgroups (slabs in the
- * workspace).  ticket (nullable): dl3_pwconv_bwd_weight_tickets(K,N) device words, zero before the first launch and left
- * zero — the last-arriving workgroup of each weight tile then sums the slabs in slab order itself (see dl3_tail above);
- * NULL: a second launch (dl3_reduce_partials) folds them. */
-int dl3_pwconv_bwd_weight_tickets(int K, int N);
+/* dw[K,N] = T(x)^T . dY ; dbias[N] (nullable) = colsum(dY) */
 int dl3_pwconv_bwd_weight(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
                           const float *g, int ldg, const float *yraw, int ldyraw, const float *cA,
                           const float *cB, const float *cC, float *dw, float *dbias, int M, int K, int N,
-                          void *workspace, size_t workspace_bytes, unsigned int *ticket, void *stream);
+                          void *workspace, size_t workspace_bytes, void *stream);
 /* out[cols][rows] = in[rows][cols]^T  (W[K,N] -> WT[N,K] for bwd_data) */
 int dl3_transpose(const float *in, float *out, int rows, int cols, void *stream);
 /* n transposes in one launch (all W -> WT of a backward pass).  desc (device, int64 [n][6]): in pointer, out pointer,

@@ -102,14 +102,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // ---------------------------------------------------------------- last-arriving-workgroup reductions ("tails")
 // Partial rows that another workgroup of the SAME launch will read are published with agent-scope (write-through)
-// stores and read back with agent-scope loads: the 8 XCDs have private, mutually non-coherent L2s
-// (cdna_hip_programming.md, Guideline 16).  No fences: every word that crosses workgroups takes the coherent path.
+// stores: the 8 XCDs have private, mutually non-coherent L2s (cdna_hip_programming.md, Guideline 16, recipe R1).  The
+// reader — the workgroup that drew the last ticket — executes ONE agent-scope acquire (drops its stale L1 / L2 lines)
+// and then uses plain vector loads, which the compiler is free to batch.  (Agent-scope atomic LOADS in the fold loops
+// were measured first: every one is waited for individually, ~1.5 us each — 0.1-1 ms per launch, 2.5x the whole step.)
 __device__ __forceinline__ void dl3_pub(float *p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ float dl3_sub(const float *p) {
-  return __hip_atomic_load(const_cast<float *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+__device__ __forceinline__ float dl3_sub(const float *p) { return *p; }  // after the reader's acquire (dl3_last_arrival)
 
 // All threads of the workgroup call this AFTER their dl3_pub stores.  Returns true (to every thread) in exactly one
 // workgroup per group: the one that drew ticket `expected - 1`, i.e. after which all `expected` rows are visible.
@@ -124,7 +124,9 @@ __device__ __forceinline__ bool dl3_last_arrival(unsigned int *ticket, unsigned 
     s_last = last;
   }
   __syncthreads();
-  return s_last != 0u;
+  if (s_last == 0u) return false;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every wave of the reader: stale lines out, then plain loads
+  return true;
 }
 
 // BatchNorm finalize of channels [c0, c0 + nc) from partial rows part[P][ldc][2], by the whole workgroup (256 threads =
@@ -138,6 +140,7 @@ __device__ __forceinline__ void dl3_tail_bn(const dl3_tail &T, const float *part
     const bool cok = (cb + cl) < nc;
     double a1 = 0.0, a2 = 0.0;
     if (cok)
+#pragma unroll 8
       for (int p = q; p < P; p += 8) {
         const float *r = part + ((size_t)p * ldc + c) * 2;
         a1 += (double)dl3_sub(r);
@@ -199,6 +202,7 @@ __device__ __forceinline__ void dl3_tail_sum(const float *part, int P, size_t ps
       const size_t idx = (size_t)r * ldr + c0 + cb + cl;
       double a = 0.0;
       if (cok)
+#pragma unroll 8
         for (int p = q; p < P; p += 8) a += (double)dl3_sub(part + (size_t)p * pstride + idx);
       s_sum[threadIdx.x] = a;
       __syncthreads();

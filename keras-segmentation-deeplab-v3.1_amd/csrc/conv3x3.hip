@@ -612,7 +612,7 @@ extern "C" int dl3_conv3x3_gemm_bwd_weight(const float *x, const float *in_scale
                      in_scale, in_shift, in_act, col, G);
   DL3_LAUNCH_CHECK("conv3x3_gemm_bwd_weight(im2col)");
   return dl3_pwconv_bwd_weight(col, 9 * Cin, nullptr, nullptr, DL3_ACT_NONE, g, Cout, yraw, Cout, cA, cB, cC, dw,
-                               nullptr, (int)M, 9 * Cin, Cout, (char *)workspace + cb, workspace_bytes - cb, nullptr, stream);
+                               nullptr, (int)M, 9 * Cin, Cout, (char *)workspace + cb, workspace_bytes - cb, stream);
 }
 
 extern "C" int dl3_conv3x3_gemm_bwd_data(const float *g, const float *yraw, const float *cA, const float *cB,

@@ -36,6 +36,7 @@ struct GemmArgs {
   float *part;
   int mtiles;
   dl3_tail tail;  // BatchNorm finalize by the last-arriving workgroup of a column tile (ticket == nullptr: none)
+  int tune;       // bit 0: raise the wave priority for the MFMA main loop (s_setprio), drop it for the epilogue
 };
 
 constexpr int BK = 16;
@@ -44,6 +45,9 @@ constexpr int BK = 16;
 #endif
 #ifndef DL3_STREAM_TAIL
 #define DL3_STREAM_TAIL 2
+#endif
+#ifndef DL3_GEMM_TUNE_DEFAULT
+#define DL3_GEMM_TUNE_DEFAULT 0
 #endif
 #ifndef DL3_WGRAD_MS
 #define DL3_WGRAD_MS 16
@@ -475,6 +479,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
     transform(0);
     adopt();
     __syncthreads();
+    if (P.tune & 1) __builtin_amdgcn_s_setprio(1);  // main loop: the matrix pipe of this SIMD goes to this wave first
     for (int kt = 0; kt < ktiles; ++kt) {
       const float *Bs = lds + (kt & 1) * KT * LDB;
       const bool more = kt + 1 < ktiles;
@@ -509,6 +514,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
     }
 
     // ---------------- epilogue (same C/D layout as the LDS-staged kernel)
+    if (P.tune & 1) __builtin_amdgcn_s_setprio(0);  // memory phase: yield to the co-resident wave's MFMAs
     const bool full = (m0 + BM <= P.M) && (n0 + BN <= P.N);
     if (FWD && full) {
       if (!P.ep_add) stream_epilogue_full<TM, TN, false, false, false>(P, acc, m0, nw0, wm, l31, lhi, st1, st2);
@@ -610,8 +616,6 @@ struct WgradArgs {
   const float *cA, *cB, *cC;
   float *ws;  // [S][K][N]
   int M, K, N, Mper;
-  float *dw;              // with tickets: the finished gradient [K][N], written by each tile's last-arriving workgroup
-  unsigned int *ticket;   // one word per (k tile, n tile), zero between launches; nullptr: slabs only (caller reduces)
 };
 
 template <int TA, int TB, int WA, int WB, bool VEC>
@@ -785,11 +789,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
       __syncthreads();
     }
   }
-  // one split: the tile IS the gradient.  Several splits: every workgroup publishes its slab tile; with tickets the
-  // last one to arrive for this (k tile, n tile) sums the S slabs in slab order (fixed, whoever is last) — the
-  // dl3_reduce_partials launch that used to follow is gone
-  const bool direct = P.ticket && gridDim.z == 1;
-  float *out = direct ? P.dw : P.ws + (size_t)bz * P.K * P.N;
+  float *out = P.ws + (size_t)bz * P.K * P.N;
 #pragma unroll
   for (int i = 0; i < TA; i++)
 #pragma unroll
@@ -798,25 +798,9 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int krow = kbase + (wa * TA + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (krow < P.K && col < P.N) {
-          if (P.ticket && !direct) dl3_pub(out + (size_t)krow * P.N + col, acc[i][j][r]);
-          else out[(size_t)krow * P.N + col] = acc[i][j][r];
-        }
+        if (krow < P.K && col < P.N) out[(size_t)krow * P.N + col] = acc[i][j][r];
       }
     }
-  if (P.ticket && !direct && dl3_last_arrival(P.ticket + by_ * gridDim.x + bx, gridDim.z)) {
-    const int S = gridDim.z;
-    const size_t slab = (size_t)P.K * P.N;
-    for (int e = tid; e < BKT * BNT; e += 256) {
-      const int krow = kbase + e / BNT, col = nbase + e % BNT;
-      if (krow < P.K && col < P.N) {
-        const float *q = P.ws + (size_t)krow * P.N + col;
-        float a = 0.f;
-        for (int z = 0; z < S; z++) a += dl3_sub(q + z * slab);
-        P.dw[(size_t)krow * P.N + col] = a;
-      }
-    }
-  }
 }
 
 // column sums of dY over row ranges: partial [PR][N]; block = 64 columns x 4 row lanes
@@ -903,7 +887,8 @@ GemmCfg pick_gemm(int M, int K, int N, bool two, bool small) {
 
 int gemm_grid_y(int M, int N, const GemmCfg &c) {
   const int mtiles = dl3_cdiv(M, c.BM), ntn = dl3_cdiv(N, c.BN);
-  int py = 2048 / ntn;
+  const int pytot = env_int("DL3_GEMM_PY");  // tuning aid: target number of workgroups per launch
+  int py = (pytot > 0 ? pytot : 2048) / ntn;
   if (py < 32) py = 32;
   if (mtiles <= py) return mtiles;
   const int iters = dl3_cdiv(mtiles, py);  // every workgroup loops over the same number of row tiles
@@ -929,6 +914,10 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   const bool stream = vec && env_int("DL3_GEMM_IMPL") != 0 && A.K <= DL3_STREAM_KMAX;
   const GemmCfg c = pick_gemm(A.M, A.K, A.N, two, stream);
   A.mtiles = dl3_cdiv(A.M, c.BM);
+  {
+    const int t = env_int("DL3_GEMM_TUNE");  // tuning aid: see GemmArgs::tune
+    A.tune = t >= 0 ? t : DL3_GEMM_TUNE_DEFAULT;
+  }
   dim3 grid(dl3_cdiv(A.N, c.BN), gemm_grid_y(A.M, A.N, c));
   // stream-A kernel: 10-25 % faster than the LDS-staged kernel on every layer shape, forward and bwd-data
   // (tools/gemm_tune.py).  The two-tensor bwd-data operand uses 16-deep K-tiles so that its register budget does not
@@ -1116,10 +1105,6 @@ extern "C" int dl3_pwconv_bwd_data(const float *g, int ldg, const float *yraw, i
   return DL3_OK;
 }
 
-extern "C" int dl3_pwconv_bwd_weight_tickets(int K, int N) {
-  return (K > 0 && N > 0) ? dl3_cdiv(K, 32) * dl3_cdiv(N, 32) : 0;  // an upper bound over every tile shape
-}
-
 extern "C" size_t dl3_pwconv_bwd_weight_workspace(int M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0) return 0;
   // S depends on the operand form; size for the larger
@@ -1132,8 +1117,7 @@ extern "C" size_t dl3_pwconv_bwd_weight_workspace(int M, int K, int N) {
 extern "C" int dl3_pwconv_bwd_weight(const float *x, int ldx, const float *in_scale, const float *in_shift,
                                      int in_act, const float *g, int ldg, const float *yraw, int ldyraw,
                                      const float *cA, const float *cB, const float *cC, float *dw, float *dbias,
-                                     int M, int K, int N, void *workspace, size_t workspace_bytes,
-                                     unsigned int *ticket, void *stream) {
+                                     int M, int K, int N, void *workspace, size_t workspace_bytes, void *stream) {
   int rc = gemm_common_check("pwconv_bwd_weight", M, K, N);
   if (rc) return rc;
   DL3_CHECK_ARG(x && g && dw && workspace, "pwconv_bwd_weight: null pointer");
@@ -1153,8 +1137,6 @@ extern "C" int dl3_pwconv_bwd_weight(const float *x, int ldx, const float *in_sc
   A.g = g; A.ldg = ldg; A.y = two ? yraw : nullptr; A.ldy = ldyraw;
   A.cA = cA; A.cB = cB; A.cC = cC;
   A.ws = (float *)workspace;
-  A.dw = dw;
-  A.ticket = ticket;
   A.M = M; A.K = K; A.N = N;
   A.Mper = dl3_cdiv(dl3_cdiv(M, S), DL3_WGRAD_MS) * DL3_WGRAD_MS;
   hipStream_t st = (hipStream_t)stream;
@@ -1174,10 +1156,8 @@ extern "C" int dl3_pwconv_bwd_weight(const float *x, int ldx, const float *in_sc
     default: launch_wgrad<1, 3, 4, 1>(A, grid, st, xvec && dvec); break;
   }
   DL3_LAUNCH_CHECK("pwconv_bwd_weight");
-  if (!ticket) {
-    rc = dl3_reduce_partials(A.ws, S, K * N, dw, stream);
-    if (rc) return rc;
-  }
+  rc = dl3_reduce_partials(A.ws, S, K * N, dw, stream);
+  if (rc) return rc;
   if (dbias) {
     float *cpart = A.ws + (size_t)S * K * N;
     const int pr = colsum_rows(M);

@@ -132,6 +132,12 @@ class Engine:
         # sums are done by the last-arriving workgroup of the producing kernel instead of 160 tiny launches per step.
         # DL3_TAILS=0 keeps the separate dl3_bn_finalize / dl3_bn_bwd_finalize / dl3_reduce_partials launches.
         self.use_tails = os.environ.get("DL3_TAILS", "1") != "0"
+        # A tail folds P partial rows with ONE workgroup per channel group while the rest of the chip idles; the separate
+        # finalize launch spreads the same fold over C/8 workgroups.  Measured on MI355X: tails win while P
+        # is small (small batches: the launch they save costs more than the fold), and lose at the benchmark batch
+        # (P of several hundred: +2 ms per step at B=64).  Layers whose launch writes more rows than this keep the
+        # separate launch.
+        self.tail_max_rows = int(os.environ.get("DL3_TAIL_MAXP", "48"))
         self.tickets = torch.zeros(1 << 16, dtype=torch.int32, device=self.device)
         self._ticket_cursor = 0
         self._build_params()
@@ -265,12 +271,12 @@ class Engine:
                              self.wptr(n + "/moving_mean:0") if upd else None,
                              self.wptr(n + "/moving_variance:0") if upd else None])
 
-    def bn_bwd_tail(self, buf, groups, wsum=None):
+    def bn_bwd_tail(self, buf, groups, wsum=None, rows=0):
         """dl3_tail for the kernel that writes the LAST gradient contribution into buf: the BatchNorm-backward finalize
         of the one BatchNormalization living in buf (in-kernel dl3_bn_bwd_finalize).  None if that is not the simple
         case (no BN, several BNs in a concat buffer, a BN on a channel slice): the caller then records the separate
         launch."""
-        if not self.use_tails:
+        if not self.use_tails or rows > self.tail_max_rows:
             return None
         kind = capi.TAIL_NONE
         f = {}
@@ -434,7 +440,7 @@ class Engine:
         C = v.C
         n = l.name
         v.buf.bns.append((l, v.off, C))
-        if self.bn_batch and self.use_tails and unit.tail_idx is not None:
+        if self.bn_batch and self.use_tails and unit.tail_idx is not None and unit.P <= self.tail_max_rows:
             # the producing kernel's last-arriving workgroup finalises this BatchNorm (no dl3_bn_finalize launch)
             t = self.bn_fwd_tail(l, v.buf, v.off, C, unit.tail_groups)
             unit.fwd_rec[2][unit.tail_idx] = self.tail_arg(t)
@@ -690,7 +696,7 @@ class Engine:
         need_x = masked or need_stat
         if view.off != 0 or view.C != buf.ld:
             raise NotImplementedError("element-wise gradient into a channel slice")
-        tail = self.bn_bwd_tail(buf, self.lib.dl3_grad_finish_tail_groups(buf.ld)) if need_stat else None
+        tail = self.bn_bwd_tail(buf, self.lib.dl3_grad_finish_tail_groups(buf.ld), rows=P) if need_stat else None
         self.op(self.ops_bwd, "dl3_grad_finish", gin, ldgin, gin_div, gin_scale, ptr(gout), buf.ld,
                 ptr(add), buf.ld, ptr(buf.t) if need_x else None, buf.ld,
                 view.scale() if masked else None, view.shift() if masked else None, view.act,
@@ -713,7 +719,7 @@ class Engine:
                 if buf.bns:
                     P = self.lib.dl3_rows_partials(buf.M)
                     dpart = self.empty(P * buf.ld * 2)
-                    tail = self.bn_bwd_tail(buf, self.lib.dl3_grad_finish_tail_groups(buf.ld))
+                    tail = self.bn_bwd_tail(buf, self.lib.dl3_grad_finish_tail_groups(buf.ld), rows=P)
                     self.op(self.ops_bwd, "dl3_grad_finish", ptr(g), buf.ld, 1, 1.0, ptr(g), buf.ld, None, 0,
                             ptr(buf.t), buf.ld, None, None, ACT_NONE, buf.vptr(V_MEAN), buf.vptr(V_INVSTD),
                             ptr(dpart), buf.M, buf.ld, 0.0, 0, None, self.tail_arg(tail))
@@ -941,9 +947,8 @@ class PwUnit(_ConvBase):
         s, t, a = inv.xform()
         if eng.trainable(self.wname()) or (self.bias and eng.trainable(self.bias)):
             ws = eng.lib.dl3_pwconv_bwd_weight_workspace(M, K, N)
-            tick = eng._tickets(eng.lib.dl3_pwconv_bwd_weight_tickets(K, N)) if eng.use_tails else None
             eng.op_ws(eng.ops_bwd, "dl3_pwconv_bwd_weight", ws, 17, inv.p(), inv.ld, s, t, a, g, ldg, y, ldy, cA, cB, cC,
-                      eng.gptr(self.wname()), eng.gptr(self.bias) if self.bias else None, M, K, N, 0, ws, tick)
+                      eng.gptr(self.wname()), eng.gptr(self.bias) if self.bias else None, M, K, N, 0, ws)
         ibuf = inv.buf
         if not ibuf.requires_grad:
             return
@@ -956,7 +961,7 @@ class PwUnit(_ConvBase):
         if need_stat and (inv.off != 0 or inv.C != ibuf.ld):
             raise NotImplementedError("BN-backward statistics through a channel slice")
         need_x = a != ACT_NONE or need_stat
-        tail = eng.bn_bwd_tail(ibuf, eng.lib.dl3_pwconv_tail_groups(K)) if need_stat else None
+        tail = eng.bn_bwd_tail(ibuf, eng.lib.dl3_pwconv_tail_groups(K), rows=P) if need_stat else None
         eng.op(eng.ops_bwd, "dl3_pwconv_bwd_data", g, ldg, y, ldy, cA, cB, cC, ptr(wT),
                gout.data_ptr() + 4 * inv.off, ibuf.ld, inv.p() if need_x else None, inv.ld,
                s if a != ACT_NONE else None, t if a != ACT_NONE else None, a,
@@ -1004,7 +1009,7 @@ class DwUnit(_ConvBase):
         # tail: the slab's last workgroup sums the weight-gradient partials (no dl3_reduce_partials launch) and, when this
         # is the last contribution into the input buffer, finalises its BatchNorm backward
         tail = eng.bn_bwd_tail(ibuf if need_stat else None, eng.lib.dl3_dwconv3x3_tail_groups(C),
-                               wsum=eng.gptr(self.wname()))
+                               wsum=eng.gptr(self.wname()), rows=self.P)
         bn_in_tail = tail is not None and tail.kind == capi.TAIL_BN_BWD
         eng.op(eng.ops_bwd, "dl3_dwconv3x3_bwd", g, y, cA, cB, cC, inv.p(), s, t, a, eng.wptr(self.wname()),
                ptr(gout), ptr(add), ibuf.vptr(V_MEAN) if need_stat else None,

@@ -506,7 +506,7 @@ def test_fit_generator_with_device_targets():
     _load(model2, params)
     model2.compile(optimizer=dict(lr=7e-4, epsilon=1e-8, decay=1e-6))
     ref = []
-    for _ in range(2):
+    for _ in range(5):
         for i in range(3):
             Yh, SWh, _ = O.prepare_targets(labs[2 * i:2 * i + 2].reshape(2, -1), C)
             ref.append(model2.train_on_batch(imgs[2 * i:2 * i + 2].astype(np.float32), Yh, SWh))

@@ -380,24 +380,10 @@ def test_pwconv_bwd_weight(L, case):
     call("dl3_pwconv_bwd_weight", ptr(dev(x)), K, ptr(dev(s)) if s is not None else None,
          ptr(dev(t)) if t is not None else None, a, ptr(dev(g)), N, ptr(dev(yraw)) if two else None, N,
          ptr(dev(cA)) if two else None, ptr(dev(cB)) if two else None, ptr(dev(cC)) if two else None, ptr(dw),
-         ptr(db) if dbias else None, M, K, N, ptr(ws), nbytes, None)
+         ptr(db) if dbias else None, M, K, N, ptr(ws), nbytes)
     assert relerr(host(dw), ref) < TOL
     if dbias:
         assert relerr(host(db), dY.sum(0)) < TOL
-    # with tickets: the last-arriving workgroup of each weight tile folds the split-M slabs (no reduce launch); the
-    # slab order is fixed, so the result is the same on every run
-    tick = torch.zeros(L.dl3_pwconv_bwd_weight_tickets(K, N), dtype=torch.int32, device="cuda")
-    outs = []
-    for _ in range(3):
-        dw2 = empty(K, N)
-        call("dl3_pwconv_bwd_weight", ptr(dev(x)), K, ptr(dev(s)) if s is not None else None,
-             ptr(dev(t)) if t is not None else None, a, ptr(dev(g)), N, ptr(dev(yraw)) if two else None, N,
-             ptr(dev(cA)) if two else None, ptr(dev(cB)) if two else None, ptr(dev(cC)) if two else None, ptr(dw2),
-             ptr(db) if dbias else None, M, K, N, ptr(ws), nbytes, tick.data_ptr())
-        outs.append(host(dw2))
-        assert int(host(tick).max()) == 0
-    assert relerr(outs[0], ref) < TOL
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 32, 3, 32, 2), (1, 17, 19, 3, 32, 2), (1, 16, 16, 32, 64, 1)])
@@ -775,10 +761,10 @@ def test_adam_fill(L):
 
 def test_error_reporting(L):
     """bad arguments come back as a status + message, not a crash (include/dl3.h conventions)"""
-    rc = L.dl3_pwconv_fwd(None, 4, None, None, 0, None, None, None, 4, 4, 4, 4, None, stream())
+    rc = L.dl3_pwconv_fwd(None, 4, None, None, 0, None, None, None, 4, 4, 4, 4, None, None, stream())
     assert rc == -1 and b"null" in L.dl3_last_error()
     x = empty(16, 6)
-    rc = L.dl3_dwconv3x3_fwd(ptr(x), None, None, 0, ptr(x), ptr(x), 1, 4, 4, 6, 1, 1, 1, 1, 4, 4, None, 0, stream())
+    rc = L.dl3_dwconv3x3_fwd(ptr(x), None, None, 0, ptr(x), ptr(x), 1, 4, 4, 6, 1, 1, 1, 1, 4, 4, None, 0, None, stream())
     assert rc == -4
 
 

@@ -52,7 +52,7 @@ def worker(batch, kind):
             nb = L.dl3_pwconv_bwd_weight_workspace(M, K, N)
             ws = torch.empty(nb // 4 + 4, device="cuda")
             run = lambda: capi.call("dl3_pwconv_bwd_weight", ptr(x), K, ptr(v[0]), ptr(v[1]), 2, ptr(g), N, ptr(y), N,
-                                    ptr(v[2]), ptr(v[3]), ptr(v[4]), ptr(dw), None, M, K, N, ptr(ws), nb, None, st)
+                                    ptr(v[2]), ptr(v[3]), ptr(v[4]), ptr(dw), None, M, K, N, ptr(ws), nb, st)
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
