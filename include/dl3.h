@@ -52,67 +52,25 @@ extern "C" {
 int dl3_version(void);
 const char *dl3_last_error(void);
 
-/* ---- "tail": what the LAST-ARRIVING workgroup of a channel group does with the partial rows ---------------
- * A kernel that reduces per-channel partials (BatchNorm batch statistics in a forward epilogue, BatchNorm-backward sums
- * in a bwd-data epilogue, depthwise weight gradients) can finish the reduction itself: every workgroup publishes its
- * partial row with write-through stores, takes a ticket from a per-channel-group counter, and the workgroup that draws
- * the last ticket folds ALL rows of its group in a FIXED order (double accumulation) and evaluates what
- * dl3_bn_finalize / dl3_bn_bwd_finalize / dl3_reduce_partials would have — same arithmetic, no extra launch, result
- * independent of which workgroup happens to be last (run-to-run bit-identical).  The ops that take a
- * `const dl3_tail *tail` (nullable) read the struct on the host at call time.  All channel-indexed pointers are indexed
- * like the op's partial buffer (channel 0 = first channel the op reduces).
- *   ticket: device memory, one word per channel group of the launch (dl3_*_tail_groups()), zero before the first
- *           launch; the tail leaves every word zero again (replayable inside a hipGraph).
- *   kind DL3_TAIL_BN_FWD: o = {scale, shift, mean, invstd, moving_mean|NULL, moving_var|NULL}   (dl3_bn_finalize)
- *   kind DL3_TAIL_BN_BWD: o = {cA, cB, cC, dgamma|NULL, dbeta|NULL, -}                          (dl3_bn_bwd_finalize)
- *   kind DL3_TAIL_NONE  : no BatchNorm work (wsum only)
- *   wsum (dl3_dwconv3x3_bwd only, nullable): finished depthwise weight gradient [3][3][C] = sum of dw_partial rows. */
-#define DL3_TAIL_NONE 0
-#define DL3_TAIL_BN_FWD 1
-#define DL3_TAIL_BN_BWD 2
-typedef struct dl3_tail {
-  unsigned int *ticket;
-  int kind;
-  int batch_mode;
-  float eps;
-  float momentum;
-  double count;
-  double var_unbias;
-  const float *gamma;
-  const float *beta;
-  const float *mean;
-  const float *invstd;
-  float *o[6];
-  float *wsum;
-} dl3_tail;
-int dl3_sizeof_tail(void); /* sizeof(dl3_tail), for bindings that mirror the struct */
-
 /* ---- DepthwiseConv2D 3x3 (deeplabv3p.py:73-74, :186-188) ------------------------------ */
 /* number of partial rows P written by dwconv fwd (stat_partial [P][C][2]) and bwd
  * (dstat_partial [P][C][2], dw_partial [P][9][C]) for this shape/impl */
 int dl3_dwconv3x3_partials(int N, int H, int W, int C, int stride, int rate, int Ho, int Wo, int impl);
-/* ticket words a tail needs for a depthwise launch over C channels (one per 32-channel slab) */
-int dl3_dwconv3x3_tail_groups(int C);
 /* y[n,oy,ox,c] = sum_{i,j} T(x)[n, oy*stride-pad_t+i*rate, ox*stride-pad_l+j*rate, c] * w[i][j][c];
- * stat_partial (nullable): per-channel sum(y), sum(y^2) partials; tail (nullable, kind BN_FWD): the BatchNorm of this
- * layer's output is finalised by the launch itself */
+ * stat_partial (nullable): per-channel sum(y), sum(y^2) partials */
 int dl3_dwconv3x3_fwd(const float *x, const float *in_scale, const float *in_shift, int in_act,
                       const float *w, float *y, int N, int H, int W, int C, int stride, int rate,
-                      int pad_t, int pad_l, int Ho, int Wo, float *stat_partial, int impl, const dl3_tail *tail,
-                      void *stream);
+                      int pad_t, int pad_l, int Ho, int Wo, float *stat_partial, int impl, void *stream);
 /* fused bwd-data + bwd-weight.
  *   dY = cA*g + cB*yraw + cC                                   [N,Ho,Wo,C]
  *   dw_partial[p][i][j][c] = partial sum_{n,oy,ox} T(x)[...tap...] * dY
  *   dx = mask_{in_act}(conv^T(dY, w)) + dx_add                 [N,H,W,C]   (dx nullable)
- *   dstat_partial (nullable): sum(dx), sum(dx * (x-x_mean)*x_invstd) partials
- *   tail (nullable): kind BN_BWD finalises the BatchNorm backward of the INPUT tensor's BatchNorm from dstat_partial;
- *   tail->wsum receives the finished weight gradient [3][3][C] (sum of the dw_partial rows) */
+ *   dstat_partial (nullable): sum(dx), sum(dx * (x-x_mean)*x_invstd) partials */
 int dl3_dwconv3x3_bwd(const float *g, const float *yraw, const float *cA, const float *cB, const float *cC,
                       const float *x, const float *in_scale, const float *in_shift, int in_act,
                       const float *w, float *dx, const float *dx_add, const float *x_mean,
                       const float *x_invstd, float *dstat_partial, float *dw_partial, int N, int H, int W,
-                      int C, int stride, int rate, int pad_t, int pad_l, int Ho, int Wo, int impl, const dl3_tail *tail,
-                      void *stream);
+                      int C, int stride, int rate, int pad_t, int pad_l, int Ho, int Wo, int impl, void *stream);
 
 /* ---- Conv2D 1x1 = GEMM on fp32 MFMA (deeplabv3p.py:78-79,:175,:194,:377,:385,:406,:420,:438) -- */
 /* P for the [M,K]x[K,N] GEMM's per-output-channel partials */
@@ -120,9 +78,7 @@ int dl3_pwconv_partials(int M, int K, int N);
 /* y[M,N](ldy) = T(x)[M,K](ldx) . w[K,N] (+bias[N]); stat_partial (nullable) [P][N][2] = sum(y), sum(y^2) */
 int dl3_pwconv_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
                    const float *w, const float *bias, float *y, int ldy, int M, int K, int N,
-                   float *stat_partial, const dl3_tail *tail, void *stream);
-/* ticket words a tail needs for this GEMM (one per column tile; N = number of output channels of the launch) */
-int dl3_pwconv_tail_groups(int N);
+                   float *stat_partial, void *stream);
 /* dx[M,K](lddx) = mask_{in_act}(dY[M,N] . wT[N,K]) + add_scale*dx_add ; dY = cA*g + cB*yraw + cC.
  * x/in_scale/in_shift/in_act describe the FORWARD input (needed for the mask and x_hat);
  * dx_add row address = dx_add + (m / add_div)*ldadd (add_div = H*W broadcasts a per-image vector);
@@ -131,8 +87,7 @@ int dl3_pwconv_bwd_data(const float *g, int ldg, const float *yraw, int ldyraw, 
                         const float *cB, const float *cC, const float *wT, float *dx, int lddx,
                         const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
                         const float *dx_add, int ldadd, int add_div, float add_scale, const float *x_mean,
-                        const float *x_invstd, float *dstat_partial, int M, int K, int N, const dl3_tail *tail,
-                        void *stream);
+                        const float *x_invstd, float *dstat_partial, int M, int K, int N, void *stream);
 size_t dl3_pwconv_bwd_weight_workspace(int M, int K, int N);
 /* dw[K,N] = T(x)^T . dY ; dbias[N] (nullable) = colsum(dY) */
 int dl3_pwconv_bwd_weight(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
@@ -222,8 +177,7 @@ int dl3_grad_finish(const float *gin, int ldgin, int gin_div, float gin_scale, f
                     const float *add, int ldadd, const float *xraw, int ldx, const float *scale,
                     const float *shift, int act, const float *mean, const float *invstd, float *dstat_partial,
                     int M, int C, float drop_rate, unsigned long long drop_seed, const unsigned long long *drop_step,
-                    const dl3_tail *tail, void *stream);
-int dl3_grad_finish_tail_groups(int C); /* ticket words: one per 32 channels */
+                    void *stream);
 /* strided 1x1 convolutions (Xception shortcuts, _conv2d_same(kernel_size=1, stride=2), deeplabv3p.py:143-145) sample
  * rows/cols 0, s, 2s, ...: y[n,oy,ox,c] = T(x)[n, oy*s, ox*s, c] compacts the sampled pixels for the GEMM;
  * the backward scatters the compact gradient back (zeros elsewhere). */

@@ -26,10 +26,8 @@ _CTYPES = {
     "void *": ctypes.c_void_p,
     "const void *": ctypes.c_void_p,
     "void * *": ctypes.POINTER(ctypes.c_void_p),
-    "const dl3_tail *": ctypes.c_void_p,
     "const long long *": ctypes.c_void_p,
     "unsigned long long *": ctypes.c_void_p,
-    "unsigned int *": ctypes.c_void_p,
     "const unsigned long long *": ctypes.c_void_p,
     "const char *": ctypes.c_char_p,
     "int": ctypes.c_int,
@@ -68,18 +66,6 @@ def parse_header(path=HEADER):
     return protos
 
 
-class Tail(ctypes.Structure):
-    """mirror of `dl3_tail` (include/dl3.h): the finalize work a kernel's last-arriving workgroup does itself"""
-    _fields_ = [("ticket", ctypes.c_void_p), ("kind", ctypes.c_int), ("batch_mode", ctypes.c_int),
-                ("eps", ctypes.c_float), ("momentum", ctypes.c_float), ("count", ctypes.c_double),
-                ("var_unbias", ctypes.c_double), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
-                ("mean", ctypes.c_void_p), ("invstd", ctypes.c_void_p), ("o", ctypes.c_void_p * 6),
-                ("wsum", ctypes.c_void_p)]
-
-
-TAIL_NONE, TAIL_BN_FWD, TAIL_BN_BWD = 0, 1, 2
-
-
 class DL3Error(RuntimeError):
     pass
 
@@ -111,8 +97,6 @@ def lib():
             raise DL3Error("libdl3.so does not export %s declared in include/dl3.h" % name)
         fn.restype = _CTYPES[ret]
         fn.argtypes = [_CTYPES[t] for t, _ in args]
-    if L.dl3_sizeof_tail() != ctypes.sizeof(Tail):
-        raise DL3Error("capi.Tail (%d bytes) does not mirror dl3_tail (%d bytes)" % (ctypes.sizeof(Tail), L.dl3_sizeof_tail()))
     _lib = L
     return L
 

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void grad_finish_kernel(const float *gin, int 
                                                           const float *__restrict__ invstd,
                                                           float *__restrict__ part, long M, int C, float drop_rate,
                                                           unsigned long long seed,
-                                                          const unsigned long long *__restrict__ step, dl3_tail T) {
+                                                          const unsigned long long *__restrict__ step) {
   __shared__ float red[256 * 2];
   seed = dl3_step_seed(seed, step);
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
@@ -222,11 +222,9 @@ __global__ __launch_bounds__(256) void grad_finish_kernel(const float *gin, int 
         a1 += red[(q * 32 + cl) * 2];
         a2 += red[(q * 32 + cl) * 2 + 1];
       }
-      dl3_pub(part + ((size_t)blockIdx.y * C + c) * 2, a1);
-      dl3_pub(part + ((size_t)blockIdx.y * C + c) * 2 + 1, a2);
+      part[((size_t)blockIdx.y * C + c) * 2] = a1;
+      part[((size_t)blockIdx.y * C + c) * 2 + 1] = a2;
     }
-    if (T.ticket && dl3_last_arrival(T.ticket + blockIdx.x, gridDim.y))
-      dl3_tail_bn(T, part, (int)gridDim.y, C, blockIdx.x * 32, min(32, C - (int)blockIdx.x * 32));
   }
 }
 
@@ -431,27 +429,19 @@ extern "C" int dl3_grad_finish(const float *gin, int ldgin, int gin_div, float g
                                const float *xraw, int ldx, const float *scale, const float *shift, int act,
                                const float *mean, const float *invstd, float *dstat_partial, int M, int C,
                                float drop_rate, unsigned long long drop_seed, const unsigned long long *drop_step,
-                               const dl3_tail *tail, void *stream) {
+                               void *stream) {
   DL3_CHECK_ARG(gin && gout && M > 0 && C > 0, "grad_finish: bad argument");
   DL3_CHECK_ARG(act == DL3_ACT_NONE || xraw, "grad_finish: activation mask needs xraw");
   DL3_CHECK_ARG(!dstat_partial || (xraw && mean && invstd), "grad_finish: dstat needs xraw, mean, invstd");
   DL3_CHECK_ARG((scale == nullptr) == (shift == nullptr), "grad_finish: scale/shift must come together");
-  dl3_tail T{};
-  if (tail) {
-    DL3_CHECK_ARG(dstat_partial && tail->ticket && tail->kind == DL3_TAIL_BN_BWD && !tail->wsum,
-                  "grad_finish: the tail needs dstat_partial, a ticket buffer and kind BN_BWD");
-    T = *tail;
-  }
   dim3 grid(dl3_cdiv(C, 32), dl3_rows_partials(M));
   hipLaunchKernelGGL(grad_finish_kernel, grid, dim3(256), 0, (hipStream_t)stream, gin, ldgin, gin_div, gin_scale,
                      gout, ldgout, add,
                      ldadd, xraw, ldx, scale, shift, act, mean, invstd, dstat_partial, (long)M, C, drop_rate,
-                     drop_seed, drop_step, T);
+                     drop_seed, drop_step);
   DL3_LAUNCH_CHECK("grad_finish");
   return DL3_OK;
 }
-
-extern "C" int dl3_grad_finish_tail_groups(int C) { return dl3_cdiv(C, 32); }
 
 extern "C" int dl3_gap_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
                            float *out, int N, int HW, int C, float out_scale, void *stream) {

@@ -99,118 +99,3 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-
-// ---------------------------------------------------------------- last-arriving-workgroup reductions ("tails")
-// Partial rows that another workgroup of the SAME launch will read are published with agent-scope (write-through)
-// stores: the 8 XCDs have private, mutually non-coherent L2s (cdna_hip_programming.md, Guideline 16, recipe R1).  The
-// reader — the workgroup that drew the last ticket — executes ONE agent-scope acquire (drops its stale L1 / L2 lines)
-// and then uses plain vector loads, which the compiler is free to batch.  (Agent-scope atomic LOADS in the fold loops
-// were measured first: every one is waited for individually, ~1.5 us each — 0.1-1 ms per launch, 2.5x the whole step.)
-__device__ __forceinline__ void dl3_pub(float *p, float v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float dl3_sub(const float *p) { return *p; }  // after the reader's acquire (dl3_last_arrival)
-
-// All threads of the workgroup call this AFTER their dl3_pub stores.  Returns true (to every thread) in exactly one
-// workgroup per group: the one that drew ticket `expected - 1`, i.e. after which all `expected` rows are visible.
-__device__ __forceinline__ bool dl3_last_arrival(unsigned int *ticket, unsigned expected) {
-  __shared__ unsigned int s_last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's published stores have completed
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned last = (old + 1u == expected) ? 1u : 0u;
-    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-    s_last = last;
-  }
-  __syncthreads();
-  if (s_last == 0u) return false;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every wave of the reader: stale lines out, then plain loads
-  return true;
-}
-
-// BatchNorm finalize of channels [c0, c0 + nc) from partial rows part[P][ldc][2], by the whole workgroup (256 threads =
-// 8 row lanes x 32 channels; row lane q sums rows q, q+8, ... in double, the lanes are combined in the order 0..7).
-// The arithmetic is that of bn_finalize_kernel / bn_bwd_finalize_kernel (bn.hip).
-__device__ __forceinline__ void dl3_tail_bn(const dl3_tail &T, const float *part, int P, int ldc, int c0, int nc) {
-  __shared__ double s_red[256 * 2];
-  const int cl = threadIdx.x & 31, q = threadIdx.x >> 5;
-  for (int cb = 0; cb < nc; cb += 32) {
-    const int c = c0 + cb + cl;
-    const bool cok = (cb + cl) < nc;
-    double a1 = 0.0, a2 = 0.0;
-    if (cok)
-#pragma unroll 8
-      for (int p = q; p < P; p += 8) {
-        const float *r = part + ((size_t)p * ldc + c) * 2;
-        a1 += (double)dl3_sub(r);
-        a2 += (double)dl3_sub(r + 1);
-      }
-    s_red[threadIdx.x * 2] = a1;
-    s_red[threadIdx.x * 2 + 1] = a2;
-    __syncthreads();
-    if (q == 0 && cok) {
-      double s1 = 0.0, s2 = 0.0;
-      for (int j = 0; j < 8; j++) {
-        s1 += s_red[(j * 32 + cl) * 2];
-        s2 += s_red[(j * 32 + cl) * 2 + 1];
-      }
-      if (T.kind == DL3_TAIL_BN_FWD) {
-        const double m = s1 / T.count;
-        double var = s2 / T.count - m * m;
-        if (var < 0.0) var = 0.0;
-        const double is = 1.0 / sqrt(var + (double)T.eps);
-        const double sc = (double)T.gamma[c] * is;
-        T.o[0][c] = (float)sc;
-        T.o[1][c] = (float)((double)T.beta[c] - m * sc);
-        T.o[2][c] = (float)m;
-        T.o[3][c] = (float)is;
-        if (T.o[4]) {
-          const double mom = (double)T.momentum;
-          T.o[4][c] = (float)(mom * T.o[4][c] + (1.0 - mom) * m);
-          T.o[5][c] = (float)(mom * T.o[5][c] + (1.0 - mom) * var * T.var_unbias);
-        }
-      } else {  // DL3_TAIL_BN_BWD: s1 = sum g = dbeta, s2 = sum g * x_hat = dgamma
-        if (T.o[4]) T.o[4][c] = (float)s1;
-        if (T.o[3]) T.o[3][c] = (float)s2;
-        const double a = (double)T.gamma[c] * (double)T.invstd[c];
-        if (T.batch_mode) {
-          const double b = -a * (double)T.invstd[c] * s2 / T.count;
-          T.o[0][c] = (float)a;
-          T.o[1][c] = (float)b;
-          T.o[2][c] = (float)(-a * s1 / T.count - b * (double)T.mean[c]);
-        } else {
-          T.o[0][c] = (float)a;
-          T.o[1][c] = 0.f;
-          T.o[2][c] = 0.f;
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
-
-// out[i] = sum_p part[p * stride + idx(i)] for the n = rows * nc values {r * ldr + c0 + j}: plain fixed-order sums
-// (row lanes as above, double accumulation) — the depthwise weight gradient of a channel slab.
-__device__ __forceinline__ void dl3_tail_sum(const float *part, int P, size_t pstride, int rows, int ldr, int c0, int nc,
-                                             float *out) {
-  __shared__ double s_sum[256];
-  const int cl = threadIdx.x & 31, q = threadIdx.x >> 5;
-  for (int r = 0; r < rows; r++)
-    for (int cb = 0; cb < nc; cb += 32) {
-      const bool cok = (cb + cl) < nc;
-      const size_t idx = (size_t)r * ldr + c0 + cb + cl;
-      double a = 0.0;
-      if (cok)
-#pragma unroll 8
-        for (int p = q; p < P; p += 8) a += (double)dl3_sub(part + (size_t)p * pstride + idx);
-      s_sum[threadIdx.x] = a;
-      __syncthreads();
-      if (q == 0 && cok) {
-        double s = 0.0;
-        for (int j = 0; j < 8; j++) s += s_sum[j * 32 + cl];
-        out[idx] = (float)s;
-      }
-      __syncthreads();
-    }
-}

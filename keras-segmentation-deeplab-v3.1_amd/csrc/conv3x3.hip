@@ -587,7 +587,7 @@ extern "C" int dl3_conv3x3_gemm_fwd(const float *x, const float *in_scale, const
                      in_scale, in_shift, in_act, col, G);
   DL3_LAUNCH_CHECK("conv3x3_gemm_fwd(im2col)");
   return dl3_pwconv_fwd(col, 9 * Cin, nullptr, nullptr, DL3_ACT_NONE, w, nullptr, y, Cout, (int)M, 9 * Cin, Cout,
-                        stat_partial, nullptr, stream);
+                        stat_partial, stream);
 }
 
 extern "C" int dl3_conv3x3_gemm_bwd_weight(const float *x, const float *in_scale, const float *in_shift, int in_act,
@@ -636,7 +636,7 @@ extern "C" int dl3_conv3x3_gemm_bwd_data(const float *g, const float *yraw, cons
   float *dcol = (float *)workspace;
   const long M = (long)N * Ho * Wo;
   rc = dl3_pwconv_bwd_data(g, Cout, yraw, Cout, cA, cB, cC, wT, dcol, 9 * Cin, nullptr, 0, nullptr, nullptr,
-                           DL3_ACT_NONE, nullptr, 0, 1, 1.f, nullptr, nullptr, nullptr, (int)M, 9 * Cin, Cout, nullptr, stream);
+                           DL3_ACT_NONE, nullptr, 0, 1, 1.f, nullptr, nullptr, nullptr, (int)M, 9 * Cin, Cout, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(col2im3x3_kernel, dim3(conv_blocks((long)N * H * W)), dim3(256), 0, (hipStream_t)stream, dcol, dx,
                      x, in_scale, in_shift, in_act, dx_add, x_mean, x_invstd, dstat_partial, G);

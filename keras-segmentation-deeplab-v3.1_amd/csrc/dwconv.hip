@@ -53,22 +53,9 @@ __device__ __forceinline__ void reduce_px(float (&v)[NV], float *lds /* [4][8][N
 
 __device__ __forceinline__ void write_stat_partial(float *part, int p, int C, int c, f32x4 s1, f32x4 s2) {
   // part [P][C][2]
-  // published (write-through) stores: the last-arriving workgroup of the slab may fold these rows (common.h tails)
   float *d = part + ((size_t)p * C + c) * 2;
-  dl3_pub(d + 0, s1.x); dl3_pub(d + 1, s2.x); dl3_pub(d + 2, s1.y); dl3_pub(d + 3, s2.y);
-  dl3_pub(d + 4, s1.z); dl3_pub(d + 5, s2.z); dl3_pub(d + 6, s1.w); dl3_pub(d + 7, s2.w);
-}
-__device__ __forceinline__ void pub4(float *p, f32x4 v) {
-  dl3_pub(p, v.x); dl3_pub(p + 1, v.y); dl3_pub(p + 2, v.z); dl3_pub(p + 3, v.w);
-}
-// the slab's last-arriving workgroup finishes the reductions of its 32 channels (dl3.h "tail")
-__device__ __forceinline__ void dw_tail(const dl3_tail &T, int slab, int rows, int C, const float *stat,
-                                        const float *wpart) {
-  if (!T.ticket) return;
-  if (!dl3_last_arrival(T.ticket + slab, (unsigned)rows)) return;
-  const int c0 = slab * 32, nc = min(32, C - c0);
-  if (T.kind != DL3_TAIL_NONE && stat) dl3_tail_bn(T, stat, rows, C, c0, nc);
-  if (T.wsum && wpart) dl3_tail_sum(wpart, rows, (size_t)9 * C, 9, C, c0, nc, T.wsum);
+  d[0] = s1.x; d[1] = s2.x; d[2] = s1.y; d[3] = s2.y;
+  d[4] = s1.z; d[5] = s2.z; d[6] = s1.w; d[7] = s2.w;
 }
 
 // Workgroup -> tile decode for the march kernels.  The grid is 1-D and padded to a multiple of 8: hardware hands
@@ -96,7 +83,7 @@ __global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x,
                                                     const float *__restrict__ w, float *__restrict__ y,
                                                     int H, int W, int C, int r, int nchunk, int TK, int nxseg,
                                                     int nphase, int ppb, int nslab, int ny, int N, int xcd,
-                                                    float *__restrict__ part, dl3_tail T) {
+                                                    float *__restrict__ part) {
   __shared__ float red[4 * 8 * 8];
   const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
   DwTile tile;
@@ -184,7 +171,6 @@ __global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x,
       f32x4 r1 = {v[0], v[1], v[2], v[3]}, r2 = {v[4], v[5], v[6], v[7]};
       write_stat_partial(part, p, C, c, r1, r2);
     }
-    dw_tail(T, slab, N * ny * nxseg, C, part, nullptr);
   }
 }
 
@@ -201,7 +187,7 @@ __global__ __launch_bounds__(256) void dw_march2_fwd(const float *__restrict__ x
                                                      const float *__restrict__ w, float *__restrict__ y,
                                                      int H, int W, int C, int r, int nchunk, int TK, int nxseg,
                                                      int nphase, int ppb, int nslab, int ny, int N, int xcd,
-                                                     float *__restrict__ part, dl3_tail T) {
+                                                     float *__restrict__ part) {
   __shared__ float red[4 * 8 * 8];
   const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
   DwTile tile;
@@ -283,7 +269,6 @@ __global__ __launch_bounds__(256) void dw_march2_fwd(const float *__restrict__ x
       f32x4 r1 = {v[0], v[1], v[2], v[3]}, r2 = {v[4], v[5], v[6], v[7]};
       write_stat_partial(part, p, C, c, r1, r2);
     }
-    dw_tail(T, slab, N * ny * nxseg, C, part, nullptr);
   }
 }
 
@@ -296,7 +281,7 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
     const float *__restrict__ sc, const float *__restrict__ sh, int act, const float *__restrict__ w,
     float *__restrict__ dx, const float *__restrict__ dx_add, const float *__restrict__ xmean,
     const float *__restrict__ xinvstd, float *__restrict__ dpart, float *__restrict__ wpart, int H, int W, int C,
-    int r, int nchunk, int TK, int nxseg, int nphase, int ppb, int nslab, int ny, int N, int xcd, dl3_tail T) {
+    int r, int nchunk, int TK, int nxseg, int nphase, int ppb, int nslab, int ny, int N, int xcd) {
   __shared__ float red[4 * 8 * 36];
   const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
   DwTile tile;
@@ -429,7 +414,7 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
 #pragma unroll
       for (int i = 0; i < 9; i++) {
         f32x4 o = {v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]};
-        pub4(wpart + ((size_t)p * 9 + i) * C + c, o);
+        st4(wpart + ((size_t)p * 9 + i) * C + c, o);
       }
     }
   }
@@ -441,7 +426,6 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
       write_stat_partial(dpart, p, C, c, r1, r2);
     }
   }
-  dw_tail(T, slab, N * ny * nxseg, C, dpart, wpart);
 }
 
 // ======================================================================================
@@ -450,7 +434,7 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
 __global__ __launch_bounds__(256) void dw_gather_fwd(const float *__restrict__ x, const float *__restrict__ sc,
                                                      const float *__restrict__ sh, int act,
                                                      const float *__restrict__ w, float *__restrict__ y, DwGeom G,
-                                                     float *__restrict__ part, dl3_tail T) {
+                                                     float *__restrict__ part) {
   __shared__ float red[4 * 8 * 8];
   const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
   const int c = blockIdx.x * 32 + cq * 4;
@@ -493,7 +477,6 @@ __global__ __launch_bounds__(256) void dw_gather_fwd(const float *__restrict__ x
       f32x4 r1 = {v[0], v[1], v[2], v[3]}, r2 = {v[4], v[5], v[6], v[7]};
       write_stat_partial(part, blockIdx.y, G.C, c, r1, r2);
     }
-    dw_tail(T, blockIdx.x, gridDim.y, G.C, part, nullptr);
   }
 }
 
@@ -506,7 +489,7 @@ __global__ __launch_bounds__(256) void dw_gather_bwd(
     const float *__restrict__ cB, const float *__restrict__ cC, const float *__restrict__ x,
     const float *__restrict__ sc, const float *__restrict__ sh, int act, const float *__restrict__ w,
     float *__restrict__ dx, const float *__restrict__ dx_add, const float *__restrict__ xmean,
-    const float *__restrict__ xinvstd, float *__restrict__ dpart, float *__restrict__ wpart, DwGeom G, dl3_tail T) {
+    const float *__restrict__ xinvstd, float *__restrict__ dpart, float *__restrict__ wpart, DwGeom G) {
   __shared__ float red[4 * 8 * 36];
   const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
   const int c = blockIdx.x * 32 + cq * 4;
@@ -580,7 +563,7 @@ __global__ __launch_bounds__(256) void dw_gather_bwd(
 #pragma unroll
       for (int i = 0; i < 9; i++) {
         f32x4 o = {v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]};
-        pub4(wpart + ((size_t)blockIdx.y * 9 + i) * G.C + c, o);
+        st4(wpart + ((size_t)blockIdx.y * 9 + i) * G.C + c, o);
       }
     }
   }
@@ -592,7 +575,6 @@ __global__ __launch_bounds__(256) void dw_gather_bwd(
       write_stat_partial(dpart, blockIdx.y, G.C, c, r1, r2);
     }
   }
-  dw_tail(T, blockIdx.x, gridDim.y, G.C, dpart, wpart);
 }
 
 // ======================================================================================
@@ -607,7 +589,7 @@ __global__ __launch_bounds__(256) void dw_s2_bwd(
     const float *__restrict__ cB, const float *__restrict__ cC, const float *__restrict__ x,
     const float *__restrict__ sc, const float *__restrict__ sh, int act, const float *__restrict__ w,
     float *__restrict__ dx, const float *__restrict__ dx_add, const float *__restrict__ xmean,
-    const float *__restrict__ xinvstd, float *__restrict__ dpart, float *__restrict__ wpart, DwGeom G, dl3_tail T) {
+    const float *__restrict__ xinvstd, float *__restrict__ dpart, float *__restrict__ wpart, DwGeom G) {
   __shared__ float red[4 * 8 * 36];
   const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
   const int c = blockIdx.x * 32 + cq * 4;
@@ -696,7 +678,7 @@ __global__ __launch_bounds__(256) void dw_s2_bwd(
 #pragma unroll
       for (int i = 0; i < 9; i++) {
         f32x4 o = {v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]};
-        pub4(wpart + ((size_t)blockIdx.y * 9 + i) * G.C + c, o);
+        st4(wpart + ((size_t)blockIdx.y * 9 + i) * G.C + c, o);
       }
     }
   }
@@ -708,7 +690,6 @@ __global__ __launch_bounds__(256) void dw_s2_bwd(
       write_stat_partial(dpart, blockIdx.y, G.C, c, r1, r2);
     }
   }
-  dw_tail(T, blockIdx.x, gridDim.y, G.C, dpart, wpart);
 }
 
 // ---- host-side decomposition (shared by *_partials and the launchers) -------------------
@@ -746,7 +727,9 @@ DwPlan dw_plan(int N, int H, int W, int C, int stride, int rate, int Ho, int Wo,
     const int Kmax = dl3_cdiv(H, rate);
     // rows per block: as long as possible (halo re-read = 2/TK) while keeping >= ~2048 blocks
     int TK = Kmax;
-    while (TK > 8 && (long)N * p.nslab * p.nxseg * p.nphase * dl3_cdiv(Kmax, TK) < 2048) TK = (TK + 1) / 2;
+    long want = 2048;  // workgroups per launch to aim for (DL3_DW_BLOCKS: tuning aid)
+    if (const char *eb = getenv("DL3_DW_BLOCKS")) want = atol(eb) > 0 ? atol(eb) : want;
+    while (TK > 8 && (long)N * p.nslab * p.nxseg * p.nphase * dl3_cdiv(Kmax, TK) < want) TK = (TK + 1) / 2;
     p.TK = TK;
     p.nchunk = dl3_cdiv(Kmax, TK);
     // large rates: a phase holds only Kmax = 2..6 rows -> give a workgroup several phases (~12 rows of work)
@@ -783,8 +766,6 @@ int resolve_impl(int impl, int H, int W, int stride, int rate, int pad_t, int pa
 
 }  // namespace
 
-extern "C" int dl3_dwconv3x3_tail_groups(int C) { return dl3_cdiv(C, 32); }
-
 extern "C" int dl3_dwconv3x3_partials(int N, int H, int W, int C, int stride, int rate, int Ho, int Wo,
                                       int impl) {
   // pads are implied: march needs SAME stride-1 geometry, which the caller guarantees when it asks for it
@@ -807,7 +788,7 @@ static int dw_check(int N, int H, int W, int C, int stride, int rate, int Ho, in
 extern "C" int dl3_dwconv3x3_fwd(const float *x, const float *in_scale, const float *in_shift, int in_act,
                                  const float *w, float *y, int N, int H, int W, int C, int stride, int rate,
                                  int pad_t, int pad_l, int Ho, int Wo, float *stat_partial, int impl,
-                                 const dl3_tail *tail, void *stream) {
+                                 void *stream) {
   int rc = dw_check(N, H, W, C, stride, rate, Ho, Wo);
   if (rc) return rc;
   DL3_CHECK_ARG(x && w && y, "dwconv3x3_fwd: null pointer");
@@ -816,33 +797,26 @@ extern "C" int dl3_dwconv3x3_fwd(const float *x, const float *in_scale, const fl
   DL3_UNSUPPORTED(im < 0, "dwconv3x3_fwd: march impl needs stride 1, pad == rate, Ho == H, Wo == W");
   DwPlan p = dw_plan(N, H, W, C, stride, rate, Ho, Wo, im, false);
   hipStream_t st = (hipStream_t)stream;
-  dl3_tail T{};
-  if (tail) {
-    DL3_CHECK_ARG(stat_partial && tail->ticket && tail->kind == DL3_TAIL_BN_FWD && !tail->wsum,
-                  "dwconv3x3_fwd: the tail needs stat_partial, a ticket buffer and kind BN_FWD");
-    T = *tail;
-  }
   if (im == DL3_IMPL_MARCH) {
     dim3 grid(march_grid(p, N));
     if (p.two)
       hipLaunchKernelGGL(dw_march2_fwd, grid, dim3(256), 0, st, x, in_scale, in_shift, in_act, w, y, H, W, C, rate,
-                         p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial, T);
+                         p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial);
     else
       hipLaunchKernelGGL(dw_march_fwd, grid, dim3(256), 0, st, x, in_scale, in_shift, in_act, w, y, H, W, C, rate,
-                         p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial, T);
-    // the two-pixel forward writes fewer partial rows than the backward's decomposition: zero the rest (a tail folds
-    // exactly the rows this launch wrote and needs no padding)
+                         p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial);
+    // the two-pixel forward writes fewer partial rows than the backward's decomposition: zero the rest
     const int Pmax = dl3_dwconv3x3_partials(N, H, W, C, stride, rate, Ho, Wo, im);
-    if (stat_partial && !tail && Pmax > p.P)
+    if (stat_partial && Pmax > p.P)
       (void)hipMemsetAsync(stat_partial + (size_t)p.P * C * 2, 0, (size_t)(Pmax - p.P) * C * 2 * sizeof(float), st);
   } else {
     DwGeom G{N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo};
     dim3 grid(p.nslab, p.PB);
     hipLaunchKernelGGL(dw_gather_fwd, grid, dim3(256), 0, st, x, in_scale, in_shift, in_act, w, y, G,
-                       stat_partial, T);
+                       stat_partial);
     // gather fwd writes PB partial rows; pad the rest (caller sized the buffer with *_partials)
     const int Pmax = dl3_dwconv3x3_partials(N, H, W, C, stride, rate, Ho, Wo, im);
-    if (stat_partial && !tail && Pmax > p.P)
+    if (stat_partial && Pmax > p.P)
       (void)hipMemsetAsync(stat_partial + (size_t)p.P * C * 2, 0, (size_t)(Pmax - p.P) * C * 2 * sizeof(float), st);
   }
   DL3_LAUNCH_CHECK("dwconv3x3_fwd");
@@ -854,7 +828,7 @@ extern "C" int dl3_dwconv3x3_bwd(const float *g, const float *yraw, const float 
                                  int in_act, const float *w, float *dx, const float *dx_add,
                                  const float *x_mean, const float *x_invstd, float *dstat_partial,
                                  float *dw_partial, int N, int H, int W, int C, int stride, int rate, int pad_t,
-                                 int pad_l, int Ho, int Wo, int impl, const dl3_tail *tail, void *stream) {
+                                 int pad_l, int Ho, int Wo, int impl, void *stream) {
   int rc = dw_check(N, H, W, C, stride, rate, Ho, Wo);
   if (rc) return rc;
   DL3_CHECK_ARG(g && x && w && dw_partial, "dwconv3x3_bwd: null pointer");
@@ -865,29 +839,23 @@ extern "C" int dl3_dwconv3x3_bwd(const float *g, const float *yraw, const float 
   DL3_UNSUPPORTED(im < 0, "dwconv3x3_bwd: march impl needs stride 1, pad == rate, Ho == H, Wo == W");
   DwPlan p = dw_plan(N, H, W, C, stride, rate, Ho, Wo, im, true);
   hipStream_t st = (hipStream_t)stream;
-  dl3_tail T{};
-  if (tail) {
-    DL3_CHECK_ARG(tail->ticket && (tail->kind == DL3_TAIL_NONE || (tail->kind == DL3_TAIL_BN_BWD && dstat_partial)),
-                  "dwconv3x3_bwd: the tail needs a ticket buffer and, for kind BN_BWD, dstat_partial");
-    T = *tail;
-  }
   if (im == DL3_IMPL_MARCH) {
     dim3 grid(march_grid(p, N));
     hipLaunchKernelGGL(dw_march_bwd, grid, dim3(256), 0, st, g, yraw, cA, cB, cC, x, in_scale, in_shift, in_act,
                        w, dx, dx_add, x_mean, x_invstd, dstat_partial, dw_partial, H, W, C, rate, p.nchunk, p.TK,
-                       p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), T);
+                       p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd());
   } else {
     DwGeom G{N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo};
     dim3 grid(p.nslab, p.PB);
     const char *e = getenv("DL3_DW_S2");  // 0 = generic gather for stride 2 as well (tuning / test aid)
     if (stride == 2 && rate == 1 && pad_t <= 1 && pad_l <= 1 && !(e && atoi(e) == 0))
       hipLaunchKernelGGL(dw_s2_bwd, grid, dim3(256), 0, st, g, yraw, cA, cB, cC, x, in_scale, in_shift, in_act, w, dx,
-                         dx_add, x_mean, x_invstd, dstat_partial, dw_partial, G, T);
+                         dx_add, x_mean, x_invstd, dstat_partial, dw_partial, G);
     else
       hipLaunchKernelGGL(dw_gather_bwd, grid, dim3(256), 0, st, g, yraw, cA, cB, cC, x, in_scale, in_shift, in_act,
-                         w, dx, dx_add, x_mean, x_invstd, dstat_partial, dw_partial, G, T);
+                         w, dx, dx_add, x_mean, x_invstd, dstat_partial, dw_partial, G);
     const int Pmax = dl3_dwconv3x3_partials(N, H, W, C, stride, rate, Ho, Wo, im);
-    if (Pmax > p.P && !tail) {
+    if (Pmax > p.P) {
       (void)hipMemsetAsync(dw_partial + (size_t)p.P * 9 * C, 0, (size_t)(Pmax - p.P) * 9 * C * sizeof(float), st);
       if (dstat_partial)
         (void)hipMemsetAsync(dstat_partial + (size_t)p.P * C * 2, 0, (size_t)(Pmax - p.P) * C * 2 * sizeof(float), st);

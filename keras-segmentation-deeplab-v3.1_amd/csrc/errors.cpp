@@ -14,4 +14,3 @@ void dl3_set_error(const char *fmt, ...) {
 
 extern "C" const char *dl3_last_error(void) { return g_err; }
 extern "C" int dl3_version(void) { return 100; }
-extern "C" int dl3_sizeof_tail(void) { return (int)sizeof(dl3_tail); }

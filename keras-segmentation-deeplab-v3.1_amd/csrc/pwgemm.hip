@@ -35,8 +35,6 @@ struct GemmArgs {
   const float *ep_mean, *ep_invstd;
   float *part;
   int mtiles;
-  dl3_tail tail;  // BatchNorm finalize by the last-arriving workgroup of a column tile (ticket == nullptr: none)
-  int tune;       // bit 0: raise the wave priority for the MFMA main loop (s_setprio), drop it for the epilogue
 };
 
 constexpr int BK = 16;
@@ -46,8 +44,11 @@ constexpr int BK = 16;
 #ifndef DL3_STREAM_TAIL
 #define DL3_STREAM_TAIL 2
 #endif
-#ifndef DL3_GEMM_TUNE_DEFAULT
-#define DL3_GEMM_TUNE_DEFAULT 0
+#ifndef DL3_WGRAD_WGS_DEFAULT
+#define DL3_WGRAD_WGS_DEFAULT 1024
+#endif
+#ifndef DL3_GEMM_PY_DEFAULT
+#define DL3_GEMM_PY_DEFAULT 2048
 #endif
 #ifndef DL3_WGRAD_MS
 #define DL3_WGRAD_MS 16
@@ -295,13 +296,10 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmArgs P) {
           a1 += sred[(w * BN + cl) * 2 + 0];
           a2 += sred[(w * BN + cl) * 2 + 1];
         }
-        dl3_pub(P.part + ((size_t)by * P.N + col) * 2 + 0, a1);
-        dl3_pub(P.part + ((size_t)by * P.N + col) * 2 + 1, a2);
+        P.part[((size_t)by * P.N + col) * 2 + 0] = a1;
+        P.part[((size_t)by * P.N + col) * 2 + 1] = a2;
       }
     }
-    // every workgroup of column tile bx has published its row `by`: the last one to arrive finalises the BatchNorm
-    if (P.tail.ticket && dl3_last_arrival(P.tail.ticket + bx, gridDim.y))
-      dl3_tail_bn(P.tail, P.part, (int)gridDim.y, P.N, n0, min(BN, P.N - n0));
   }
 }
 
@@ -479,7 +477,6 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
     transform(0);
     adopt();
     __syncthreads();
-    if (P.tune & 1) __builtin_amdgcn_s_setprio(1);  // main loop: the matrix pipe of this SIMD goes to this wave first
     for (int kt = 0; kt < ktiles; ++kt) {
       const float *Bs = lds + (kt & 1) * KT * LDB;
       const bool more = kt + 1 < ktiles;
@@ -514,7 +511,6 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
     }
 
     // ---------------- epilogue (same C/D layout as the LDS-staged kernel)
-    if (P.tune & 1) __builtin_amdgcn_s_setprio(0);  // memory phase: yield to the co-resident wave's MFMAs
     const bool full = (m0 + BM <= P.M) && (n0 + BN <= P.N);
     if (FWD && full) {
       if (!P.ep_add) stream_epilogue_full<TM, TN, false, false, false>(P, acc, m0, nw0, wm, l31, lhi, st1, st2);
@@ -595,13 +591,10 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
           a1 += sred[(w * BN + cl) * 2 + 0];
           a2 += sred[(w * BN + cl) * 2 + 1];
         }
-        dl3_pub(P.part + ((size_t)by * P.N + col) * 2 + 0, a1);
-        dl3_pub(P.part + ((size_t)by * P.N + col) * 2 + 1, a2);
+        P.part[((size_t)by * P.N + col) * 2 + 0] = a1;
+        P.part[((size_t)by * P.N + col) * 2 + 1] = a2;
       }
     }
-    // every workgroup of column tile bx has published its row `by`: the last one to arrive finalises the BatchNorm
-    if (P.tail.ticket && dl3_last_arrival(P.tail.ticket + bx, gridDim.y))
-      dl3_tail_bn(P.tail, P.part, (int)gridDim.y, P.N, n0, min(BN, P.N - n0));
   }
 }
 
@@ -887,8 +880,11 @@ GemmCfg pick_gemm(int M, int K, int N, bool two, bool small) {
 
 int gemm_grid_y(int M, int N, const GemmCfg &c) {
   const int mtiles = dl3_cdiv(M, c.BM), ntn = dl3_cdiv(N, c.BN);
-  const int pytot = env_int("DL3_GEMM_PY");  // tuning aid: target number of workgroups per launch
-  int py = (pytot > 0 ? pytot : 2048) / ntn;
+  // target number of workgroups per launch.  Measured at the benchmark batch (MI355X, B=64, whole step): 4096 -> 59.2 ms,
+  // 2048 -> 58.8, 1024 -> 58.9, 512 -> 57.9: two resident workgroups per CU that each loop over row tiles beat several
+  // waves of short-lived ones (and write fewer BatchNorm partial rows).  DL3_GEMM_PY overrides (tuning aid).
+  const int pytot = env_int("DL3_GEMM_PY");
+  int py = (pytot > 0 ? pytot : DL3_GEMM_PY_DEFAULT) / ntn;
   if (py < 32) py = 32;
   if (mtiles <= py) return mtiles;
   const int iters = dl3_cdiv(mtiles, py);  // every workgroup loops over the same number of row tiles
@@ -914,10 +910,6 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   const bool stream = vec && env_int("DL3_GEMM_IMPL") != 0 && A.K <= DL3_STREAM_KMAX;
   const GemmCfg c = pick_gemm(A.M, A.K, A.N, two, stream);
   A.mtiles = dl3_cdiv(A.M, c.BM);
-  {
-    const int t = env_int("DL3_GEMM_TUNE");  // tuning aid: see GemmArgs::tune
-    A.tune = t >= 0 ? t : DL3_GEMM_TUNE_DEFAULT;
-  }
   dim3 grid(dl3_cdiv(A.N, c.BN), gemm_grid_y(A.M, A.N, c));
   // stream-A kernel: 10-25 % faster than the LDS-staged kernel on every layer shape, forward and bwd-data
   // (tools/gemm_tune.py).  The two-tensor bwd-data operand uses 16-deep K-tiles so that its register budget does not
@@ -959,7 +951,8 @@ const WgCfg kWgCfgs[] = {{0, 64, 64},  {1, 128, 128}, {2, 160, 128}, {3, 128, 16
 
 int wgrad_splits(int M, int K, int N, const WgCfg &c) {
   const long tiles = (long)dl3_cdiv(K, c.BKT) * dl3_cdiv(N, c.BNT);
-  long S = 1024 / tiles;
+  const int wgs = env_int("DL3_WGRAD_WGS");  // tuning aid: target number of workgroups per weight-gradient launch
+  long S = (wgs > 0 ? wgs : DL3_WGRAD_WGS_DEFAULT) / tiles;
   const long cap_traffic = (long)((double)M * (K + N) / (4.0 * K * N));
   const long cap_rows = M / 64;
   if (S > cap_traffic) S = cap_traffic;
@@ -1012,8 +1005,6 @@ void launch_wgrad(const WgradArgs &A, dim3 grid, hipStream_t st, bool vec) {
 
 extern "C" int dl3_reduce_partials(const float *partial, int P, int n, float *out, void *stream);
 
-extern "C" int dl3_pwconv_tail_groups(int N) { return N > 0 ? dl3_cdiv(N, 32) : 0; }
-
 extern "C" int dl3_pwconv_partials(int M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0) return 0;
   // the stat partial row count must not depend on which operand form is used: take the max
@@ -1040,7 +1031,7 @@ static void pad_partials(float *part, int M, int K, int N, int written, hipStrea
 
 extern "C" int dl3_pwconv_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
                               const float *w, const float *bias, float *y, int ldy, int M, int K, int N,
-                              float *stat_partial, const dl3_tail *tail, void *stream) {
+                              float *stat_partial, void *stream) {
   int rc = gemm_common_check("pwconv_fwd", M, K, N);
   if (rc) return rc;
   DL3_CHECK_ARG(x && w && y, "pwconv_fwd: null pointer");
@@ -1054,14 +1045,9 @@ extern "C" int dl3_pwconv_fwd(const float *x, int ldx, const float *in_scale, co
   A.add_div = 1; A.add_scale = 1.f;
   A.stat_mode = stat_partial ? 1 : 0;
   A.part = stat_partial;
-  if (tail) {
-    DL3_CHECK_ARG(stat_partial && tail->ticket && tail->kind == DL3_TAIL_BN_FWD && !tail->wsum,
-                  "pwconv_fwd: the tail needs stat_partial, a ticket buffer and kind BN_FWD");
-    A.tail = *tail;
-  }
   hipStream_t st = (hipStream_t)stream;
   const int written = run_gemm(A, st);
-  if (stat_partial && !tail) pad_partials(stat_partial, M, K, N, written, st);
+  if (stat_partial) pad_partials(stat_partial, M, K, N, written, st);
   DL3_LAUNCH_CHECK("pwconv_fwd");
   return DL3_OK;
 }
@@ -1071,7 +1057,7 @@ extern "C" int dl3_pwconv_bwd_data(const float *g, int ldg, const float *yraw, i
                                    const float *x, int ldx, const float *in_scale, const float *in_shift,
                                    int in_act, const float *dx_add, int ldadd, int add_div, float add_scale,
                                    const float *x_mean, const float *x_invstd, float *dstat_partial, int M,
-                                   int K, int N, const dl3_tail *tail, void *stream) {
+                                   int K, int N, void *stream) {
   int rc = gemm_common_check("pwconv_bwd_data", M, K, N);
   if (rc) return rc;
   DL3_CHECK_ARG(g && wT && dx, "pwconv_bwd_data: null pointer");
@@ -1093,14 +1079,9 @@ extern "C" int dl3_pwconv_bwd_data(const float *g, int ldg, const float *yraw, i
   A.stat_mode = dstat_partial ? 2 : 0;
   A.ep_mean = x_mean; A.ep_invstd = x_invstd;
   A.part = dstat_partial;
-  if (tail) {
-    DL3_CHECK_ARG(dstat_partial && tail->ticket && tail->kind == DL3_TAIL_BN_BWD && !tail->wsum,
-                  "pwconv_bwd_data: the tail needs dstat_partial, a ticket buffer and kind BN_BWD");
-    A.tail = *tail;
-  }
   hipStream_t st = (hipStream_t)stream;
   const int written = run_gemm(A, st);
-  if (dstat_partial && !tail) pad_partials(dstat_partial, M, N, K, written, st);
+  if (dstat_partial) pad_partials(dstat_partial, M, N, K, written, st);
   DL3_LAUNCH_CHECK("pwconv_bwd_data");
   return DL3_OK;
 }

@@ -128,18 +128,6 @@ class Engine:
         self._calls = 0
         self._keep = []
         self.drop_step = torch.zeros(1, dtype=torch.int64, device=self.device)  # device-side step number (dropout)
-        # "tails" (include/dl3.h dl3_tail): BatchNorm finalize / BatchNorm-backward finalize / depthwise weight-gradient
-        # sums are done by the last-arriving workgroup of the producing kernel instead of 160 tiny launches per step.
-        # DL3_TAILS=0 keeps the separate dl3_bn_finalize / dl3_bn_bwd_finalize / dl3_reduce_partials launches.
-        self.use_tails = os.environ.get("DL3_TAILS", "1") != "0"
-        # A tail folds P partial rows with ONE workgroup per channel group while the rest of the chip idles; the separate
-        # finalize launch spreads the same fold over C/8 workgroups.  Measured on MI355X: tails win while P
-        # is small (small batches: the launch they save costs more than the fold), and lose at the benchmark batch
-        # (P of several hundred: +2 ms per step at B=64).  Layers whose launch writes more rows than this keep the
-        # separate launch.
-        self.tail_max_rows = int(os.environ.get("DL3_TAIL_MAXP", "48"))
-        self.tickets = torch.zeros(1 << 16, dtype=torch.int32, device=self.device)
-        self._ticket_cursor = 0
         self._build_params()
         self._lower()
         if self.training:
@@ -237,69 +225,6 @@ class Engine:
             if l._engine is not None and l._engine is not self:
                 pass
             l._engine = self
-
-    # ------------------------------------------------------------------ tails
-    def _tickets(self, n):
-        off = self._ticket_cursor
-        self._ticket_cursor += int(n)
-        if self._ticket_cursor > self.tickets.numel():
-            raise RuntimeError("ticket arena exhausted")
-        return self.tickets.data_ptr() + 4 * off
-
-    def _tail(self, groups, kind, **f):
-        t = capi.Tail()
-        t.ticket = self._tickets(groups)
-        t.kind = kind
-        for k, v in f.items():
-            if k == "o":
-                for i, q in enumerate(v):
-                    t.o[i] = q
-            else:
-                setattr(t, k, v)
-        self._keep.append(t)
-        return t
-
-    def bn_fwd_tail(self, l, buf, off, C, groups):
-        """dl3_tail that makes a forward kernel finalise BatchNormalization `l` of its own output (channels
-        off..off+C of buf) — the in-kernel form of dl3_bn_finalize"""
-        n = l.name
-        upd = l.trainable  # Keras 2.2.x: a non-trainable layer's moving statistics receive no update
-        return self._tail(groups, capi.TAIL_BN_FWD, eps=l.cfg["eps"], momentum=l.cfg["momentum"], count=float(buf.M),
-                          var_unbias=BN_VARIANCE[self.bn_variance](float(buf.M), float(l.cfg["eps"])),
-                          gamma=self.wptr(n + "/gamma:0"), beta=self.wptr(n + "/beta:0"),
-                          o=[buf.vptr(V_SCALE, off), buf.vptr(V_SHIFT, off), buf.vptr(V_MEAN, off), buf.vptr(V_INVSTD, off),
-                             self.wptr(n + "/moving_mean:0") if upd else None,
-                             self.wptr(n + "/moving_variance:0") if upd else None])
-
-    def bn_bwd_tail(self, buf, groups, wsum=None, rows=0):
-        """dl3_tail for the kernel that writes the LAST gradient contribution into buf: the BatchNorm-backward finalize
-        of the one BatchNormalization living in buf (in-kernel dl3_bn_bwd_finalize).  None if that is not the simple
-        case (no BN, several BNs in a concat buffer, a BN on a channel slice): the caller then records the separate
-        launch."""
-        if not self.use_tails or rows > self.tail_max_rows:
-            return None
-        kind = capi.TAIL_NONE
-        f = {}
-        if buf is not None and buf.bns:
-            if len(buf.bns) != 1 or buf.bns[0][1] != 0 or buf.bns[0][2] != buf.ld:
-                return None if wsum is None else self._tail(groups, capi.TAIL_NONE, wsum=wsum)
-            bn, off, C = buf.bns[0]
-            n = bn.name
-            kind = capi.TAIL_BN_BWD
-            f = dict(batch_mode=1 if self.bn_batch else 0, count=float(buf.M), gamma=self.wptr(n + "/gamma:0"),
-                     mean=buf.vptr(V_MEAN, 0), invstd=buf.vptr(V_INVSTD, 0),
-                     o=[buf.vptr(V_CA, 0), buf.vptr(V_CB, 0), buf.vptr(V_CC, 0), self.gptr(n + "/gamma:0"),
-                        self.gptr(n + "/beta:0"), None])
-        elif wsum is None:
-            return None
-        if wsum is not None:
-            f["wsum"] = wsum
-        return self._tail(groups, kind, **f)
-
-    @staticmethod
-    def tail_arg(t):
-        import ctypes
-        return None if t is None else ctypes.addressof(t)
 
     # ------------------------------------------------------------------ op recording
     def op(self, lst, name, *args):
@@ -440,11 +365,7 @@ class Engine:
         C = v.C
         n = l.name
         v.buf.bns.append((l, v.off, C))
-        if self.bn_batch and self.use_tails and unit.tail_idx is not None and unit.P <= self.tail_max_rows:
-            # the producing kernel's last-arriving workgroup finalises this BatchNorm (no dl3_bn_finalize launch)
-            t = self.bn_fwd_tail(l, v.buf, v.off, C, unit.tail_groups)
-            unit.fwd_rec[2][unit.tail_idx] = self.tail_arg(t)
-        elif self.bn_batch:
+        if self.bn_batch:
             # Keras 2.2.x collects no updates from a non-trainable layer: a frozen BatchNormalization still normalises
             # with the batch statistics in the training phase, but its moving statistics stay as loaded
             upd = l.trainable
@@ -696,14 +617,12 @@ class Engine:
         need_x = masked or need_stat
         if view.off != 0 or view.C != buf.ld:
             raise NotImplementedError("element-wise gradient into a channel slice")
-        tail = self.bn_bwd_tail(buf, self.lib.dl3_grad_finish_tail_groups(buf.ld), rows=P) if need_stat else None
         self.op(self.ops_bwd, "dl3_grad_finish", gin, ldgin, gin_div, gin_scale, ptr(gout), buf.ld,
                 ptr(add), buf.ld, ptr(buf.t) if need_x else None, buf.ld,
                 view.scale() if masked else None, view.shift() if masked else None, view.act,
                 buf.vptr(V_MEAN) if need_stat else None, buf.vptr(V_INVSTD) if need_stat else None, ptr(dpart),
-                buf.M, buf.ld, drop[0], drop[1], self.drop_step.data_ptr() if drop[0] > 0 else None,
-                self.tail_arg(tail))
-        if need_stat and tail is None:
+                buf.M, buf.ld, drop[0], drop[1], self.drop_step.data_ptr() if drop[0] > 0 else None)
+        if need_stat:
             self.finish_bn_bwd(buf, dpart, P, buf.ld)
 
     def contrib_passthrough(self, buf, view, g):
@@ -719,12 +638,10 @@ class Engine:
                 if buf.bns:
                     P = self.lib.dl3_rows_partials(buf.M)
                     dpart = self.empty(P * buf.ld * 2)
-                    tail = self.bn_bwd_tail(buf, self.lib.dl3_grad_finish_tail_groups(buf.ld), rows=P)
                     self.op(self.ops_bwd, "dl3_grad_finish", ptr(g), buf.ld, 1, 1.0, ptr(g), buf.ld, None, 0,
                             ptr(buf.t), buf.ld, None, None, ACT_NONE, buf.vptr(V_MEAN), buf.vptr(V_INVSTD),
-                            ptr(dpart), buf.M, buf.ld, 0.0, 0, None, self.tail_arg(tail))
-                    if tail is None:
-                        self.finish_bn_bwd(buf, dpart, P, buf.ld)
+                            ptr(dpart), buf.M, buf.ld, 0.0, 0, None)
+                    self.finish_bn_bwd(buf, dpart, P, buf.ld)
             else:
                 buf.addend = g
             return
@@ -916,7 +833,6 @@ class _ConvBase:
         self.bn = None
         self.stat, self.P = None, 0
         self.want_stat = want_stat
-        self.fwd_rec, self.tail_idx, self.tail_groups = None, None, 0  # forward op record / position of its `tail` argument
         eng._consume(inv)
 
     def wname(self):
@@ -934,11 +850,8 @@ class PwUnit(_ConvBase):
             self.P = eng.lib.dl3_pwconv_partials(self.M, self.K, self.N)
             self.stat = eng.empty(self.P * self.N * 2)
         s, t, a = inv.xform()
-        self.fwd_rec = eng.op(eng.ops_fwd, "dl3_pwconv_fwd", inv.p(), inv.ld, s, t, a, eng.wptr(self.wname()),
-                              eng.wptr(self.bias) if self.bias else None, outv.p(), outv.ld, self.M, self.K, self.N,
-                              ptr(self.stat), None)
-        if want_stat:
-            self.tail_idx, self.tail_groups = 13, eng.lib.dl3_pwconv_tail_groups(self.N)
+        eng.op(eng.ops_fwd, "dl3_pwconv_fwd", inv.p(), inv.ld, s, t, a, eng.wptr(self.wname()),
+               eng.wptr(self.bias) if self.bias else None, outv.p(), outv.ld, self.M, self.K, self.N, ptr(self.stat))
 
     def bwd(self):
         eng, inv, outv = self.eng, self.inv, self.outv
@@ -961,14 +874,13 @@ class PwUnit(_ConvBase):
         if need_stat and (inv.off != 0 or inv.C != ibuf.ld):
             raise NotImplementedError("BN-backward statistics through a channel slice")
         need_x = a != ACT_NONE or need_stat
-        tail = eng.bn_bwd_tail(ibuf, eng.lib.dl3_pwconv_tail_groups(K), rows=P) if need_stat else None
         eng.op(eng.ops_bwd, "dl3_pwconv_bwd_data", g, ldg, y, ldy, cA, cB, cC, ptr(wT),
                gout.data_ptr() + 4 * inv.off, ibuf.ld, inv.p() if need_x else None, inv.ld,
                s if a != ACT_NONE else None, t if a != ACT_NONE else None, a,
                (add.data_ptr() + 4 * inv.off) if add is not None else None, ibuf.ld, 1, 1.0,
                ibuf.vptr(V_MEAN, inv.off) if need_stat else None, ibuf.vptr(V_INVSTD, inv.off) if need_stat else None,
-               ptr(dpart), M, K, N, eng.tail_arg(tail))
-        if need_stat and tail is None:
+               ptr(dpart), M, K, N)
+        if need_stat:
             eng.finish_bn_bwd(ibuf, dpart, P, ibuf.ld)
 
 
@@ -984,10 +896,8 @@ class DwUnit(_ConvBase):
         if want_stat:
             self.stat = eng.empty(self.P * C * 2)
         s, t, a = inv.xform()
-        self.fwd_rec = eng.op(eng.ops_fwd, "dl3_dwconv3x3_fwd", inv.p(), s, t, a, eng.wptr(self.wname()), outv.p(),
-                              *self.geom, ptr(self.stat), eng.dw_impl, None)
-        if want_stat:
-            self.tail_idx, self.tail_groups = 18, eng.lib.dl3_dwconv3x3_tail_groups(C)
+        eng.op(eng.ops_fwd, "dl3_dwconv3x3_fwd", inv.p(), s, t, a, eng.wptr(self.wname()), outv.p(), *self.geom,
+               ptr(self.stat), eng.dw_impl)
 
     def wname(self):
         return self.layer.name + "/depthwise_kernel:0"
@@ -1006,18 +916,11 @@ class DwUnit(_ConvBase):
             gout, add, last = eng.contrib_kernel(ibuf)
             need_stat = last and bool(ibuf.bns)
             dpart = eng.empty(self.P * C * 2) if need_stat else None
-        # tail: the slab's last workgroup sums the weight-gradient partials (no dl3_reduce_partials launch) and, when this
-        # is the last contribution into the input buffer, finalises its BatchNorm backward
-        tail = eng.bn_bwd_tail(ibuf if need_stat else None, eng.lib.dl3_dwconv3x3_tail_groups(C),
-                               wsum=eng.gptr(self.wname()), rows=self.P)
-        bn_in_tail = tail is not None and tail.kind == capi.TAIL_BN_BWD
         eng.op(eng.ops_bwd, "dl3_dwconv3x3_bwd", g, y, cA, cB, cC, inv.p(), s, t, a, eng.wptr(self.wname()),
                ptr(gout), ptr(add), ibuf.vptr(V_MEAN) if need_stat else None,
-               ibuf.vptr(V_INVSTD) if need_stat else None, ptr(dpart), ptr(wpart), *self.geom, eng.dw_impl,
-               eng.tail_arg(tail))
-        if tail is None:
-            eng.op(eng.ops_bwd, "dl3_reduce_partials", ptr(wpart), self.P, 9 * C, eng.gptr(self.wname()))
-        if need_stat and not bn_in_tail:
+               ibuf.vptr(V_INVSTD) if need_stat else None, ptr(dpart), ptr(wpart), *self.geom, eng.dw_impl)
+        eng.op(eng.ops_bwd, "dl3_reduce_partials", ptr(wpart), self.P, 9 * C, eng.gptr(self.wname()))
+        if need_stat:
             eng.finish_bn_bwd(ibuf, dpart, self.P, C)
 
 

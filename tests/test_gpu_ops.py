@@ -5,9 +5,8 @@ import pytest
 import torch
 
 from oracle import dl3_oracle as O
-from dl3_amd import capi
-from tests.gpu_util import (TailCheck, call, dev, dropout_keep_mask, empty, fold_partials, host, np_act, np_mask, ptr,
-                            relerr, stream)
+from tests.gpu_util import (call, dev, dropout_keep_mask, empty, fold_partials, host, np_act, np_mask, ptr, relerr,
+                            stream)
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-4
@@ -82,23 +81,11 @@ def test_dwconv_fwd(L, case):
     y, part = empty(N, Ho, Wo, C), empty(P, C, 2)
     call("dl3_dwconv3x3_fwd", ptr(dev(x)), ptr(dev(s)) if s is not None else None,
          ptr(dev(t)) if t is not None else None, a, ptr(dev(w)), ptr(y), N, H, W, C, stride, rate, pt, pl, Ho, Wo,
-         ptr(part), impl, None)
+         ptr(part), impl)
     assert relerr(host(y), ref) < TOL
     s1, s2 = fold_partials(part, P, C)
     assert relerr(s1, ref.sum((0, 1, 2))) < 1e-3
     assert relerr(s2, (ref ** 2).sum((0, 1, 2))) < 1e-3
-    # the same launch with a tail: the slab's last-arriving workgroup finalises the BatchNorm of the output itself
-    tc = TailCheck(capi.TAIL_BN_FWD, L.dl3_dwconv3x3_tail_groups(C), C, rng, N * Ho * Wo)
-    y2, part2 = empty(N, Ho, Wo, C), empty(P, C, 2)
-    for _ in range(2):  # twice: the tickets must have been left at zero
-        call("dl3_dwconv3x3_fwd", ptr(dev(x)), ptr(dev(s)) if s is not None else None,
-             ptr(dev(t)) if t is not None else None, a, ptr(dev(w)), ptr(y2), N, H, W, C, stride, rate, pt, pl, Ho, Wo,
-             ptr(part2), impl, tc.addr)
-    assert np.array_equal(host(y2), host(y))
-    tc.mm = tc.mom * tc.mm + (1 - tc.mom) * (ref.sum((0, 1, 2)) / tc.count)  # (the first of the two launches)
-    v_ = np.maximum((ref ** 2).sum((0, 1, 2)) / tc.count - (ref.sum((0, 1, 2)) / tc.count) ** 2, 0)
-    tc.mv = tc.mom * tc.mv + (1 - tc.mom) * v_ * tc.unb
-    tc.check_fwd(ref.sum((0, 1, 2)), (ref ** 2).sum((0, 1, 2)), tol=1e-3)
 
 
 @pytest.mark.parametrize("case", DW_CASES)
@@ -129,31 +116,13 @@ def test_dwconv_bwd(L, case):
     call("dl3_dwconv3x3_bwd", ptr(dev(g)), ptr(dev(yraw)), ptr(dev(cA)), ptr(dev(cB)), ptr(dev(cC)), ptr(dev(x)),
          ptr(dev(s)) if s is not None else None, ptr(dev(t)) if t is not None else None, a, ptr(dev(w)), ptr(dx),
          ptr(dev(add)), ptr(dev(mean)), ptr(dev(invstd)), ptr(dpart), ptr(wpart), N, H, W, C, stride, rate, pt, pl,
-         Ho, Wo, impl, None)
+         Ho, Wo, impl)
     assert relerr(host(dx), dx_ref) < TOL
     dwg = host(wpart).reshape(P, 3, 3, C).astype(np.float64).sum(0)
     assert relerr(dwg, dw_ref) < 1e-3
     s1, s2 = fold_partials(dpart, P, C)
     assert relerr(s1, dx_ref.sum((0, 1, 2))) < 1e-3
     assert relerr(s2, (dx_ref * (x - mean) * invstd).sum((0, 1, 2))) < 1e-3
-    # with a tail: BatchNorm-backward coefficients of the INPUT tensor's BatchNorm and the finished weight gradient
-    tc = TailCheck(capi.TAIL_BN_BWD, L.dl3_dwconv3x3_tail_groups(C), C, rng, N * H * W, wsum_n=9 * C)
-    tc.set_bwd_inputs(mean, invstd)
-    dx2, dpart2, wpart2 = empty(N, H, W, C), empty(P, C, 2), empty(P, 9, C)
-    for _ in range(2):
-        call("dl3_dwconv3x3_bwd", ptr(dev(g)), ptr(dev(yraw)), ptr(dev(cA)), ptr(dev(cB)), ptr(dev(cC)), ptr(dev(x)),
-             ptr(dev(s)) if s is not None else None, ptr(dev(t)) if t is not None else None, a, ptr(dev(w)), ptr(dx2),
-             ptr(dev(add)), ptr(dev(mean)), ptr(dev(invstd)), ptr(dpart2), ptr(wpart2), N, H, W, C, stride, rate, pt, pl,
-             Ho, Wo, impl, tc.addr)
-    assert np.array_equal(host(dx2), host(dx))
-    assert relerr(host(tc.wsum).reshape(3, 3, C), dw_ref) < 1e-3
-    tc.check_bwd(dx_ref.sum((0, 1, 2)), (dx_ref * (x - mean) * invstd).sum((0, 1, 2)))
-    # a tail that only sums the weight gradient (no BatchNorm in the input buffer)
-    tw = TailCheck(capi.TAIL_NONE, L.dl3_dwconv3x3_tail_groups(C), C, rng, N * H * W, wsum_n=9 * C)
-    call("dl3_dwconv3x3_bwd", ptr(dev(g)), ptr(dev(yraw)), ptr(dev(cA)), ptr(dev(cB)), ptr(dev(cC)), ptr(dev(x)),
-         ptr(dev(s)) if s is not None else None, ptr(dev(t)) if t is not None else None, a, ptr(dev(w)), ptr(dx2),
-         ptr(dev(add)), None, None, None, ptr(wpart2), N, H, W, C, stride, rate, pt, pl, Ho, Wo, impl, tw.addr)
-    assert np.array_equal(host(tw.wsum), host(tc.wsum)) and int(host(tw.ticket).max()) == 0
 
 
 @pytest.mark.parametrize("ppb", [2, 3, 5])
@@ -189,7 +158,7 @@ def test_dwconv_bwd_plain_operand(L):
     P = L.dl3_dwconv3x3_partials(N, H, W, C, 1, 2, H, W, 0)
     dx, wpart = empty(N, H, W, C), empty(P, 9, C)
     call("dl3_dwconv3x3_bwd", ptr(dev(g)), None, None, None, None, ptr(dev(x)), None, None, 0, ptr(dev(w)), ptr(dx),
-         None, None, None, None, ptr(wpart), N, H, W, C, 1, 2, 2, 2, H, W, 0, None)
+         None, None, None, None, ptr(wpart), N, H, W, C, 1, 2, 2, 2, H, W, 0)
     assert relerr(host(dx), grads[id(xv)]) < TOL
     assert relerr(host(wpart).reshape(P, 3, 3, C).sum(0), grads[id(wv)]) < 1e-3
 
@@ -237,7 +206,7 @@ def test_pwconv_fwd(L, case):
     xd = dev(xfull)
     call("dl3_pwconv_fwd", ptr(xd, xoff), ldx, ptr(dev(s)) if s is not None else None,
          ptr(dev(t)) if t is not None else None, a, ptr(dev(w)), ptr(dev(b)) if bias else None, ptr(yfull, lye), ldy,
-         M, K, N, ptr(part), None)
+         M, K, N, ptr(part))
     y = host(yfull)
     assert relerr(y[:, lye:], ref) < TOL
     if lye:
@@ -245,19 +214,6 @@ def test_pwconv_fwd(L, case):
     s1, s2 = fold_partials(part, P, N)
     assert relerr(s1, ref.sum(0)) < 1e-3
     assert relerr(s2, (ref ** 2).sum(0)) < 1e-3
-    # with a tail: the last-arriving workgroup of every column tile finalises the BatchNorm of its columns
-    tc = TailCheck(capi.TAIL_BN_FWD, L.dl3_pwconv_tail_groups(N), N, rng, M)
-    y2 = torch.zeros(M, ldy, dtype=torch.float32, device="cuda")
-    part2 = empty(P, N, 2)
-    for _ in range(2):
-        call("dl3_pwconv_fwd", ptr(xd, xoff), ldx, ptr(dev(s)) if s is not None else None,
-             ptr(dev(t)) if t is not None else None, a, ptr(dev(w)), ptr(dev(b)) if bias else None, ptr(y2, lye), ldy,
-             M, K, N, ptr(part2), tc.addr)
-    assert np.array_equal(host(y2), y)
-    v_ = np.maximum((ref ** 2).sum(0) / tc.count - (ref.sum(0) / tc.count) ** 2, 0)
-    tc.mm = tc.mom * tc.mm + (1 - tc.mom) * (ref.sum(0) / tc.count)
-    tc.mv = tc.mom * tc.mv + (1 - tc.mom) * v_ * tc.unb
-    tc.check_fwd(ref.sum(0), (ref ** 2).sum(0), tol=1e-3)
 
 
 @pytest.mark.parametrize("cfg", range(7))
@@ -323,24 +279,12 @@ def test_pwconv_bwd_data(L, case):
          ptr(dev(cB)) if two else None, ptr(dev(cC)) if two else None, ptr(wT), ptr(dx), K,
          ptr(dev(x)) if need_x else None, K, ptr(dev(s)) if s is not None else None,
          ptr(dev(t)) if t is not None else None, a, ptr(dev(add)) if add is not None else None, K, add_div, add_scale,
-         ptr(dev(mean)) if stats else None, ptr(dev(invstd)) if stats else None, ptr(dpart) if stats else None, M, K, N,
-         None)
+         ptr(dev(mean)) if stats else None, ptr(dev(invstd)) if stats else None, ptr(dpart) if stats else None, M, K, N)
     assert relerr(host(dx), ref) < TOL
     if stats:
         s1, s2 = fold_partials(dpart, P, K)
         assert relerr(s1, ref.sum(0)) < 1e-3
         assert relerr(s2, (ref * (x - mean) * invstd).sum(0)) < 1e-3
-        tc = TailCheck(capi.TAIL_BN_BWD, L.dl3_pwconv_tail_groups(K), K, rng, M)
-        tc.set_bwd_inputs(mean, invstd)
-        dx2, dpart2 = empty(M, K), empty(P, K, 2)
-        for _ in range(2):
-            call("dl3_pwconv_bwd_data", ptr(dev(g)), N, ptr(dev(yraw)) if two else None, N, ptr(dev(cA)) if two else None,
-                 ptr(dev(cB)) if two else None, ptr(dev(cC)) if two else None, ptr(wT), ptr(dx2), K, ptr(dev(x)), K,
-                 ptr(dev(s)) if s is not None else None, ptr(dev(t)) if t is not None else None, a,
-                 ptr(dev(add)) if add is not None else None, K, add_div, add_scale, ptr(dev(mean)), ptr(dev(invstd)),
-                 ptr(dpart2), M, K, N, tc.addr)
-        assert np.array_equal(host(dx2), host(dx))
-        tc.check_bwd(ref.sum(0), (ref * (x - mean) * invstd).sum(0))
 
 
 BW_CASES = [
@@ -511,7 +455,7 @@ def test_affine_add_and_dropout(L):
     o1, o2 = empty(M2, C2), empty(M2, C2)
     call("dl3_affine_add", ptr(dev(ones)), C2, None, None, 0, None, 0, None, None, 0, ptr(o1), C2, M2, C2, 0.1, 1234, None)
     call("dl3_grad_finish", ptr(dev(ones)), C2, 1, 1.0, ptr(o2), C2, None, 0, None, 0, None, None, 0, None, None, None,
-         M2, C2, 0.1, 1234, None, None)
+         M2, C2, 0.1, 1234, None)
     h1, h2 = host(o1), host(o2)
     assert np.array_equal(h1, h2)
     keep = (h1 != 0).mean()
@@ -526,7 +470,7 @@ def test_affine_add_and_dropout(L):
         call("dl3_affine_add", ptr(dev(ones)), C2, None, None, 0, None, 0, None, None, 0, ptr(o1), C2, M2, C2, 0.1, 1234,
              step.data_ptr())
         call("dl3_grad_finish", ptr(dev(ones)), C2, 1, 1.0, ptr(o2), C2, None, 0, None, 0, None, None, 0, None, None,
-             None, M2, C2, 0.1, 1234, step.data_ptr(), None)
+             None, M2, C2, 0.1, 1234, step.data_ptr())
         call("dl3_counter_add", step.data_ptr(), 1)
         m1, m2 = host(o1) != 0, host(o2) != 0
         assert np.array_equal(m1, m2)
@@ -548,25 +492,17 @@ def test_grad_finish_and_gap(L):
     P = L.dl3_rows_partials(M)
     out, part = empty(M, C), empty(P, C, 2)
     call("dl3_grad_finish", ptr(dev(g)), C, 1, 1.0, ptr(out), C, ptr(dev(add)), C, ptr(dev(x)), C, ptr(dev(s)),
-         ptr(dev(t)), 1, ptr(dev(mean)), ptr(dev(invstd)), ptr(part), M, C, 0.0, 0, None, None)
+         ptr(dev(t)), 1, ptr(dev(mean)), ptr(dev(invstd)), ptr(part), M, C, 0.0, 0, None)
     ref = g * np_mask(s * x + t, 1) + add
     assert relerr(host(out), ref) < 1e-6
     s1, s2 = fold_partials(part, P, C)
     assert relerr(s1, ref.astype(np.float64).sum(0)) < 1e-4
     assert relerr(s2, (ref.astype(np.float64) * (x - mean) * invstd).sum(0)) < 1e-4
-    tc = TailCheck(capi.TAIL_BN_BWD, L.dl3_grad_finish_tail_groups(C), C, rng, M)
-    tc.set_bwd_inputs(mean, invstd)
-    out2, part2 = empty(M, C), empty(P, C, 2)
-    for _ in range(2):
-        call("dl3_grad_finish", ptr(dev(g)), C, 1, 1.0, ptr(out2), C, ptr(dev(add)), C, ptr(dev(x)), C, ptr(dev(s)),
-             ptr(dev(t)), 1, ptr(dev(mean)), ptr(dev(invstd)), ptr(part2), M, C, 0.0, 0, None, tc.addr)
-    assert np.array_equal(host(out2), host(out))
-    tc.check_bwd(ref.astype(np.float64).sum(0), (ref.astype(np.float64) * (x - mean) * invstd).sum(0))
     # broadcast form (backward of the global average pool) accumulating in place
     gv = rng.normal(0, 1, (M // HW, C)).astype(np.float32)
     acc = dev(add)
     call("dl3_grad_finish", ptr(dev(gv)), C, HW, 1.0 / HW, ptr(acc), C, ptr(acc), C, None, 0, None, None, 0, None, None,
-         None, M, C, 0.0, 0, None, None)
+         None, M, C, 0.0, 0, None)
     assert relerr(host(acc), add + np.repeat(gv, HW, axis=0) / HW) < 1e-6
     # global average pool with transform, reading a channel slice
     N = M // HW
@@ -761,10 +697,10 @@ def test_adam_fill(L):
 
 def test_error_reporting(L):
     """bad arguments come back as a status + message, not a crash (include/dl3.h conventions)"""
-    rc = L.dl3_pwconv_fwd(None, 4, None, None, 0, None, None, None, 4, 4, 4, 4, None, None, stream())
+    rc = L.dl3_pwconv_fwd(None, 4, None, None, 0, None, None, None, 4, 4, 4, 4, None, stream())
     assert rc == -1 and b"null" in L.dl3_last_error()
     x = empty(16, 6)
-    rc = L.dl3_dwconv3x3_fwd(ptr(x), None, None, 0, ptr(x), ptr(x), 1, 4, 4, 6, 1, 1, 1, 1, 4, 4, None, 0, None, stream())
+    rc = L.dl3_dwconv3x3_fwd(ptr(x), None, None, 0, ptr(x), ptr(x), 1, 4, 4, 6, 1, 1, 1, 1, 4, 4, None, 0, stream())
     assert rc == -4
 
 

@@ -18,9 +18,9 @@ for N, H, W, C, r in cases:
     v = [f(C) for _ in range(7)]
     P = L.dl3_dwconv3x3_partials(N, H, W, C, 1, r, H, W, 0)
     part, dpart, wpart = f(P, C, 2), f(P, C, 2), f(P, 9, C)
-    fwd = lambda: capi.call("dl3_dwconv3x3_fwd", ptr(x), ptr(v[0]), ptr(v[1]), 2, ptr(w), ptr(y), N, H, W, C, 1, r, r, r, H, W, ptr(part), 0, None, st)
+    fwd = lambda: capi.call("dl3_dwconv3x3_fwd", ptr(x), ptr(v[0]), ptr(v[1]), 2, ptr(w), ptr(y), N, H, W, C, 1, r, r, r, H, W, ptr(part), 0, st)
     bwd = lambda: capi.call("dl3_dwconv3x3_bwd", ptr(g), ptr(y), ptr(v[2]), ptr(v[3]), ptr(v[4]), ptr(x), ptr(v[0]), ptr(v[1]), 2, ptr(w),
-                            ptr(dx), None, ptr(v[5]), ptr(v[6]), ptr(dpart), ptr(wpart), N, H, W, C, 1, r, r, r, H, W, 0, None, st)
+                            ptr(dx), None, ptr(v[5]), ptr(v[6]), ptr(dpart), ptr(wpart), N, H, W, C, 1, r, r, r, H, W, 0, st)
     e = N * H * W * C * 4.0
     tf, tb = bench.time_kernel(fwd), bench.time_kernel(bwd)
     print("N%d %dx%dx%d r%-2d P=%5d  fwd %.3f ms %.2f TB/s | bwd %.3f ms %.2f TB/s" % (N, H, W, C, r, P, tf, 2 * e / tf / 1e9, tb, 4 * e / tb / 1e9))

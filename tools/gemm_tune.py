@@ -38,14 +38,14 @@ def worker(batch, kind):
         if kind == "fwd":
             a, b, c, sc, sh = f(M, K), f(K, N), f(M, N), f(K), f(K)
             pp = f(L.dl3_pwconv_partials(M, K, N), N, 2)
-            run = lambda: capi.call("dl3_pwconv_fwd", ptr(a), K, ptr(sc), ptr(sh), 2, ptr(b), None, ptr(c), N, M, K, N, ptr(pp), None, st)
+            run = lambda: capi.call("dl3_pwconv_fwd", ptr(a), K, ptr(sc), ptr(sh), 2, ptr(b), None, ptr(c), N, M, K, N, ptr(pp), st)
         elif kind == "dgrad":  # dx[M,K] = dY[M,N].WT with BN-backward operand, mask and stats
             g, y, wT, dx, x = f(M, N), f(M, N), f(N, K), f(M, K), f(M, K)
             v = [f(max(K, N)) for _ in range(7)]
             pp = f(L.dl3_pwconv_partials(M, N, K), K, 2)
             run = lambda: capi.call("dl3_pwconv_bwd_data", ptr(g), N, ptr(y), N, ptr(v[0]), ptr(v[1]), ptr(v[2]), ptr(wT),
                                     ptr(dx), K, ptr(x), K, ptr(v[3]), ptr(v[4]), 2, None, K, 1, 1.0, ptr(v[5]), ptr(v[6]),
-                                    ptr(pp), M, K, N, None, st)
+                                    ptr(pp), M, K, N, st)
         else:
             x, g, y, dw = f(M, K), f(M, N), f(M, N), f(K, N)
             v = [f(max(K, N)) for _ in range(5)]
