@@ -880,11 +880,14 @@ GemmCfg pick_gemm(int M, int K, int N, bool two, bool small) {
 
 int gemm_grid_y(int M, int N, const GemmCfg &c) {
   const int mtiles = dl3_cdiv(M, c.BM), ntn = dl3_cdiv(N, c.BN);
-  // target number of workgroups per launch.  Measured at the benchmark batch (MI355X, B=64, whole step): 4096 -> 59.2 ms,
-  // 2048 -> 58.8, 1024 -> 58.9, 512 -> 57.9: two resident workgroups per CU that each loop over row tiles beat several
-  // waves of short-lived ones (and write fewer BatchNorm partial rows).  DL3_GEMM_PY overrides (tuning aid).
+  // target number of workgroups per launch (DL3_GEMM_PY overrides: tuning aid).  Measured on MI355X, whole step:
   const int pytot = env_int("DL3_GEMM_PY");
-  int py = (pytot > 0 ? pytot : DL3_GEMM_PY_DEFAULT) / ntn;
+  // plenty of row tiles (>= 4 per resident workgroup): 512 workgroups = exactly two per CU, each a persistent loop over
+  // its row tiles (sweep at B=64: 256 -> 64.3 ms, 384 -> 66.4, 512 -> 57.7, 640 -> 63.0, 768 -> 60.3, 2048 -> 58.4: any
+  // count that is not a whole number of waves of the chip leaves a ragged last wave); fewer tiles: several waves of
+  // short workgroups balance better (B=2: 2048 -> 4.97 ms, 512 -> 5.08)
+  const int dflt = ((long)mtiles * ntn >= 2048) ? 512 : DL3_GEMM_PY_DEFAULT;
+  int py = (pytot > 0 ? pytot : dflt) / ntn;
   if (py < 32) py = 32;
   if (mtiles <= py) return mtiles;
   const int iters = dl3_cdiv(mtiles, py);  // every workgroup loops over the same number of row tiles
