@@ -118,24 +118,27 @@ int dl3_conv3x3_bwd_data(const float *g, const float *yraw, const float *cA, con
                          const float *x_invstd, float *dstat_partial, int N, int H, int W, int Cin, int Cout,
                          int stride, int pad_t, int pad_l, int Ho, int Wo, void *stream);
 
-/* MFMA route for a dense 3x3 conv with Cin a multiple of 4 (xception entry_flow_conv1_2, deeplabv3p.py:289):
- * im2col into the caller's workspace, then the 1x1-conv GEMM kernels, then (bwd-data) col2im.  Same semantics as the
- * three ops above except: stat_partial has P = dl3_pwconv_partials(N*Ho*Wo, 9*Cin, Cout) rows; bwd_weight writes the
- * finished dw [3][3][Cin][Cout] (no partial rows); bwd_data takes wT [Cout][9*Cin] (dl3_transpose of w). */
-size_t dl3_conv3x3_gemm_workspace(int N, int H, int W, int Cin, int Cout, int stride, int Ho, int Wo);
-int dl3_conv3x3_gemm_fwd(const float *x, const float *in_scale, const float *in_shift, int in_act, const float *w,
+/* Matrix-pipe route for a dense 3x3 conv between 32- or 64-channel tensors (xception entry_flow_conv1_2 32 -> 64,
+ * deeplabv3p.py:289), im2col-free: the taps are gathered straight into the MFMA A operand, the weight slice of one tap
+ * is the LDS-staged B operand.  Same semantics as the three ops above except: the stat partial buffers have
+ * P = dl3_conv3x3_mfma_partials(N, Ho, Wo) (forward) / (N, H, W) (bwd-data) rows; bwd_weight writes the finished
+ * dw [3][3][Cin][Cout] (its per-workgroup slabs live in the caller's workspace); bwd_data takes
+ * wT [Cout][9*Cin] (dl3_transpose of w). */
+int dl3_conv3x3_mfma_supported(int Cin, int Cout);
+int dl3_conv3x3_mfma_partials(int N, int Hc, int Wc);
+int dl3_conv3x3_mfma_fwd(const float *x, const float *in_scale, const float *in_shift, int in_act, const float *w,
                          float *y, int N, int H, int W, int Cin, int Cout, int stride, int pad_t, int pad_l, int Ho,
-                         int Wo, float *stat_partial, void *workspace, size_t workspace_bytes, void *stream);
-int dl3_conv3x3_gemm_bwd_weight(const float *x, const float *in_scale, const float *in_shift, int in_act,
+                         int Wo, float *stat_partial, void *stream);
+size_t dl3_conv3x3_mfma_bwd_weight_workspace(int N, int H, int W, int Cin, int Cout, int stride, int Ho, int Wo);
+int dl3_conv3x3_mfma_bwd_weight(const float *x, const float *in_scale, const float *in_shift, int in_act,
                                 const float *g, const float *yraw, const float *cA, const float *cB, const float *cC,
                                 float *dw, int N, int H, int W, int Cin, int Cout, int stride, int pad_t, int pad_l,
                                 int Ho, int Wo, void *workspace, size_t workspace_bytes, void *stream);
-int dl3_conv3x3_gemm_bwd_data(const float *g, const float *yraw, const float *cA, const float *cB, const float *cC,
+int dl3_conv3x3_mfma_bwd_data(const float *g, const float *yraw, const float *cA, const float *cB, const float *cC,
                               const float *wT, float *dx, const float *x, const float *in_scale,
                               const float *in_shift, int in_act, const float *dx_add, const float *x_mean,
                               const float *x_invstd, float *dstat_partial, int N, int H, int W, int Cin, int Cout,
-                              int stride, int pad_t, int pad_l, int Ho, int Wo, void *workspace,
-                              size_t workspace_bytes, void *stream);
+                              int stride, int pad_t, int pad_l, int Ho, int Wo, void *stream);
 
 /* ---- BatchNormalization (54 layers mnv2 / 146 xception; eps 1e-3 or 1e-5) -------------- */
 /* training mode: fold stat partials [P][ldc][2] (channels c0..c0+C-1 at partial + 2*c0) into

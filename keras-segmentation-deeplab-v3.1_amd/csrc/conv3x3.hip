@@ -375,90 +375,283 @@ __global__ __launch_bounds__(256) void conv3x3_stem_wgrad_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// MFMA route for a dense 3x3 conv with many input channels (xception entry_flow_conv1_2: 32 -> 64 at 256x256,
-// 1.2 GMAC / image, deeplabv3p.py:289): im2col -> the 1x1-conv GEMM kernels -> col2im.  The column matrix
-// [N*Ho*Wo][9*Cin] costs one extra write + read of 9x the input, which the matrix pipe wins back ~10x over.
+// Dense 3x3 conv with many channels on the matrix pipe, im2col-free (xception entry_flow_conv1_2: 32 -> 64 at
+// 256x256, 1.2 GMAC / image, deeplabv3p.py:289).  The reduction axis (tap, channel) is walked tap by tap: for tap t
+// the A operand of v_mfma_f32_32x32x2_f32 is GATHERED from the tensor itself — lane (pixel = lane & 31, half = lane >> 5)
+// loads 16 consecutive channels of its tap-shifted pixel (four 16-byte loads; the 9x overlap between taps is served by
+// L1/L2, no column matrix exists) — and the 32 x CO weight slice of (tap, 32-channel chunk) is staged through
+// double-buffered LDS as the B operand.  One kernel serves
+//   forward   y[p][co]  = sum_{t,ci} T(x)[p (+) t][ci] * W[t][ci][co]        (epilogue: BN batch-stat partials)
+//   bwd-data  dx[p][ci] = sum_{t,co} dY[p (-) t][co]   * W[t][ci][co]        (prologue: BN-backward affine of two
+//             tensors on load; epilogue: activation mask, residual gradient, BN-backward stat partials)
+// A wave owns TP = 2 tiles of 32 pixels (one weight fragment read feeds both); a workgroup 256 pixels per step.
 // ---------------------------------------------------------------------------------------
-// col[m][(i*3+j)*Cin + c] = T(x)[n, oy*stride-pad_t+i, ox*stride-pad_l+j, c] (0 outside the image).
-// thread = one float4 of one (output pixel, tap); consecutive threads walk the row of the column matrix.
-__global__ __launch_bounds__(256) void im2col3x3_kernel(const float *__restrict__ x, const float *__restrict__ sc,
-                                                        const float *__restrict__ sh, int act,
-                                                        float *__restrict__ col, CGeom G) {
-  const int CQ = G.Cin / 4, RQ = 9 * CQ;
-  const long total = (long)G.N * G.Ho * G.Wo * RQ;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int q = (int)(idx % RQ);
-    const long m = idx / RQ;
-    const int tap = q / CQ, c = (q % CQ) * 4;
-    const int ox = (int)(m % G.Wo), oy = (int)((m / G.Wo) % G.Ho), n = (int)(m / ((long)G.Wo * G.Ho));
-    const int iy = oy * G.stride - G.pad_t + tap / 3, ix = ox * G.stride - G.pad_l + tap % 3;
-    const int iyc = min(max(iy, 0), G.H - 1), ixc = min(max(ix, 0), G.W - 1);
-    const float live = (iy == iyc && ix == ixc) ? 1.f : 0.f;
-    f32x4 v = ld4(x + (((size_t)n * G.H + iyc) * G.W + ixc) * G.Cin + c);
-    if (sc) v = ld4(sc + c) * v + ld4(sh + c);
-    v = dl3_act4(v, act) * splat4(live);
-    st4_nt(col + (size_t)idx * 4, v);
+struct TapArgs {
+  const float *a, *a2;                 // gathered tensor(s) [N, Ha, Wa, CA]
+  const float *ka, *kb, *kc;           // element transform act(ka*a + kb*a2 + kc) per channel (ka == nullptr: identity)
+  int a_act;
+  const float *w;                      // B[t][k][j] = w[t * w_ld_t + k * w_ld_k + j]
+  int w_ld_t, w_ld_k;
+  float *c;                            // output [N, Hc, Wc, CO]
+  const float *ep_x, *ep_scale, *ep_shift;  // bwd-data epilogue: forward input (mask, x_hat)
+  int ep_act;
+  const float *ep_add, *ep_mean, *ep_invstd;
+  float *part;                         // [gridDim.x][CO][2] (nullable)
+  int N, Ha, Wa, Hc, Wc, stride, pad_t, pad_l;
+};
+
+template <int CA, int CO, bool BWD>
+__global__ __launch_bounds__(256, 2) void conv3x3_tap_mfma_kernel(TapArgs P) {
+  constexpr int NJ = CO / 32, NCH = CA / 32, TP = 2, NST = 9 * NCH, NW = (32 * CO / 4) / 256;
+  static_assert(CA % 32 == 0 && CO % 32 == 0 && NW >= 1 && NJ <= 4, "32-channel chunks");
+  __shared__ float Ws[2][32 * CO];
+  __shared__ float cf[3][CA];
+  __shared__ float red[4][2 * CO];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const bool two = BWD && P.a2 != nullptr;
+  for (int i = tid; i < CA; i += 256) {
+    cf[0][i] = P.ka ? P.ka[i] : 1.f;
+    cf[1][i] = two ? P.kb[i] : 0.f;
+    cf[2][i] = P.ka ? P.kc[i] : 0.f;
+  }
+  float st1[NJ], st2[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) st1[j] = st2[j] = 0.f;
+  const long NP = (long)P.N * P.Hc * P.Wc;
+
+  f32x4 rw[NW];
+  auto load_w = [&](int q) {  // stage q = (tap, chunk): 32 k-rows x CO columns
+    const int t = q / NCH, ch = q % NCH;
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+      const int idx = tid + 256 * i, kk = idx / (CO / 4), c4 = (idx % (CO / 4)) * 4;
+      rw[i] = ld4(P.w + (size_t)t * P.w_ld_t + (size_t)(ch * 32 + kk) * P.w_ld_k + c4);
+    }
+  };
+  auto store_w = [&](float *dst) {
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+      const int idx = tid + 256 * i;
+      st4(dst + (idx / (CO / 4)) * CO + (idx % (CO / 4)) * 4, rw[i]);
+    }
+  };
+
+  for (long base = (long)blockIdx.x * (128 * TP); base < NP; base += (long)gridDim.x * (128 * TP)) {
+    int py[TP], px[TP], pn[TP];
+#pragma unroll
+    for (int tp = 0; tp < TP; tp++) {
+      const long p = min(base + (wave * TP + tp) * 32 + l31, NP - 1);
+      px[tp] = (int)(p % P.Wc);
+      py[tp] = (int)((p / P.Wc) % P.Hc);
+      pn[tp] = (int)(p / ((long)P.Wc * P.Hc));
+    }
+    f32x16 acc[TP][NJ];
+#pragma unroll
+    for (int tp = 0; tp < TP; tp++)
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[tp][j][r] = 0.f;
+
+    load_w(0);
+    __syncthreads();  // previous step's readers are done with both buffers (and cf is visible)
+    store_w(Ws[0]);
+    __syncthreads();
+    for (int q = 0; q < NST; ++q) {
+      const int t = q / NCH, ch = q % NCH, ti = t / 3, tj = t % 3;
+      if (q + 1 < NST) load_w(q + 1);
+      // gather: 16 consecutive channels (ch*32 + lhi*16 ..) of the tap-shifted pixel, all loads issued first
+      f32x4 av[TP][4], bv[TP][4];
+      float live[TP];
+#pragma unroll
+      for (int tp = 0; tp < TP; tp++) {
+        int gy, gx;
+        bool ok;
+        if (!BWD) {
+          gy = py[tp] * P.stride - P.pad_t + ti;
+          gx = px[tp] * P.stride - P.pad_l + tj;
+          ok = gy >= 0 && gy < P.Ha && gx >= 0 && gx < P.Wa;
+        } else {  // transposed: which output pixel used this input pixel under tap (ti, tj)?
+          const int ty = py[tp] + P.pad_t - ti, tx = px[tp] + P.pad_l - tj;
+          gy = ty / P.stride;
+          gx = tx / P.stride;
+          ok = ty >= 0 && tx >= 0 && ty % P.stride == 0 && tx % P.stride == 0 && gy < P.Ha && gx < P.Wa;
+        }
+        const int gyc = min(max(gy, 0), P.Ha - 1), gxc = min(max(gx, 0), P.Wa - 1);
+        live[tp] = ok ? 1.f : 0.f;
+        const size_t off = (((size_t)pn[tp] * P.Ha + gyc) * P.Wa + gxc) * CA + ch * 32 + lhi * 16;
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+          av[tp][v] = ld4(P.a + off + 4 * v);
+          if (BWD) bv[tp][v] = two ? ld4(P.a2 + off + 4 * v) : splat4(0.f);
+        }
+      }
+      float aop[TP][16];
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const int cbase = ch * 32 + lhi * 16 + 4 * v;
+        const f32x4 fa = ld4(&cf[0][cbase]), fb = ld4(&cf[1][cbase]), fc = ld4(&cf[2][cbase]);
+#pragma unroll
+        for (int tp = 0; tp < TP; tp++) {
+          f32x4 x4 = fa * av[tp][v] + fc;
+          if (BWD) x4 += fb * bv[tp][v];
+          x4 = dl3_act4(x4, P.a_act) * splat4(live[tp]);
+          aop[tp][4 * v + 0] = x4.x; aop[tp][4 * v + 1] = x4.y; aop[tp][4 * v + 2] = x4.z; aop[tp][4 * v + 3] = x4.w;
+        }
+      }
+      const float *B = Ws[q & 1];
+#pragma unroll
+      for (int s_ = 0; s_ < 16; s_++) {
+        float bf[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) bf[j] = B[(lhi * 16 + s_) * CO + j * 32 + l31];
+#pragma unroll
+        for (int tp = 0; tp < TP; tp++)
+#pragma unroll
+          for (int j = 0; j < NJ; j++)
+            acc[tp][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[tp][s_], bf[j], acc[tp][j], 0, 0, 0);
+      }
+      if (q + 1 < NST) store_w(Ws[(q + 1) & 1]);
+      __syncthreads();
+    }
+
+    // epilogue: C/D reg r of lane l is pixel row (r&3) + 8*(r>>2) + 4*(l>>5) of the tile, channel l & 31
+#pragma unroll
+    for (int tp = 0; tp < TP; tp++) {
+      const long tbase = base + (wave * TP + tp) * 32;
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const int col = j * 32 + l31;
+        float es = 1.f, et = 0.f, mu = 0.f, is = 0.f;
+        if (BWD && P.ep_scale) { es = P.ep_scale[col]; et = P.ep_shift[col]; }
+        if (BWD && P.ep_mean) { mu = P.ep_mean[col]; is = P.ep_invstd[col]; }
+        float xr[16], ad[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const long p = min(tbase + (r & 3) + 8 * (r >> 2) + 4 * lhi, NP - 1);
+          xr[r] = (BWD && P.ep_x) ? P.ep_x[(size_t)p * CO + col] : 0.f;
+          ad[r] = (BWD && P.ep_add) ? P.ep_add[(size_t)p * CO + col] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const long p = tbase + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          float v = acc[tp][j][r];
+          if (BWD && P.ep_x) v *= dl3_act_mask(es * xr[r] + et, P.ep_act);
+          v += ad[r];
+          if (p < NP) {
+            __builtin_nontemporal_store(v, &P.c[(size_t)p * CO + col]);
+            st1[j] += v;
+            st2[j] += BWD ? v * ((xr[r] - mu) * is) : v * v;
+          }
+        }
+      }
+    }
+  }
+  if (P.part) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const float a1 = st1[j] + __shfl_xor(st1[j], 32, 64), a2 = st2[j] + __shfl_xor(st2[j], 32, 64);
+      if (lhi == 0) { red[wave][2 * (j * 32 + l31)] = a1; red[wave][2 * (j * 32 + l31) + 1] = a2; }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * CO; i += 256)
+      P.part[(size_t)blockIdx.x * CO * 2 + i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
   }
 }
 
-// dx[n,iy,ix,c] = mask(x) * sum over the taps (i,j) whose output pixel exists of dcol[(n,oy,ox)][(i*3+j)*Cin + c]
-// (+ dx_add); deterministic gather form of the transposed im2col.  Same epilogue / partial layout as the direct
-// bwd-data kernel: thread = (input pixel, 4 input channels).
-__global__ __launch_bounds__(256) void col2im3x3_kernel(const float *__restrict__ dcol, float *__restrict__ dx,
-                                                        const float *__restrict__ x, const float *__restrict__ sc,
-                                                        const float *__restrict__ sh, int act,
-                                                        const float *__restrict__ dx_add,
-                                                        const float *__restrict__ xmean,
-                                                        const float *__restrict__ xinvstd, float *__restrict__ part,
-                                                        CGeom G) {
-  __shared__ float red[256 * 8];
-  const int CQ = G.Cin / 4;
-  const int cq = threadIdx.x % CQ, pl = threadIdx.x / CQ, PL = 256 / CQ;
-  const int ci = cq * 4;
-  f32x4 s = splat4(1.f), t = splat4(0.f), mu = splat4(0.f), is = splat4(0.f);
-  if (sc) { s = ld4(sc + ci); t = ld4(sh + ci); }
-  if (part) { mu = ld4(xmean + ci); is = ld4(xinvstd + ci); }
-  f32x4 s1 = splat4(0.f), s2 = splat4(0.f);
-  const long NP = (long)G.N * G.H * G.W;
-  const size_t ldc = (size_t)9 * G.Cin;
-  for (long p = (long)blockIdx.x * PL + pl; p < NP; p += (long)gridDim.x * PL) {
-    const int ix = (int)(p % G.W), iy = (int)((p / G.W) % G.H), n = (int)(p / ((long)G.W * G.H));
-    f32x4 acc = splat4(0.f);
+// Weight gradient of the same convolution, im2col-free: dW[t][ci][co] = sum_p T(x)[p (+) t][ci] * dY[p][co] with the
+// pixel index as the reduction axis (two pixels per MFMA, as in conv3x3_stem_wgrad_kernel) and (ci, co) as the 32x32
+// tile axes.  A workgroup is THREE waves, one per kernel row i: wave i accumulates the three taps (i, 0..2) for every
+// (32-ci block, 32-co block) — 3*NCI*NCO accumulator tiles — so all nine taps of a pixel pair are covered by one pass
+// over dY (the three waves read the same dY rows, L1 serves two of them).  Operands come straight from global memory
+// with 128-byte coalesced dword loads (one channel per lane); no LDS in the main loop.
+struct TapWgArgs {
+  const float *x, *xs, *xt; int x_act;
+  const float *g, *y, *cA, *cB, *cC;
+  float *ws;  // [gridDim.x][9*CIN][COUT]
+  int N, H, W, Ho, Wo, stride, pad_t, pad_l;
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(192, 2) void conv3x3_tap_wgrad_kernel(TapWgArgs P) {
+  constexpr int NCI = CIN / 32, NCO = COUT / 32, U = (NCI * NCO >= 4) ? 2 : 4;  // pixel pairs in flight per iteration
+  static_assert(NCI * NCO <= 4, "register budget: 3*NCI*NCO accumulator tiles per wave");
+  const int lane = threadIdx.x & 63, ti = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const bool two = P.cA != nullptr;
+  float xs[NCI], xt[NCI], kA[NCO], kB[NCO], kC[NCO];
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-      const int ty = iy + G.pad_t - i;
-      const int oy = ty / G.stride;
-      const bool yok = ty >= 0 && (ty % G.stride) == 0 && oy < G.Ho;
-      const int oyc = min(max(oy, 0), G.Ho - 1);
+  for (int a = 0; a < NCI; a++) { xs[a] = P.xs ? P.xs[a * 32 + l31] : 1.f; xt[a] = P.xs ? P.xt[a * 32 + l31] : 0.f; }
+#pragma unroll
+  for (int b = 0; b < NCO; b++) {
+    kA[b] = two ? P.cA[b * 32 + l31] : 1.f;
+    kB[b] = two ? P.cB[b * 32 + l31] : 0.f;
+    kC[b] = two ? P.cC[b * 32 + l31] : 0.f;
+  }
+  const float *yr = two ? P.y : P.g;
+  f32x16 acc[3][NCI][NCO];
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+#pragma unroll
+    for (int a = 0; a < NCI; a++)
+#pragma unroll
+      for (int b = 0; b < NCO; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][a][b][r] = 0.f;
+
+  const long NP = (long)P.N * P.Ho * P.Wo;
+  const long per = ((NP + gridDim.x - 1) / gridDim.x + 2 * U - 1) / (2 * U) * (2 * U);
+  const long pbeg = (long)blockIdx.x * per, pend = min(NP, pbeg + per);
+  for (long q = pbeg; q < pend; q += 2 * U) {
+    float av[U][3][NCI], gv[U][NCO], yv[U][NCO], lv[U][3];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const long p = q + 2 * u + lhi;
+      const long pc = min(p, NP - 1);
+      const int ox = (int)(pc % P.Wo), oy = (int)((pc / P.Wo) % P.Ho), n = (int)(pc / ((long)P.Wo * P.Ho));
+      const int iy = oy * P.stride - P.pad_t + ti, iyc = min(max(iy, 0), P.H - 1);
 #pragma unroll
       for (int j = 0; j < 3; j++) {
-        const int tx = ix + G.pad_l - j;
-        const int ox = tx / G.stride;
-        const bool ok = yok && tx >= 0 && (tx % G.stride) == 0 && ox < G.Wo;
-        const int oxc = min(max(ox, 0), G.Wo - 1);
-        const f32x4 v = ld4(dcol + (((size_t)n * G.Ho + oyc) * G.Wo + oxc) * ldc + (i * 3 + j) * G.Cin + ci);
-        acc += v * splat4(ok ? 1.f : 0.f);
+        const int ix = ox * P.stride - P.pad_l + j, ixc = min(max(ix, 0), P.W - 1);
+        lv[u][j] = (p < pend && iy == iyc && ix == ixc) ? 1.f : 0.f;
+        const float *xp = P.x + (((size_t)n * P.H + iyc) * P.W + ixc) * CIN + l31;
+#pragma unroll
+        for (int a = 0; a < NCI; a++) av[u][j][a] = xp[a * 32];
+      }
+#pragma unroll
+      for (int b = 0; b < NCO; b++) {
+        gv[u][b] = P.g[(size_t)pc * COUT + b * 32 + l31];
+        yv[u][b] = yr[(size_t)pc * COUT + b * 32 + l31];
       }
     }
-    f32x4 out = acc, xr = splat4(0.f);
-    if (x) {
-      xr = ld4(x + (size_t)p * G.Cin + ci);
-      out = out * dl3_mask4(s * xr + t, act);
-    }
-    if (dx_add) out += ld4(dx_add + (size_t)p * G.Cin + ci);
-    st4(dx + (size_t)p * G.Cin + ci, out);
-    s1 += out;
-    s2 += out * ((xr - mu) * is);
-  }
-  if (part) {
-    float v[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
-    reduce_over_pixels<8>(v, red, CQ);
-    if ((int)threadIdx.x < CQ) {
-      float *d = part + ((size_t)blockIdx.x * G.Cin + ci) * 2;
-      d[0] = v[0]; d[1] = v[4]; d[2] = v[1]; d[3] = v[5];
-      d[4] = v[2]; d[5] = v[6]; d[6] = v[3]; d[7] = v[7];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      float bo[NCO];
+#pragma unroll
+      for (int b = 0; b < NCO; b++) bo[b] = kA[b] * gv[u][b] + kB[b] * yv[u][b] + kC[b];
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int a = 0; a < NCI; a++) {
+          const float ao = dl3_act(xs[a] * av[u][j][a] + xt[a], P.x_act) * lv[u][j];
+#pragma unroll
+          for (int b = 0; b < NCO; b++)
+            acc[j][a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, bo[b], acc[j][a][b], 0, 0, 0);
+        }
     }
   }
+  float *out = P.ws + (size_t)blockIdx.x * 9 * CIN * COUT;
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+#pragma unroll
+    for (int a = 0; a < NCI; a++)
+#pragma unroll
+      for (int b = 0; b < NCO; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int ci = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          out[((size_t)(ti * 3 + j) * CIN + ci) * COUT + b * 32 + l31] = acc[j][a][b][r];
+        }
 }
 
 int conv_blocks(long NP) {
@@ -544,102 +737,123 @@ extern "C" int dl3_conv3x3_bwd_data(const float *g, const float *yraw, const flo
   return DL3_OK;
 }
 
-// ---- MFMA route (im2col + the pointwise GEMM kernels) -----------------------------------
+// ---- matrix-pipe route for many-channel 3x3 convs (tap-gather kernels above; no column matrix) -------------
 namespace {
-size_t col_bytes(int N, int Ho, int Wo, int Cin) { return (size_t)N * Ho * Wo * 9 * Cin * sizeof(float); }
-size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
-int gemm_check(const char *name, const CGeom &G) {
+bool tap_pair_ok(int ca, int co) { return (ca == 32 || ca == 64) && (co == 32 || co == 64); }
+int tap_blocks(long NP) {
+  long b = (NP + 255) / 256;
+  return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
+}
+int tap_wgrad_blocks(long NP) {
+  long b = NP / 1024;
+  return (int)(b > 512 ? 512 : (b < 1 ? 1 : b));
+}
+int tap_check(const char *name, const CGeom &G) {
   DL3_CHECK_ARG(G.N > 0 && G.H > 0 && G.W > 0 && G.Cin > 0 && G.Cout > 0 && G.Ho > 0 && G.Wo > 0 && G.stride >= 1,
                 "%s: bad dimension", name);
-  DL3_UNSUPPORTED(G.Cin % 4 != 0 || 256 % (G.Cin / 4) != 0 || G.Cout % 4 != 0,
-                  "%s: needs Cin = 4*(a divisor of 256) and Cout %% 4 == 0 (got %d, %d)", name, G.Cin, G.Cout);
-  DL3_UNSUPPORTED((long)G.N * G.Ho * G.Wo * 9 * G.Cin >= (1l << 31) * 4, "%s: column matrix too large", name);
+  DL3_UNSUPPORTED(!tap_pair_ok(G.Cin, G.Cout), "%s: Cin, Cout must each be 32 or 64 (got %d, %d)", name, G.Cin, G.Cout);
   return DL3_OK;
 }
-int im2col_blocks(long total) {
-  long b = (total + 255) / 256;
-  return (int)(b > 16384 ? 16384 : b);
+template <bool BWD>
+void launch_tap(int ca, int co, const TapArgs &A, int blocks, hipStream_t st) {
+  dim3 g(blocks), b(256);
+  if (ca == 32 && co == 32) hipLaunchKernelGGL((conv3x3_tap_mfma_kernel<32, 32, BWD>), g, b, 0, st, A);
+  else if (ca == 32 && co == 64) hipLaunchKernelGGL((conv3x3_tap_mfma_kernel<32, 64, BWD>), g, b, 0, st, A);
+  else if (ca == 64 && co == 32) hipLaunchKernelGGL((conv3x3_tap_mfma_kernel<64, 32, BWD>), g, b, 0, st, A);
+  else hipLaunchKernelGGL((conv3x3_tap_mfma_kernel<64, 64, BWD>), g, b, 0, st, A);
 }
 }  // namespace
 
-extern "C" size_t dl3_conv3x3_gemm_workspace(int N, int H, int W, int Cin, int Cout, int stride, int Ho, int Wo) {
+extern "C" int dl3_conv3x3_mfma_supported(int Cin, int Cout) { return tap_pair_ok(Cin, Cout) ? 1 : 0; }
+
+extern "C" int dl3_conv3x3_mfma_partials(int N, int Hc, int Wc) {
+  if (N <= 0 || Hc <= 0 || Wc <= 0) return 0;
+  return tap_blocks((long)N * Hc * Wc);
+}
+
+extern "C" int dl3_conv3x3_mfma_fwd(const float *x, const float *in_scale, const float *in_shift, int in_act,
+                                    const float *w, float *y, int N, int H, int W, int Cin, int Cout, int stride,
+                                    int pad_t, int pad_l, int Ho, int Wo, float *stat_partial, void *stream) {
+  CGeom G{N, H, W, Cin, Cout, stride, pad_t, pad_l, Ho, Wo};
+  int rc = tap_check("conv3x3_mfma_fwd", G);
+  if (rc) return rc;
+  DL3_CHECK_ARG(x && w && y, "conv3x3_mfma_fwd: null pointer");
+  DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "conv3x3_mfma_fwd: scale/shift must come together");
+  TapArgs A{};
+  A.a = x; A.a2 = nullptr; A.ka = in_scale; A.kb = nullptr; A.kc = in_shift; A.a_act = in_act;
+  A.w = w; A.w_ld_t = Cin * Cout; A.w_ld_k = Cout;
+  A.c = y; A.part = stat_partial;
+  A.N = N; A.Ha = H; A.Wa = W; A.Hc = Ho; A.Wc = Wo; A.stride = stride; A.pad_t = pad_t; A.pad_l = pad_l;
+  launch_tap<false>(Cin, Cout, A, tap_blocks((long)N * Ho * Wo), (hipStream_t)stream);
+  DL3_LAUNCH_CHECK("conv3x3_mfma_fwd");
+  return DL3_OK;
+}
+
+extern "C" int dl3_conv3x3_mfma_bwd_data(const float *g, const float *yraw, const float *cA, const float *cB,
+                                         const float *cC, const float *wT, float *dx, const float *x,
+                                         const float *in_scale, const float *in_shift, int in_act,
+                                         const float *dx_add, const float *x_mean, const float *x_invstd,
+                                         float *dstat_partial, int N, int H, int W, int Cin, int Cout, int stride,
+                                         int pad_t, int pad_l, int Ho, int Wo, void *stream) {
+  CGeom G{N, H, W, Cin, Cout, stride, pad_t, pad_l, Ho, Wo};
+  int rc = tap_check("conv3x3_mfma_bwd_data", G);
+  if (rc) return rc;
+  DL3_CHECK_ARG(g && wT && dx, "conv3x3_mfma_bwd_data: null pointer");
+  DL3_CHECK_ARG(!cA || (yraw && cB && cC), "conv3x3_mfma_bwd_data: cA needs yraw, cB, cC");
+  DL3_CHECK_ARG(in_act == DL3_ACT_NONE || x, "conv3x3_mfma_bwd_data: activation mask needs x");
+  DL3_CHECK_ARG(!dstat_partial || (x && x_mean && x_invstd), "conv3x3_mfma_bwd_data: dstat needs x, x_mean, x_invstd");
+  DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "conv3x3_mfma_bwd_data: scale/shift must come together");
+  TapArgs A{};
+  A.a = g; A.a2 = cA ? yraw : nullptr; A.ka = cA; A.kb = cB; A.kc = cC; A.a_act = DL3_ACT_NONE;
+  A.w = wT; A.w_ld_t = Cin; A.w_ld_k = 9 * Cin;  // wT [Cout][9*Cin]: B[t][k = co][j = ci]
+  A.c = dx;
+  const bool need_x = in_act != DL3_ACT_NONE || dstat_partial;
+  A.ep_x = need_x ? x : nullptr; A.ep_scale = in_scale; A.ep_shift = in_shift; A.ep_act = in_act;
+  A.ep_add = dx_add; A.ep_mean = dstat_partial ? x_mean : nullptr; A.ep_invstd = dstat_partial ? x_invstd : nullptr;
+  A.part = dstat_partial;
+  A.N = N; A.Ha = Ho; A.Wa = Wo; A.Hc = H; A.Wc = W; A.stride = stride; A.pad_t = pad_t; A.pad_l = pad_l;
+  launch_tap<true>(Cout, Cin, A, tap_blocks((long)N * H * W), (hipStream_t)stream);
+  DL3_LAUNCH_CHECK("conv3x3_mfma_bwd_data");
+  return DL3_OK;
+}
+
+extern "C" int dl3_reduce_partials(const float *partial, int P, int n, float *out, void *stream);
+
+extern "C" size_t dl3_conv3x3_mfma_bwd_weight_workspace(int N, int H, int W, int Cin, int Cout, int stride, int Ho,
+                                                        int Wo) {
   (void)H; (void)W; (void)stride;
   if (N <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0) return 0;
-  return align256(col_bytes(N, Ho, Wo, Cin)) + dl3_pwconv_bwd_weight_workspace(N * Ho * Wo, 9 * Cin, Cout);
+  return (size_t)tap_wgrad_blocks((long)N * Ho * Wo) * 9 * Cin * Cout * sizeof(float);
 }
 
-extern "C" int dl3_conv3x3_gemm_fwd(const float *x, const float *in_scale, const float *in_shift, int in_act,
-                                    const float *w, float *y, int N, int H, int W, int Cin, int Cout, int stride,
-                                    int pad_t, int pad_l, int Ho, int Wo, float *stat_partial, void *workspace,
-                                    size_t workspace_bytes, void *stream) {
-  CGeom G{N, H, W, Cin, Cout, stride, pad_t, pad_l, Ho, Wo};
-  int rc = gemm_check("conv3x3_gemm_fwd", G);
-  if (rc) return rc;
-  DL3_CHECK_ARG(x && w && y && workspace, "conv3x3_gemm_fwd: null pointer");
-  DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "conv3x3_gemm_fwd: scale/shift must come together");
-  if (workspace_bytes < col_bytes(N, Ho, Wo, Cin)) {
-    dl3_set_error("conv3x3_gemm_fwd: workspace %zu < %zu bytes", workspace_bytes, col_bytes(N, Ho, Wo, Cin));
-    return DL3_EWORKSPACE;
-  }
-  float *col = (float *)workspace;
-  const long M = (long)N * Ho * Wo;
-  hipLaunchKernelGGL(im2col3x3_kernel, dim3(im2col_blocks(M * 9 * (Cin / 4))), dim3(256), 0, (hipStream_t)stream, x,
-                     in_scale, in_shift, in_act, col, G);
-  DL3_LAUNCH_CHECK("conv3x3_gemm_fwd(im2col)");
-  return dl3_pwconv_fwd(col, 9 * Cin, nullptr, nullptr, DL3_ACT_NONE, w, nullptr, y, Cout, (int)M, 9 * Cin, Cout,
-                        stat_partial, stream);
-}
-
-extern "C" int dl3_conv3x3_gemm_bwd_weight(const float *x, const float *in_scale, const float *in_shift, int in_act,
+extern "C" int dl3_conv3x3_mfma_bwd_weight(const float *x, const float *in_scale, const float *in_shift, int in_act,
                                            const float *g, const float *yraw, const float *cA, const float *cB,
                                            const float *cC, float *dw, int N, int H, int W, int Cin, int Cout,
                                            int stride, int pad_t, int pad_l, int Ho, int Wo, void *workspace,
                                            size_t workspace_bytes, void *stream) {
   CGeom G{N, H, W, Cin, Cout, stride, pad_t, pad_l, Ho, Wo};
-  int rc = gemm_check("conv3x3_gemm_bwd_weight", G);
+  int rc = tap_check("conv3x3_mfma_bwd_weight", G);
   if (rc) return rc;
-  DL3_CHECK_ARG(x && g && dw && workspace, "conv3x3_gemm_bwd_weight: null pointer");
-  DL3_CHECK_ARG(!cA || (yraw && cB && cC), "conv3x3_gemm_bwd_weight: cA needs yraw, cB, cC");
-  const size_t need = dl3_conv3x3_gemm_workspace(N, H, W, Cin, Cout, stride, Ho, Wo);
+  DL3_CHECK_ARG(x && g && dw && workspace, "conv3x3_mfma_bwd_weight: null pointer");
+  DL3_CHECK_ARG(!cA || (yraw && cB && cC), "conv3x3_mfma_bwd_weight: cA needs yraw, cB, cC");
+  DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "conv3x3_mfma_bwd_weight: scale/shift must come together");
+  const size_t need = dl3_conv3x3_mfma_bwd_weight_workspace(N, H, W, Cin, Cout, stride, Ho, Wo);
   if (workspace_bytes < need) {
-    dl3_set_error("conv3x3_gemm_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);
+    dl3_set_error("conv3x3_mfma_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);
     return DL3_EWORKSPACE;
   }
-  float *col = (float *)workspace;
-  const size_t cb = align256(col_bytes(N, Ho, Wo, Cin));
-  const long M = (long)N * Ho * Wo;
-  hipLaunchKernelGGL(im2col3x3_kernel, dim3(im2col_blocks(M * 9 * (Cin / 4))), dim3(256), 0, (hipStream_t)stream, x,
-                     in_scale, in_shift, in_act, col, G);
-  DL3_LAUNCH_CHECK("conv3x3_gemm_bwd_weight(im2col)");
-  return dl3_pwconv_bwd_weight(col, 9 * Cin, nullptr, nullptr, DL3_ACT_NONE, g, Cout, yraw, Cout, cA, cB, cC, dw,
-                               nullptr, (int)M, 9 * Cin, Cout, (char *)workspace + cb, workspace_bytes - cb, stream);
-}
-
-extern "C" int dl3_conv3x3_gemm_bwd_data(const float *g, const float *yraw, const float *cA, const float *cB,
-                                         const float *cC, const float *wT, float *dx, const float *x,
-                                         const float *in_scale, const float *in_shift, int in_act,
-                                         const float *dx_add, const float *x_mean, const float *x_invstd,
-                                         float *dstat_partial, int N, int H, int W, int Cin, int Cout, int stride,
-                                         int pad_t, int pad_l, int Ho, int Wo, void *workspace,
-                                         size_t workspace_bytes, void *stream) {
-  CGeom G{N, H, W, Cin, Cout, stride, pad_t, pad_l, Ho, Wo};
-  int rc = gemm_check("conv3x3_gemm_bwd_data", G);
-  if (rc) return rc;
-  DL3_CHECK_ARG(g && wT && dx && workspace, "conv3x3_gemm_bwd_data: null pointer");
-  DL3_CHECK_ARG(!cA || (yraw && cB && cC), "conv3x3_gemm_bwd_data: cA needs yraw, cB, cC");
-  DL3_CHECK_ARG(in_act == DL3_ACT_NONE || x, "conv3x3_gemm_bwd_data: activation mask needs x");
-  DL3_CHECK_ARG(!dstat_partial || (x && x_mean && x_invstd), "conv3x3_gemm_bwd_data: dstat needs x, x_mean, x_invstd");
-  if (workspace_bytes < col_bytes(N, Ho, Wo, Cin)) {
-    dl3_set_error("conv3x3_gemm_bwd_data: workspace %zu < %zu bytes", workspace_bytes, col_bytes(N, Ho, Wo, Cin));
-    return DL3_EWORKSPACE;
-  }
-  float *dcol = (float *)workspace;
-  const long M = (long)N * Ho * Wo;
-  rc = dl3_pwconv_bwd_data(g, Cout, yraw, Cout, cA, cB, cC, wT, dcol, 9 * Cin, nullptr, 0, nullptr, nullptr,
-                           DL3_ACT_NONE, nullptr, 0, 1, 1.f, nullptr, nullptr, nullptr, (int)M, 9 * Cin, Cout, stream);
-  if (rc) return rc;
-  hipLaunchKernelGGL(col2im3x3_kernel, dim3(conv_blocks((long)N * H * W)), dim3(256), 0, (hipStream_t)stream, dcol, dx,
-                     x, in_scale, in_shift, in_act, dx_add, x_mean, x_invstd, dstat_partial, G);
-  DL3_LAUNCH_CHECK("conv3x3_gemm_bwd_data(col2im)");
-  return DL3_OK;
+  TapWgArgs A{};
+  A.x = x; A.xs = in_scale; A.xt = in_shift; A.x_act = in_act;
+  A.g = g; A.y = yraw; A.cA = cA; A.cB = cB; A.cC = cC;
+  A.ws = (float *)workspace;
+  A.N = N; A.H = H; A.W = W; A.Ho = Ho; A.Wo = Wo; A.stride = stride; A.pad_t = pad_t; A.pad_l = pad_l;
+  const int blocks = tap_wgrad_blocks((long)N * Ho * Wo);
+  dim3 gr(blocks), bl(192);
+  hipStream_t st = (hipStream_t)stream;
+  if (Cin == 32 && Cout == 32) hipLaunchKernelGGL((conv3x3_tap_wgrad_kernel<32, 32>), gr, bl, 0, st, A);
+  else if (Cin == 32 && Cout == 64) hipLaunchKernelGGL((conv3x3_tap_wgrad_kernel<32, 64>), gr, bl, 0, st, A);
+  else if (Cin == 64 && Cout == 32) hipLaunchKernelGGL((conv3x3_tap_wgrad_kernel<64, 32>), gr, bl, 0, st, A);
+  else hipLaunchKernelGGL((conv3x3_tap_wgrad_kernel<64, 64>), gr, bl, 0, st, A);
+  DL3_LAUNCH_CHECK("conv3x3_mfma_bwd_weight");
+  return dl3_reduce_partials(A.ws, blocks, 9 * Cin * Cout, dw, stream);
 }

@@ -934,17 +934,17 @@ class Conv3Unit(_ConvBase):
         if inv.off != 0 or inv.ld != Cin or outv.off != 0 or outv.ld != Cout:
             raise NotImplementedError("dense 3x3 conv on channel slices")
         self.geom = (eng.B, H, W, Cin, Cout, stride, pt, pl, Ho, Wo)
-        # many input channels (xception entry_flow_conv1_2, 32 -> 64): im2col + the MFMA GEMM kernels; the 3-channel
-        # stem convs stay on the direct vector-ALU kernel
-        self.gemm = Cin >= 8 and Cin % 4 == 0 and 256 % (Cin // 4) == 0 and Cout % 4 == 0
+        # 32/64-channel tensors (xception entry_flow_conv1_2, 32 -> 64): the im2col-free matrix-pipe kernels (taps
+        # gathered straight into the MFMA operand); the 3-channel stem convs have their own MFMA kernels behind
+        # dl3_conv3x3_fwd
+        self.gemm = bool(eng.lib.dl3_conv3x3_mfma_supported(Cin, Cout))
         s, t, a = inv.xform()
         if self.gemm:
-            self.ws = eng.lib.dl3_conv3x3_gemm_workspace(eng.B, H, W, Cin, Cout, stride, Ho, Wo)
-            self.P = eng.lib.dl3_pwconv_partials(eng.B * Ho * Wo, 9 * Cin, Cout)
+            self.P = eng.lib.dl3_conv3x3_mfma_partials(eng.B, Ho, Wo)
             if want_stat:
                 self.stat = eng.empty(self.P * Cout * 2)
-            eng.op_ws(eng.ops_fwd, "dl3_conv3x3_gemm_fwd", self.ws, 17, inv.p(), s, t, a, eng.wptr(self.wname()),
-                      outv.p(), *self.geom, ptr(self.stat), 0, self.ws)
+            eng.op(eng.ops_fwd, "dl3_conv3x3_mfma_fwd", inv.p(), s, t, a, eng.wptr(self.wname()), outv.p(), *self.geom,
+                   ptr(self.stat))
             return
         self.P = eng.lib.dl3_conv3x3_partials(eng.B, Ho, Wo, Cout)
         if want_stat:
@@ -959,8 +959,9 @@ class Conv3Unit(_ConvBase):
         assert ldg == Cout and (y is None or ldy == Cout)
         s, t, a = inv.xform()
         if eng.trainable(self.wname()):
-            eng.op_ws(eng.ops_bwd, "dl3_conv3x3_gemm_bwd_weight", self.ws, 20, inv.p(), s, t, a, g, y, cA, cB, cC,
-                      eng.gptr(self.wname()), *self.geom, 0, self.ws)
+            ws = eng.lib.dl3_conv3x3_mfma_bwd_weight_workspace(*self.geom[:6], Ho, Wo)
+            eng.op_ws(eng.ops_bwd, "dl3_conv3x3_mfma_bwd_weight", ws, 20, inv.p(), s, t, a, g, y, cA, cB, cC,
+                      eng.gptr(self.wname()), *self.geom, 0, ws)
         ibuf = inv.buf
         if not ibuf.requires_grad:
             return
@@ -968,13 +969,13 @@ class Conv3Unit(_ConvBase):
         eng.transpose(eng.wptr(self.wname()), wT, 9 * Cin, Cout)
         gout, add, last = eng.contrib_kernel(ibuf)
         need_stat = last and bool(ibuf.bns)
-        P = eng.lib.dl3_conv3x3_partials(B, H, W, Cin)
+        P = eng.lib.dl3_conv3x3_mfma_partials(B, H, W)
         dpart = eng.empty(P * Cin * 2) if need_stat else None
         need_x = a != ACT_NONE or need_stat
-        eng.op_ws(eng.ops_bwd, "dl3_conv3x3_gemm_bwd_data", self.ws, 25, g, y, cA, cB, cC, ptr(wT), ptr(gout),
-                  inv.p() if need_x else None, s if a != ACT_NONE else None, t if a != ACT_NONE else None, a, ptr(add),
-                  ibuf.vptr(V_MEAN) if need_stat else None, ibuf.vptr(V_INVSTD) if need_stat else None, ptr(dpart),
-                  *self.geom, 0, self.ws)
+        eng.op(eng.ops_bwd, "dl3_conv3x3_mfma_bwd_data", g, y, cA, cB, cC, ptr(wT), ptr(gout),
+               inv.p() if need_x else None, s if a != ACT_NONE else None, t if a != ACT_NONE else None, a, ptr(add),
+               ibuf.vptr(V_MEAN) if need_stat else None, ibuf.vptr(V_INVSTD) if need_stat else None, ptr(dpart),
+               *self.geom)
         if need_stat:
             eng.finish_bn_bwd(ibuf, dpart, P, Cin)
 

@@ -705,14 +705,17 @@ def test_error_reporting(L):
 
 
 
-@pytest.mark.parametrize("shape", [(2, 24, 20, 32, 64, 1), (1, 17, 19, 16, 24, 2), (2, 16, 16, 8, 32, 1)])
-def test_conv3x3_gemm_route(L, shape):
-    """dense 3x3 conv through im2col + the MFMA GEMM kernels + col2im (xception entry_flow_conv1_2)"""
+@pytest.mark.parametrize("shape", [(2, 24, 20, 32, 64, 1), (1, 17, 19, 32, 64, 2), (2, 16, 16, 64, 32, 1),
+                                   (1, 9, 11, 32, 32, 1), (3, 33, 40, 64, 64, 1), (1, 70, 66, 32, 64, 1)])
+def test_conv3x3_mfma_route(L, shape):
+    """dense 3x3 conv between 32/64-channel tensors on the matrix pipe without a column matrix (xception
+    entry_flow_conv1_2, deeplabv3p.py:289): forward + BN partials, weight gradient, bwd-data + mask + add + BN-backward
+    partials; strides 1 and 2, odd sizes, more than one 256-pixel step per workgroup"""
     N, H, W, Cin, Cout, stride = shape
+    assert L.dl3_conv3x3_mfma_supported(Cin, Cout) == 1 and L.dl3_conv3x3_mfma_supported(3, 32) == 0
     rng = np.random.default_rng(16)
     Ho, pt, _ = O.same_pads(H, 3, stride, 1)
     Wo, pl, _ = O.same_pads(W, 3, stride, 1)
-    M = N * Ho * Wo
     x = rng.normal(0, 1, (N, H, W, Cin)).astype(np.float32)
     w = rng.normal(0, 0.2, (3, 3, Cin, Cout)).astype(np.float32)
     s = rng.uniform(0.5, 1.5, Cin).astype(np.float32)
@@ -722,13 +725,11 @@ def test_conv3x3_gemm_route(L, shape):
     tape = O.Tape()
     wv = w.astype(np.float64)
     ref = O.conv2d(xin, wv, stride, pt, pl, Ho, Wo, tape=tape)
-    wsb = L.dl3_conv3x3_gemm_workspace(N, H, W, Cin, Cout, stride, Ho, Wo)
-    ws = empty((wsb + 3) // 4)
-    P = L.dl3_pwconv_partials(M, 9 * Cin, Cout)
+    P = L.dl3_conv3x3_mfma_partials(N, Ho, Wo)
     y, part = empty(N, Ho, Wo, Cout), empty(P, Cout, 2)
     xd, sd, td, wd = dev(x), dev(s), dev(t), dev(w)
     geom = (N, H, W, Cin, Cout, stride, pt, pl, Ho, Wo)
-    call("dl3_conv3x3_gemm_fwd", ptr(xd), ptr(sd), ptr(td), 1, ptr(wd), ptr(y), *geom, ptr(part), ptr(ws), wsb)
+    call("dl3_conv3x3_mfma_fwd", ptr(xd), ptr(sd), ptr(td), 1, ptr(wd), ptr(y), *geom, ptr(part))
     assert relerr(host(y), ref) < TOL
     s1, s2 = fold_partials(part, P, Cout)
     assert relerr(s1, ref.sum((0, 1, 2))) < 1e-3 and relerr(s2, (ref ** 2).sum((0, 1, 2))) < 1e-3
@@ -738,31 +739,43 @@ def test_conv3x3_gemm_route(L, shape):
     dY = cA * g.astype(np.float64) + cB * yraw + cC
     grads = tape.backward(ref, dY)
     gd, cAd, cBd, cCd = dev(g), dev(cA), dev(cB), dev(cC)
+    wsb = L.dl3_conv3x3_mfma_bwd_weight_workspace(N, H, W, Cin, Cout, stride, Ho, Wo)
+    ws = empty((wsb + 3) // 4)
     dw = empty(3, 3, Cin, Cout)
-    call("dl3_conv3x3_gemm_bwd_weight", ptr(xd), ptr(sd), ptr(td), 1, ptr(gd), ptr(y), ptr(cAd), ptr(cBd), ptr(cCd),
+    call("dl3_conv3x3_mfma_bwd_weight", ptr(xd), ptr(sd), ptr(td), 1, ptr(gd), ptr(y), ptr(cAd), ptr(cBd), ptr(cCd),
          ptr(dw), *geom, ptr(ws), wsb)
     assert relerr(host(dw), grads[id(wv)]) < 1e-3
     wT = empty(Cout, 9 * Cin)
     call("dl3_transpose", ptr(wd), ptr(wT), 9 * Cin, Cout)
-    P2 = L.dl3_conv3x3_partials(N, H, W, Cin)
+    P2 = L.dl3_conv3x3_mfma_partials(N, H, W)
     dx, dpart = empty(N, H, W, Cin), empty(P2, Cin, 2)
     add = rng.normal(0, 1, (N, H, W, Cin)).astype(np.float32)
     mean = rng.normal(0, 1, Cin).astype(np.float32)
     invstd = rng.uniform(0.5, 2, Cin).astype(np.float32)
-    call("dl3_conv3x3_gemm_bwd_data", ptr(gd), ptr(y), ptr(cAd), ptr(cBd), ptr(cCd), ptr(wT), ptr(dx), ptr(xd), ptr(sd),
-         ptr(td), 1, ptr(dev(add)), ptr(dev(mean)), ptr(dev(invstd)), ptr(dpart), *geom, ptr(ws), wsb)
+    call("dl3_conv3x3_mfma_bwd_data", ptr(gd), ptr(y), ptr(cAd), ptr(cBd), ptr(cCd), ptr(wT), ptr(dx), ptr(xd), ptr(sd),
+         ptr(td), 1, ptr(dev(add)), ptr(dev(mean)), ptr(dev(invstd)), ptr(dpart), *geom)
     dx_ref = grads[id(xin)] * (z > 0) + add
     assert relerr(host(dx), dx_ref) < TOL
     d1, d2 = fold_partials(dpart, P2, Cin)
     assert relerr(d1, dx_ref.sum((0, 1, 2))) < 1e-3
     assert relerr(d2, (dx_ref * (x - mean) * invstd).sum((0, 1, 2))) < 1e-3
+    # plain gradient operand (cA == NULL), no mask, no add, no statistics
+    dx2 = empty(N, H, W, Cin)
+    call("dl3_conv3x3_mfma_bwd_data", ptr(gd), None, None, None, None, ptr(wT), ptr(dx2), None, None, None, 0, None, None,
+         None, None, *geom)
+    tape2 = O.Tape()
+    xv = x.astype(np.float64)
+    ref2 = O.conv2d(xv, wv, stride, pt, pl, Ho, Wo, tape=tape2)
+    assert relerr(host(dx2), tape2.backward(ref2, g.astype(np.float64))[id(xv)]) < TOL
     # same result as the direct vector-ALU kernel
-    if 256 % (Cout // 4) == 0:
-        y2 = empty(N, Ho, Wo, Cout)
-        call("dl3_conv3x3_fwd", ptr(xd), ptr(sd), ptr(td), 1, ptr(wd), ptr(y2), *geom, None)
-        assert relerr(host(y2), host(y)) < TOL
-    # too small a workspace is refused
-    assert L.dl3_conv3x3_gemm_fwd(ptr(xd), ptr(sd), ptr(td), 1, ptr(wd), ptr(y), *geom, None, ptr(ws), 16, stream()) == -3
+    y2 = empty(N, Ho, Wo, Cout)
+    call("dl3_conv3x3_fwd", ptr(xd), ptr(sd), ptr(td), 1, ptr(wd), ptr(y2), *geom, None)
+    assert relerr(host(y2), host(y)) < TOL
+    # too small a workspace is refused, unsupported channel counts too
+    assert L.dl3_conv3x3_mfma_bwd_weight(ptr(xd), ptr(sd), ptr(td), 1, ptr(gd), ptr(y), ptr(cAd), ptr(cBd), ptr(cCd),
+                                         ptr(dw), *geom, ptr(ws), 16, stream()) == -3
+    assert L.dl3_conv3x3_mfma_fwd(ptr(xd), None, None, 0, ptr(wd), ptr(y), N, H, W, 24, Cout, stride, pt, pl, Ho, Wo, None,
+                                  stream()) == -4
 
 
 # ---------------------------------------------------------------------------------------
