@@ -47,6 +47,70 @@ def _same_pads(size, k, stride, rate):
     return out, total // 2
 
 
+# ------------------------------------------------------------------ physical channel counts
+def stored_channels(c):
+    """channels a tensor is STORED with.  A pixel row that is not a whole number of 128-byte lines makes every
+    32-channel slab of the depthwise kernels straddle two lines: measured on MI355X, 16x64x64xC rate 2, forward /
+    backward: C=728 4.03 / 3.26 TB/s, C=736 6.44 / 4.44 TB/s (tools/dw_rates.py align).  Xception's 728-channel tensors
+    (entry_flow_block3 .. exit_flow_block1, 50+ depthwise layers) are therefore stored 736 wide: the 8 extra channels
+    carry zero weights, zero gamma / beta, and stay exactly zero forward and backward.  Only when the padding costs
+    <= 2 % traffic (144 -> 160 would cost 11 % and gains nothing net).  DL3_CHANNEL_PAD=0 disables it."""
+    if os.environ.get("DL3_CHANNEL_PAD", "1") == "0":
+        return c
+    p = (c + 31) // 32 * 32
+    return p if (p - c) <= 0.02 * c else c
+
+
+def plan_channels(model):
+    """{id(tensor): physical channel count}: a Conv2D may widen its output (zero columns), every other layer
+    propagates its input's width; producers that write slices of a Concatenate keep their logical width so that the
+    slices stay adjacent"""
+    nopad = set()
+    for l in model._topo:
+        if l.kind == "Concatenate":
+            for t in l.inbound:
+                p = t.layer
+                while p.kind not in ("Conv2D", "DepthwiseConv2D", "Add", "InputLayer", "Subpixel", "Concatenate"):
+                    p = p.inbound[0].layer
+                nopad.add(id(p))
+    phys = {}
+    for l in model._topo:
+        if l is model.input.layer:
+            phys[id(l.output)] = l.output.shape[-1]
+            continue
+        cin = [phys[id(t)] for t in l.inbound]
+        if l.kind == "Conv2D":
+            f = l.cfg["filters"]
+            c = f if id(l) in nopad else stored_channels(f)
+        elif l.kind == "Subpixel":
+            c = l.cfg["out_filters"]
+        elif l.kind == "Concatenate":
+            c = sum(cin)
+        elif l.kind == "Add":
+            if len(set(cin)) != 1:
+                raise NotImplementedError("Add of tensors stored with different channel counts (%s)" % l.name)
+            c = cin[0]
+        else:  # same logical width as the input: same stored width; otherwise (none on the path) the logical one
+            c = cin[0] if l.inbound[0].shape[-1] == l.output.shape[-1] else l.output.shape[-1]
+        phys[id(l.output)] = c
+    return phys
+
+
+def device_shape(phys, l, name, hshape):
+    """device shape of a weight: channel dimensions follow the stored width of the layer's input / output"""
+    cin = phys[id(l.inbound[0])] if l.inbound else None
+    cout = phys[id(l.output)]
+    if name.endswith("/depthwise_kernel:0"):
+        return (hshape[0], hshape[1], cin, 1)
+    if name.endswith("/kernel:0"):
+        if l.kind == "Subpixel":
+            return (hshape[0], hshape[1], cin, hshape[3])
+        return (hshape[0], hshape[1], cin, cout)
+    if l.kind == "Subpixel":
+        return tuple(hshape)
+    return (cout,)  # bias, gamma, beta, moving statistics
+
+
 class Buf:
     """One device tensor [N*H*W, ld] + its per-channel vectors + gradient accounting."""
 
@@ -128,6 +192,7 @@ class Engine:
         self._calls = 0
         self._keep = []
         self.drop_step = torch.zeros(1, dtype=torch.int64, device=self.device)  # device-side step number (dropout)
+        self._plan_channels()
         self._build_params()
         self._lower()
         if self.training:
@@ -150,19 +215,38 @@ class Engine:
         self._keep.append(t)
         return t
 
+    def _plan_channels(self):
+        self.phys = plan_channels(self.model)
+
+    def _dshape(self, l, name, hshape):
+        return device_shape(self.phys, l, name, hshape)
+
+    @staticmethod
+    def _pad_to(name, w, dshape):
+        w = np.asarray(w, np.float32)
+        if tuple(w.shape) == tuple(dshape):
+            return w
+        out = np.full(dshape, 1.0 if name.endswith("/moving_variance:0") else 0.0, np.float32)
+        out[tuple(slice(0, n) for n in w.shape)] = w
+        return out
+
     def _build_params(self):
         """Flat arenas: trainable parameters (kernels, biases, gamma, beta) | state (moving statistics and the
         weights of non-trainable layers).  One RCCL all-reduce and one Adam launch cover the whole model."""
         self.slots = {}
+        self.hshape = {}
         np_, ns = 0, 0
         for l in self.model.layers:
             for name, w in l.weights.items():
-                n = (w.size + 3) // 4 * 4
+                dshape = self._dshape(l, name, w.shape)
+                size = int(np.prod(dshape))
+                n = (size + 3) // 4 * 4
+                self.hshape[name] = tuple(w.shape)
                 if l.trainable and "/moving_" not in name:
-                    self.slots[name] = ("p", np_, w.size, w.shape, l)
+                    self.slots[name] = ("p", np_, size, dshape, l)
                     np_ += n
                 else:
-                    self.slots[name] = ("s", ns, w.size, w.shape, l)
+                    self.slots[name] = ("s", ns, size, dshape, l)
                     ns += n
         self.n_param = np_
         self.params = self.zeros(max(np_, 4))
@@ -197,7 +281,7 @@ class Engine:
         hp = np.zeros(self.params.numel(), np.float32)
         hs = np.zeros(self.state.numel(), np.float32)
         for name, (kind, off, n, shp, l) in self.slots.items():
-            (hp if kind == "p" else hs)[off:off + n] = l.weights[name].reshape(-1)
+            (hp if kind == "p" else hs)[off:off + n] = self._pad_to(name, l.weights[name], shp).reshape(-1)
         self.params.copy_(torch.from_numpy(hp))
         self.state.copy_(torch.from_numpy(hs))
         self.dirty = True
@@ -206,18 +290,22 @@ class Engine:
         hp = self.params.cpu().numpy()
         hs = self.state.cpu().numpy()
         for name, (kind, off, n, shp, l) in self.slots.items():
-            l.weights[name] = (hp if kind == "p" else hs)[off:off + n].reshape(shp).copy()
+            l.weights[name] = self._unpad(name, (hp if kind == "p" else hs)[off:off + n].reshape(shp))
 
     def sync_layer_to_host(self, layer):
         for name in layer.weights:
             kind, off, n, shp, _ = self.slots[name]
-            layer.weights[name] = self._arena(kind)[off:off + n].cpu().numpy().reshape(shp).copy()
+            layer.weights[name] = self._unpad(name, self._arena(kind)[off:off + n].cpu().numpy().reshape(shp))
 
     def sync_layer_to_device(self, layer):
         for name, w in layer.weights.items():
             kind, off, n, shp, _ = self.slots[name]
-            self._arena(kind)[off:off + n].copy_(torch.from_numpy(np.ascontiguousarray(w.reshape(-1))))
+            self._arena(kind)[off:off + n].copy_(torch.from_numpy(np.ascontiguousarray(self._pad_to(name, w, shp).reshape(-1))))
         self.dirty = True
+
+    def _unpad(self, name, arr):
+        """device layout -> the Keras shape of the weight (drops the zero channels of _cp)"""
+        return arr[tuple(slice(0, n) for n in self.hshape[name])].copy()
 
     def activate(self):
         """make this engine the one that layer.get_weights()/set_weights() talk to"""
@@ -394,7 +482,7 @@ class Engine:
             self.bufs.append(cbuf)
             self.units.append(SubsampleUnit(self, v, View(cbuf, 0, v.C), st))
             v = View(cbuf, 0, v.C)
-        Ho, Wo, N = v.shape[1], v.shape[2], l.cfg["filters"]
+        Ho, Wo, N = v.shape[1], v.shape[2], self.phys[id(l.output)]
         buf, off = self._new_out(l, Ho, Wo, N)
         u = PwUnit(self, l, v, View(buf, off, N), want_stat=self.bn_batch and self._bn_follows(l))
         self._register(u, buf, off)
@@ -453,6 +541,7 @@ class Engine:
     def _lo_Add(self, l):
         a, b = self._in(l, 0), self._in(l, 1)
         H, W, C = l.output.shape
+        C = self.phys[id(l.output)]
         buf = Buf(self, self.B, H, W, C, l.name)
         self.bufs.append(buf)
         self.units.append(AddUnit(self, a, b, View(buf, 0, C)))
@@ -819,7 +908,7 @@ class Engine:
     def grad_of(self, name):
         kind, off, n, shp, _ = self.slots[name]
         assert kind == "p"
-        return self.grads[off:off + n].cpu().numpy().reshape(shp)
+        return self._unpad(name, self.grads[off:off + n].cpu().numpy().reshape(shp))
 
 
 # ======================================================================================

@@ -228,3 +228,36 @@ def test_crf_hook_parameters():
     except ImportError:
         with pytest.raises(ImportError, match="pydensecrf"):
             U.do_crf(np.zeros((8, 8, 3), np.uint8), np.zeros((8, 8), np.int32))
+
+
+def test_stored_channel_plan():
+    """engine.plan_channels: Xception's 728-channel tensors are stored 736 wide (whole 128-byte lines per pixel row),
+    nothing else changes; device weight shapes follow; the slices of a Concatenate keep their logical widths"""
+    from dl3_amd import engine as E
+    assert [E.stored_channels(c) for c in (16, 24, 144, 304, 728, 960, 1024, 2048)] == [16, 24, 144, 304, 736, 960, 1024, 2048]
+    G.clear_session()
+    m = Deeplabv3(weights=None, input_shape=(64, 64, 3), classes=21, backbone="mobilenetv2", OS=16)
+    phys = E.plan_channels(m)
+    assert all(phys[id(l.output)] == l.output.shape[-1] for l in m.layers)
+    G.clear_session()
+    m = Deeplabv3(weights=None, input_shape=(64, 64, 3), classes=21, backbone="xception", OS=8)
+    phys = E.plan_channels(m)
+    L = {l.name: l for l in m.layers}
+    wide = [l.name for l in m.layers if phys[id(l.output)] != l.output.shape[-1]]
+    assert wide and all(L[n].output.shape[-1] == 728 and phys[id(L[n].output)] == 736 for n in wide)
+    for n in ("entry_flow_block3_separable_conv1_pointwise", "middle_flow_unit_7_separable_conv2_depthwise_BN",
+              "exit_flow_block1_separable_conv1_depthwise", "entry_flow_block3_shortcut", "add_3"):
+        if n in L:
+            assert n in wide, n
+    l = L["middle_flow_unit_1_separable_conv1_pointwise"]
+    assert E.device_shape(phys, l, l.name + "/kernel:0", (1, 1, 728, 728)) == (1, 1, 736, 736)
+    l = L["middle_flow_unit_1_separable_conv1_depthwise"]
+    assert E.device_shape(phys, l, l.name + "/depthwise_kernel:0", (3, 3, 728, 1)) == (3, 3, 736, 1)
+    l = L["exit_flow_block1_separable_conv2_pointwise"]  # 728 -> 1024: only the input side is widened
+    assert E.device_shape(phys, l, l.name + "/kernel:0", (1, 1, 728, 1024)) == (1, 1, 736, 1024)
+    l = L["middle_flow_unit_1_separable_conv1_pointwise_BN"]
+    assert E.device_shape(phys, l, l.name + "/gamma:0", (728,)) == (736,)
+    for l in m.layers:
+        if l.kind == "Concatenate":
+            assert phys[id(l.output)] == l.output.shape[-1]
+            assert all(phys[id(t)] == t.shape[-1] for t in l.inbound)
