@@ -50,8 +50,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64,
-                    help="images per GPU (4x SegModel.batch_size, utils.py:162; 50 GB of the 288 GB HBM)")
+    ap.add_argument("--batch", type=int, default=128,
+                    help="images per GPU (8x SegModel.batch_size, utils.py:162; 98 GB of the 288 GB HBM; throughput by "
+                         "batch on one MI355X, round 2: 16 -> 945, 32 -> 1042, 64 -> 1108, 128 -> 1140 img/s)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--backbone", default="mobilenetv2")
     ap.add_argument("--os", type=int, default=16, help="output stride (Xception only; MobileNetV2 always runs at 8)")
