@@ -154,6 +154,18 @@ def insitu_profile(eng, passes=3):
     return rows
 
 
+def _pmc_traffic(family, args):
+    """HBM bytes per step of a kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    separate runs, corrected as MI355X_MICROARCH.md prescribes; tools/collect_profiles.sh + tools/pmc_family.py) — only
+    for the configuration they were collected on, else None"""
+    pmc = os.path.join(ROOT, "profiles", "r02_%s_b%d_pmc.json" % (family, args.batch))
+    if os.path.exists(pmc) and args.head == "deeplab" and args.size == 512:
+        pj = json.load(open(pmc))
+        if pj.get("batch") == args.batch and pj.get("backbone") == args.backbone:
+            return pj.get("traffic_bytes_per_step")
+    return None
+
+
 def roofline_blocks(rows, args):
     tot = sum(r["ms"] for r in rows)
     fam = {}
@@ -173,18 +185,14 @@ def roofline_blocks(rows, args):
         out["roofline"] = {
             "bound": "mfma", "kernel": "Conv2D 1x1 GEMM family on v_mfma_f32_32x32x2_f32: pw_gemm_stream_kernel (forward, "
             "bwd-data) + pw_wgrad_kernel (bwd-weight), %d launches/step" % g["launches"],
-            "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS, "traffic": None,
+            "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS,
+            "traffic": _pmc_traffic("gemm", args),
             "avg_ms": g["ms"] / g["launches"], "family_ms_per_step": g["ms"], "algorithmic_flops_per_step": g["flops"],
             "algorithmic_bytes_per_step": g["bytes"], "share_of_step": g["ms"] / tot, "note": note % "FLOPs"}
     d = fam.get("dw_dilated")
     if d and d["ms"] > 0:
         gbs = d["bytes"] / d["ms"] / 1e6
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r02_dw_dilated_b%d_pmc.json" % args.batch)
-        if os.path.exists(pmc):
-            pj = json.load(open(pmc))
-            if pj.get("batch") == args.batch and pj.get("backbone") == args.backbone:
-                traffic = pj.get("traffic_bytes_per_step")
+        traffic = _pmc_traffic("dw_dilated", args)
         out["roofline_hbm"] = {
             "bound": "hbm", "kernel": "DepthwiseConv2D 3x3 rate>1 family: dw_march2_fwd / dw_march_fwd / dw_march_bwd, "
             "%d launches/step" % d["launches"],

@@ -36,7 +36,36 @@ def per_step(d, march_rows):
     return sum(tot) / len(tot), len(good)
 
 
+def gemm_family(fetch_dir, write_dir, plan):
+    """1x1-conv GEMM family by kernel name (pw_gemm_* + pw_wgrad_*): per-step sums, steps split at adam_kernel"""
+    def load(d):
+        tot, steps = 0.0, 0
+        for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = r["Kernel_Name"]
+                steps += "adam_kernel" in k
+                if "pw_gemm" in k or "pw_wgrad" in k:
+                    tot += float(r["Counter_Value"])
+        return tot / max(steps, 1), steps
+    f, fs = load(fetch_dir)
+    w, ws = load(write_dir)
+    alg = sum(r["bytes"] for r in plan["rows"] if r["family"] == "gemm")
+    fetch, write = 2.0 * f * 1024.0, w * 1024.0
+    print(json.dumps({
+        "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py --no-graph "
+                "--no-roofline --no-cpu-baseline; per-step sum over the pw_gemm_* / pw_wgrad_* dispatches; FETCH_SIZE "
+                "doubled (gfx950 correction of MI355X_MICROARCH.md; calibrated on wide coalesced reads — the GEMM A "
+                "operand is read in 16-byte pieces per lane, so treat the absolute as approximate), WRITE_SIZE as reported. "
+                "Algorithmic bytes count every operand once per launch; column tiles of a row tile re-read the activation "
+                "tile (L2 hits are not HBM traffic, misses are).",
+        "family": "gemm", "batch": plan["batch"], "backbone": plan["backbone"], "steps_used": [fs, ws],
+        "fetch_bytes_per_step": fetch, "write_bytes_per_step": write, "traffic_bytes_per_step": fetch + write,
+        "algorithmic_bytes_per_step": alg, "traffic_over_algorithmic": (fetch + write) / alg}, indent=1))
+
+
 def main():
+    if len(sys.argv) > 4 and sys.argv[4] == "gemm":
+        return gemm_family(sys.argv[1], sys.argv[2], json.load(open(sys.argv[3])))
     fetch_dir, write_dir, plan = sys.argv[1], sys.argv[2], json.load(open(sys.argv[3]))
     march_rows = [r for r in plan["rows"] if r["op"].startswith("dl3_dwconv3x3") and " s1 " in r["shape"] + " "]
     dil = [r for r in march_rows if r["family"] == "dw_dilated"]
