@@ -339,6 +339,7 @@ def main():
             rec["cpu_baseline"] = cpu_baseline_leg(args)
             log("cpu baseline done")
         print(json.dumps(rec), flush=True)
+    dp.barrier()  # rank 0's in-situ pass is local work: the others wait here, then every rank tears its communicator down
     dp.close()
 
 
