@@ -12,7 +12,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(_ROOT, "include", "dl3.h")
-LIBPATH = os.path.join(_HERE, "libdl3.so")
+LIBPATH = os.environ.get("DL3_LIBPATH") or os.path.join(_HERE, "libdl3.so")  # DL3_LIBPATH: A/B builds (tuning aid)
 
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 IMPL_AUTO, IMPL_GATHER, IMPL_MARCH = 0, 1, 2

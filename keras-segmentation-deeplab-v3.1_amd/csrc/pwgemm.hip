@@ -41,6 +41,9 @@ constexpr int BK = 16;
 #ifndef DL3_STREAM_KMAX
 #define DL3_STREAM_KMAX 2048  // largest reduction depth the stream kernel takes (coefficient vectors in LDS)
 #endif
+#ifndef DL3_STREAM_KT_FWD
+#define DL3_STREAM_KT_FWD 16  // K-tile depth of the forward instantiation (32 measured in round 2: see DESIGN.md)
+#endif
 #ifndef DL3_STREAM_TAIL
 #define DL3_STREAM_TAIL 2
 #endif
@@ -923,7 +926,7 @@ int run_gemm(GemmArgs A, hipStream_t st) {
 #define DL3_STREAM(TM_, TN_, WN_)                                                                                    \
   do {                                                                                                               \
     if (two) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, true, 16, 0, WN_>), grid, blk, 0, st, A);           \
-    else if (fwd) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, 16, 1, WN_>), grid, blk, 0, st, A);     \
+    else if (fwd) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, DL3_STREAM_KT_FWD, 1, WN_>), grid, blk, 0, st, A); \
     else hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, 16, 0, WN_>), grid, blk, 0, st, A);              \
   } while (0)
     switch (c.id) {
