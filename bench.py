@@ -251,14 +251,52 @@ def cpu_baseline_leg(args):
         return dict(value=B / med, cores=best, sweep_img_s={str(k): round(v, 3) for k, v in sweep.items()})
 
     c2 = measure(case(args.size, 21, 2), 2, "cfg2 %dx%d B=2" % (args.size, args.size))
+    cpu_a = cpu_a_leg(args, avail)
     # cfg1's shape at B=2: with one image the image-pooling BatchNorm sees a single value per channel
     c1 = measure(case(128, 2, 2), 2, "cfg1 128x128 B=2")
     return dict(value=c2["value"], unit="img/s", cores=c2["cores"], kind="port", host_cores_available=avail,
                 sample="median of 10 steps x 2 images %dx%dx21 fwd+bwd after 2 warm-up steps, torch-CPU (oneDNN) restatement "
                        "oracle/torch_ref.py, best of the thread-count sweep" % (args.size, args.size),
-                thread_sweep_img_s=c2["sweep_img_s"],
+                thread_sweep_img_s=c2["sweep_img_s"], cpu_a=cpu_a,
                 cfg1={"value": c1["value"], "unit": "img/s", "cores": c1["cores"],
                       "sample": "median of 10 steps x 2 images 128x128x2 fwd+bwd", "thread_sweep_img_s": c1["sweep_img_s"]})
+
+
+def cpu_a_leg(args, avail):
+    """CPU-A: the repo's own C / OpenMP restatement of the step — oracle/dl3_oracle.py's graph on the
+    operators of oracle/c/dl3_ops.c, float32 — cfg2 at B=2: one probe step per thread count, then the median of 3
+    steps after 1 warm-up at the best count (a step takes seconds: bounded sample)."""
+    from oracle import c_backend as CB
+    from oracle import dl3_oracle as O
+    kw = dict(backbone=args.backbone, input_shape=(args.size, args.size, 3), classes=21, OS=args.os)
+    params = O.init_params(O.param_shapes(args.backbone, 21), seed=1)
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 256, (2, args.size, args.size, 3)).astype(np.float32)
+    y = rng.integers(0, 22, (2, args.size * args.size)).astype(np.float32)
+    w = (y < 21).astype(np.float32)
+
+    def step():
+        t0 = time.perf_counter()
+        O.train_grads(params, x, y, w, **kw)
+        return time.perf_counter() - t0
+
+    sweep = {}
+    with CB.installed():
+        for t in sorted({t for t in (8, 16, 32, 64, 128) if t <= avail}):
+            CB.set_threads(t)
+            sweep[t] = 2 / step()
+            if sweep[t] < 0.6 * max(sweep.values()):
+                break
+        best = max(sweep, key=sweep.get)
+        CB.set_threads(best)
+        step()
+        ts = sorted(step() for _ in range(3))
+    log("cpu-a (C / OpenMP restatement) cfg2 B=2: %.2f img/s on %d threads (sweep %s)" % (
+        2 / ts[1], best, {k: round(v, 2) for k, v in sweep.items()}))
+    return dict(value=2 / ts[1], unit="img/s", cores=best, kind="port",
+                sample="median of 3 steps x 2 images %dx%dx21 fwd+bwd after 1 warm-up, numpy graph of oracle/dl3_oracle.py on "
+                       "the C / OpenMP operators of oracle/c/dl3_ops.c (float32)" % (args.size, args.size),
+                thread_sweep_img_s={str(k): round(v, 3) for k, v in sweep.items()})
 
 
 def main():

@@ -68,7 +68,7 @@ LATE = {
 HEAD_W = {"deeplab": "logits_semantic", "original": "conv_upsample", "subpixel": "subpixel_1"}
 
 
-def _train_parity(backbone, shape, head, OS, B):
+def _train_parity(backbone, shape, head, OS, B, second_oracle=False):
     classes = 21
     import dl3_amd  # noqa: F401
     from dl3_amd import graph as G
@@ -91,6 +91,19 @@ def _train_parity(backbone, shape, head, OS, B):
     got_loss = float(eng.loss[0].item())
     loss, grads, logits = T.train_grads(params, x, labels, sw, dtype=torch.float64, **kw)
     loss32, grads32, logits32 = T.train_grads(params, x, labels, sw, dtype=torch.float32, **kw)
+    if second_oracle:
+        # the numpy oracle on its C / OpenMP operators (oracle/c_backend.py), float64: the two restatements must agree
+        # with each other at this size before either judges the GPU
+        from oracle import c_backend as CB
+        p64 = {k: v.astype(np.float64) for k, v in params.items()}
+        with CB.installed(threads=min(32, os.cpu_count() or 1)):
+            lossB, gradsB, logitsB, _ = O.train_grads(p64, x.astype(np.float64), labels.astype(np.float64),
+                                                      sw.astype(np.float64), **kw)
+        eo = relerr(logitsB, logits)
+        go = max(_l2(gradsB[n], grads[n]) for n in grads if grads[n] is not None and np.abs(grads[n]).max() > 1e-9)
+        print("two float64 oracles at full size: logits rel %.2e, loss %.12f vs %.12f, worst gradient tensor rel-L2 %.2e"
+              % (eo, lossB, loss, go))
+        assert eo < 1e-9 and abs(lossB - loss) < 1e-10 * abs(loss) and go < 1e-6
     tag = "%s/%s OS=%d %dx%d B=%d" % (backbone, head, OS, shape[0], shape[1], B)
     e = relerr(got_logits, logits)
     print("%s: logits rel err %.2e (oracle fp32: %.2e) | loss gpu %.7f oracle %.7f" % (
@@ -127,7 +140,7 @@ def _train_parity(backbone, shape, head, OS, B):
 @pytest.mark.parametrize("head", ["deeplab", "original", "subpixel"])
 def test_cfg2_cfg3_mnv2_512_train_step(head):
     """BASELINE.json configs[1] and [2]: MobileNetV2 512x512x21, bilinear and Subpixel(+ICNR-shaped) heads, B=2"""
-    _train_parity("mobilenetv2", (512, 512, 3), head, 16, 2)
+    _train_parity("mobilenetv2", (512, 512, 3), head, 16, 2, second_oracle=(head == "deeplab"))
 
 
 def test_cfg4_xception_os8_512_forward():

@@ -265,3 +265,32 @@ def test_seg_counts_reproduce_the_metrics():
     c = O.seg_counts(np.array([[0, 0, 1, 1]]), np.array([[0, 1, 1, 2]], np.float32), 2)
     assert c.tolist() == [[[1, 2], [2, 2], [1, 1]]]
     assert U.Jaccard_from_counts(c) == (1 / 2 + 1 / 3) / 2
+
+
+@pytest.mark.parametrize("backbone,OS,head", [("mobilenetv2", 16, "deeplab"), ("mobilenetv2", 16, "subpixel"), ("xception", 8, "deeplab")])
+def test_c_operators_agree_with_numpy_operators(backbone, OS, head):
+    """oracle/c/dl3_ops.c (plain C loops, OpenMP) against the numpy operators of dl3_oracle.py, through the same graph:
+    float64 logits, loss, every gradient and the BatchNorm moving statistics to 1e-10; the float32 build within fp32."""
+    from oracle import c_backend as CB
+    shape, classes, B = (48, 40, 3), 3, 2
+    kw = dict(backbone=backbone, input_shape=shape, classes=classes, OS=OS, head=head)
+    params = O.init_params(O.param_shapes(backbone, classes, head=head), seed=3, dtype=np.float64)
+    rng = np.random.default_rng(1)
+    x = rng.integers(0, 256, (B,) + shape).astype(np.float64)
+    labels = rng.integers(0, classes + 1, (B, shape[0] * shape[1])).astype(np.float64)
+    w = (labels < classes) * rng.uniform(0.5, 2.0, labels.shape)
+    l0, g0, lg0, n0 = O.train_grads(params, x, labels, w, **kw)
+    with CB.installed(threads=4):
+        l1, g1, lg1, n1 = O.train_grads(params, x, labels, w, **kw)
+        assert O.conv2d is CB.conv2d
+    assert O.conv2d is not CB.conv2d  # restored
+    assert abs(l0 - l1) < 1e-12 * abs(l0) and np.abs(lg0 - lg1).max() < 1e-10 * np.abs(lg0).max()
+    for k, g in g0.items():
+        if g is not None and np.abs(g).max() > 1e-12:
+            assert np.linalg.norm(g - g1[k]) < 1e-9 * np.linalg.norm(g), k
+    for k, st in n0.new_stats.items():
+        assert np.allclose(st["var"], n1.new_stats[k]["var"], rtol=1e-10) and np.allclose(st["mean"], n1.new_stats[k]["mean"], rtol=1e-9, atol=1e-12)
+    p32 = {k: v.astype(np.float32) for k, v in params.items()}
+    with CB.installed(threads=4):
+        l2, g2, lg2, _ = O.train_grads(p32, x.astype(np.float32), labels.astype(np.float32), w.astype(np.float32), **kw)
+    assert lg2.dtype == np.float32 and abs(l2 - l0) < 1e-4 * abs(l0) and np.abs(lg2 - lg0).max() < 1e-3 * np.abs(lg0).max()
