@@ -368,6 +368,14 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
   // EPI: 0 generic epilogue only, 1 forward (see above).  A straight-line MASKED bwd-data variant was measured too:
   // on top of 80 accumulators its operand registers push long-lived values into scratch and it came out slower.
   constexpr bool FWD = (EPI == 1);
+  // EPI 2 (bwd-data without residual, TM = 1, TN <= 3): the masked epilogue's operand — the forward input x of the
+  // tile — is requested BEFORE the main loop and consumed after it.  The generic epilogue
+  // fetches them sub-tile by sub-tile after the last MFMA, one exposed HBM round trip each (~4 us per sub-tile; for a
+  // reduction of 96-320 that is as long as the main loop itself, and the in-situ table shows exactly these launches
+  // running at mfma-time + hbm-time).  48 accumulators + 48 operand registers fit two waves per SIMD next to the main
+  // loop's own; 80 + 80 do not (nor 48 + 96 with a residual operand: measured, spills between the loads).
+  constexpr bool PRE = (EPI == 2);
+  static_assert(!PRE || (TM == 1 && WN == 1 && TN <= 3), "prefetched epilogue: narrow single-row-block tiles only");
   // KT = depth of one K-tile: each half-wave walks KT/2 consecutive k (KT/8 float4 loads per lane and tensor)
   constexpr int WM = 4 / WN;
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, KH = KT / 2, NJ = KT / 8;
@@ -376,6 +384,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
   constexpr int KC = DL3_STREAM_KMAX + KT;       // per-k operand-transform coefficients live in LDS
   __shared__ float lds[2 * KT * LDB];
   __shared__ float cf[(TWO ? 3 : 2) * KC];
+  __shared__ float eco[PRE ? 4 * BN : 1];  // prefetched epilogue: per-column scale, shift, mean, invstd (n0 is fixed)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -402,6 +411,15 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
     cf[KC + i] = (in && xform) ? P.kc[k] : 0.f;
     if (TWO) cf[2 * KC + i] = in ? P.kb[k] : 0.f;
   }
+  if constexpr (PRE) {
+    for (int i = tid; i < BN; i += 256) {
+      const int col = min(n0 + i, P.N - 1);
+      eco[i] = P.ep_scale ? P.ep_scale[col] : 1.f;
+      eco[BN + i] = P.ep_scale ? P.ep_shift[col] : 0.f;
+      eco[2 * BN + i] = P.stat_mode == 2 ? P.ep_mean[col] : 0.f;
+      eco[3 * BN + i] = P.stat_mode == 2 ? P.ep_invstd[col] : 0.f;
+    }
+  }
   __syncthreads();
 
   for (int mt = by; mt < P.mtiles; mt += gridDim.y) {
@@ -413,6 +431,20 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
       for (int j = 0; j < TN; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const bool full = (m0 + BM <= P.M) && (n0 + BN <= P.N);
+    float pxv[PRE ? TN : 1][16];
+    if constexpr (PRE) {
+      if (full) {
+        const size_t urow = (size_t)(m0 + __builtin_amdgcn_readfirstlane(wm) * 32);
+        const float *px = P.ep_x + urow * P.ld_epx + nw0;
+        const unsigned lo_x = (unsigned)(4 * lhi * P.ld_epx + l31);
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) pxv[j][r] = (px + (size_t)((r & 3) + 8 * (r >> 2)) * P.ld_epx + j * 32)[lo_x];
+      }
+    }
 
     const float *arow[TM], *arow2[TM];
 #pragma unroll
@@ -514,11 +546,31 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
     }
 
     // ---------------- epilogue (same C/D layout as the LDS-staged kernel)
-    const bool full = (m0 + BM <= P.M) && (n0 + BN <= P.N);
     if (FWD && full) {
       if (!P.ep_add) stream_epilogue_full<TM, TN, false, false, false>(P, acc, m0, nw0, wm, l31, lhi, st1, st2);
       else stream_epilogue_full<TM, TN, false, true, false>(P, acc, m0, nw0, wm, l31, lhi, st1, st2);
       continue;
+    }
+    if constexpr (PRE) {
+      if (full) {
+        float *pc = P.c + (size_t)(m0 + __builtin_amdgcn_readfirstlane(wm) * 32) * P.ldc + nw0;
+        const unsigned lo_c = (unsigned)(4 * lhi * P.ldc + l31);
+        const bool mode2 = P.stat_mode == 2;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+          const int cl = j * 32 + l31;
+          const float es = eco[cl], et = eco[BN + cl], mu = eco[2 * BN + cl], is = eco[3 * BN + cl];
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const float xv = pxv[j][r];
+            float v = acc[0][j][r] * dl3_act_mask(es * xv + et, P.ep_act);
+            __builtin_nontemporal_store(v, &(pc + (size_t)((r & 3) + 8 * (r >> 2)) * P.ldc + j * 32)[lo_c]);
+            st1[j] += v;
+            st2[j] += mode2 ? v * ((xv - mu) * is) : v * v;
+          }
+        }
+        continue;
+      }
     }
     // everything else: generic path, every element predicated
 #pragma unroll
@@ -857,6 +909,8 @@ int env_int(const char *name) {
 
 // small: the 32-row configurations may be chosen (they exist for the stream kernel only)
 GemmCfg pick_gemm(int M, int K, int N, bool two, bool small) {
+  const int fb = env_int("DL3_GEMM_BWD_CFG");  // tuning aid: tile configuration of the two-tensor (bwd-data) launches only
+  if (two && fb >= 0 && fb < kNumGemmCfgs && (small || kGemmCfgs[fb].BM != 32)) return kGemmCfgs[fb];
   const int forced = env_int("DL3_GEMM_CFG");  // tuning aid (tools/gemm_tune.py)
   if (forced >= 0 && forced < kNumGemmCfgs && (small || kGemmCfgs[forced].BM != 32)) return kGemmCfgs[forced];
   // measured exception (tools/gemm_tune.py): a forward GEMM with a very short reduction and a wide output
@@ -879,6 +933,17 @@ GemmCfg pick_gemm(int M, int K, int N, bool two, bool small) {
     if (cost < best) { best = cost; bc = c; }
   }
   return bc;
+}
+
+// masked bwd-data launch whose epilogue operand can be prefetched (pw_gemm_stream_kernel EPI 2)
+bool pre_ok(const GemmArgs &A) {
+  return A.ep_x && !A.bias && !A.ep_add && env_int("DL3_GEMM_PRE") != 0;
+}
+// ... and for which the 128x96 prefetching tile beats the cost model's choice: short reductions (the epilogue is as
+// long as the main loop) into a wide output made of whole 96-column tiles, with enough row tiles to fill the chip
+bool pre_wanted(const GemmArgs &A) {
+  const int kmax = env_int("DL3_GEMM_PRE_KMAX");
+  return A.K <= (kmax > 0 ? kmax : 320) && A.N % 96 == 0 && A.N >= 2 * A.K && A.M >= 65536;
 }
 
 int gemm_grid_y(int M, int N, const GemmCfg &c) {
@@ -914,7 +979,8 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   const bool bvec = (A.N % 4 == 0) && (A.ldb % 4 == 0) && al16(A.b);
   const bool vec = avec && bvec;
   const bool stream = vec && env_int("DL3_GEMM_IMPL") != 0 && A.K <= DL3_STREAM_KMAX;
-  const GemmCfg c = pick_gemm(A.M, A.K, A.N, two, stream);
+  GemmCfg c = pick_gemm(A.M, A.K, A.N, two, stream);
+  if (stream && pre_ok(A) && pre_wanted(A)) c = kGemmCfgs[4];
   A.mtiles = dl3_cdiv(A.M, c.BM);
   dim3 grid(dl3_cdiv(A.N, c.BN), gemm_grid_y(A.M, A.N, c));
   // stream-A kernel: 10-25 % faster than the LDS-staged kernel on every layer shape, forward and bwd-data
@@ -929,6 +995,11 @@ int run_gemm(GemmArgs A, hipStream_t st) {
     else if (fwd) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, DL3_STREAM_KT_FWD, 1, WN_>), grid, blk, 0, st, A); \
     else hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, 16, 0, WN_>), grid, blk, 0, st, A);              \
   } while (0)
+    if (c.id == 4 && pre_ok(A)) {
+      if (two) hipLaunchKernelGGL((pw_gemm_stream_kernel<1, 3, true, 16, 2, 1>), grid, blk, 0, st, A);
+      else hipLaunchKernelGGL((pw_gemm_stream_kernel<1, 3, false, 16, 2, 1>), grid, blk, 0, st, A);
+      return (int)grid.y;
+    }
     switch (c.id) {
       case 0: DL3_STREAM(1, 4, 1); break;
       case 1: DL3_STREAM(2, 2, 1); break;
@@ -1020,6 +1091,10 @@ extern "C" int dl3_pwconv_partials(int M, int K, int N) {
       const int q = gemm_grid_y(M, N, pick_gemm(M, K, N, two != 0, small != 0));
       p = q > p ? q : p;
     }
+  if (N % 96 == 0) {  // the prefetching bwd-data variant overrides the choice with the 128x96 tile (run_gemm)
+    const int q = gemm_grid_y(M, N, kGemmCfgs[4]);
+    p = q > p ? q : p;
+  }
   return p;
 }
 

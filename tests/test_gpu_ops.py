@@ -242,6 +242,12 @@ BD_CASES = [
     (200, 2048, 256, 1, True, 0, True),      # aspp pointwise: dX is 2048 wide
     (384, 304, 256, 1, True, 0, True),
     (384, 256, 48, 1, True, 0, False),
+    # short reduction into a wide output, >= 512 row tiles: the variant that prefetches the mask operand before the
+    # main loop (128x96 tiles; the ragged last row tile takes the generic epilogue)
+    (65536 + 200, 960, 160, 2, True, 0, True),
+    (65536, 576, 96, 2, False, 0, True),
+    (66000, 192, 32, 1, True, 0, False),
+    (65536, 384, 64, None, True, 0, True),
 ]
 
 
