@@ -77,7 +77,7 @@ if __name__ == "__main__":
     if args.worker:
         worker(args.batch, args.worker)
         sys.exit(0)
-    for kind, var, ncfg in (("fwd", "DL3_GEMM_CFG", 5), ("dgrad", "DL3_GEMM_CFG", 5), ("wgrad", "DL3_WGRAD_CFG", 10)):
+    for kind, var, ncfg in (("fwd", "DL3_GEMM_CFG", 7), ("dgrad", "DL3_GEMM_CFG", 7), ("wgrad", "DL3_WGRAD_CFG", 10)):
         res = {}
         for cfg in [-1] + list(range(ncfg)):
             env = dict(os.environ)
