@@ -58,9 +58,22 @@ class DataParallel:
             idbuf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
         dist.broadcast(idbuf, src=0)  # control plane: 128 bytes over host TCP
         handle = ctypes.c_void_p()
-        capi.check(L.dl3_comm_init(ctypes.byref(handle), bytes(idbuf.numpy().tobytes()), self.rank, self.world),
-                   "dl3_comm_init")
-        self.comm = handle
+        rc = L.dl3_comm_init(ctypes.byref(handle), bytes(idbuf.numpy().tobytes()), self.rank, self.world)
+        # every rank must end up on the same data plane: agree on the outcome over the control plane
+        ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            self.comm = handle
+            return
+        if rc == 0:
+            L.dl3_comm_destroy(handle)
+        if os.environ.get("DL3_DIST_STRICT", "0") == "1":
+            capi.check(rc or 1, "dl3_comm_init (on some rank)")
+        import warnings
+        warnings.warn("dl3_comm_init failed on at least one rank (%s): gradients will be exchanged over gloo through "
+                      "host memory, NOT over RCCL/xGMI — expect the exchange to dominate small steps"
+                      % (L.dl3_last_error().decode() if rc else "this rank was fine"))
+        self.backend = "gloo"
 
     def shard(self, n_global):
         """contiguous image shard [lo, hi) of this rank (global batch = B * world)"""
