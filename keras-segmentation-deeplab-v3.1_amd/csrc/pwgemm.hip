@@ -958,8 +958,14 @@ int gemm_grid_y(int M, int N, const GemmCfg &c) {
   int py = (pytot > 0 ? pytot : dflt) / ntn;
   if (py < 32) py = 32;
   if (mtiles <= py) return mtiles;
-  const int iters = dl3_cdiv(mtiles, py);  // every workgroup loops over the same number of row tiles
-  return dl3_cdiv(mtiles, iters);
+  const int iters = dl3_cdiv(mtiles, py);  // every workgroup loops over the same number of row tiles ...
+  const int even = dl3_cdiv(mtiles, iters);
+  // ... unless that leaves more than a tenth of the chip's 512 slots empty (512 row tiles x 5 column tiles: 86 x 5 = 430
+  // workgroups of 6 tiles, most CUs carry 12 tile-times; 102 x 5 = 510 workgroups of 5 or 6 carry 10-11: the Xception
+  // 736 -> 736 GEMM at 65536 rows 0.810 -> 0.733 ms forward, 0.924 -> 0.869 bwd-data).  DL3_GEMM_RAGGED=0/1 forces.
+  const int ragged = env_int("DL3_GEMM_RAGGED");
+  if (ragged == 1 || (ragged != 0 && (long)even * ntn * 10 < 512L * 9)) return py;
+  return even;
 }
 
 template <int TM, int TN, int WM, int WN>

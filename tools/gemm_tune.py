@@ -18,7 +18,7 @@ SHAPES = [  # (pixels per image, K, N) of every distinct 1x1 conv of MobileNetV2
 
 
 XCEPTION_SHAPES = [  # Xception OS=8 at 512x512
-    (4096, 728, 728), (4096, 728, 1024), (4096, 1024, 1024), (4096, 1024, 1536), (4096, 1536, 1536), (4096, 1536, 2048),
+    (4096, 736, 736), (4096, 736, 1024), (4096, 1024, 1024), (4096, 1024, 1536), (4096, 1536, 1536), (4096, 1536, 2048),
     (4096, 2048, 256), (4096, 1280, 256), (4096, 256, 728), (16384, 256, 256), (16384, 304, 256), (16384, 128, 256),
     (65536, 128, 128), (65536, 64, 128), (65536, 288, 64),
 ]
