@@ -61,6 +61,8 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="eager launches (profiling aid; never a headline number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-split-leg", action="store_true",
+                    help="skip the second timed loop with DL3_GEMM_MATH=split (reported beside, never as, the headline)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = sweep thread counts up to os.cpu_count()")
     ap.add_argument("--plan-json", default=None, help="write the per-launch in-situ table (op, shape, ms, FLOPs, bytes)")
     return ap.parse_args()
@@ -299,6 +301,42 @@ def cpu_a_leg(args, avail):
                 thread_sweep_img_s={str(k): round(v, 3) for k, v in sweep.items()})
 
 
+def split_math_leg(args):
+    """The same K steps with the 1x1-conv forward / bwd-data GEMMs in split math (DL3_GEMM_MATH=split: every fp32 operand
+    cut EXACTLY into three bf16 pieces, six of the nine piece products on v_mfma_f32_32x32x16_bf16, fp32 accumulate;
+    csrc/pwgemm.hip split3).  Reported BESIDE the headline, which stays on the f32 MFMA."""
+    import gc
+    from dl3_amd import graph as G
+    gc.collect()
+    G.clear_session()
+    torch.cuda.empty_cache()
+    os.environ["DL3_GEMM_MATH"] = "split"
+    try:
+        model, eng = build_engine(args)
+        for _ in range(max(args.warmup, 2)):
+            eng.fwd_bwd()
+            eng.adam(None, 1.0)
+        torch.cuda.synchronize()
+        if not args.no_graph and eng.graph is None:
+            return {"error": "hipGraph capture failed"}
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.fwd_bwd()
+            eng.adam(None, 1.0)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        loss = float(eng.loss[0].item())
+    finally:
+        os.environ["DL3_GEMM_MATH"] = "f32"
+    log("split-math leg: %.1f ms/step" % (1e3 * dt / args.steps))
+    return {"value": args.batch * args.steps / dt, "unit": "img/s", "ms_per_step": 1e3 * dt / args.steps, "final_loss": loss,
+            "what": "same workload, same K steps; forward and bwd-data 1x1-conv GEMMs computed as 6 bf16 MFMAs on exact "
+                    "3-way bf16 splits of the fp32 operands (fp32 accumulate); weight-gradient GEMMs and everything else "
+                    "unchanged",
+            "accuracy": "max |err| / sum|a||b| against float64 at M=65536 K=960 N=160: split 3.3e-7, v_mfma_f32 3.7e-7 "
+                        "(tests/test_gpu_ops.py::test_split_math_error); all parity tests pass unchanged in this mode"}
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -362,6 +400,7 @@ def main():
                        "global_batch": args.batch * dp.world, "per_gpu_batch": args.batch,
                        "parallelism": "dp%d" % dp.world, "hipgraph": eng.graph is not None, "final_loss": loss,
                        "launches_per_step": len(eng.ops_fwd) + len(eng.ops_bwd) + 1,
+                       "matrix_math": "split" if os.environ.get("DL3_GEMM_MATH", "f32").startswith("s") else "f32",
                        "gradient_exchange": ("dl3_comm_allreduce_f32 (RCCL), %.2f MB" % (eng.n_param * 4 / 1e6))
                        if dp.comm is not None else ("gloo (host staged)" if dp.world > 1 else None)},
         }
@@ -373,6 +412,10 @@ def main():
                 with open(args.plan_json, "w") as f:
                     json.dump({"batch": args.batch, "backbone": args.backbone, "head": args.head, "os": args.os,
                                "size": args.size, "rows": rows}, f, indent=0)
+        if dp.world == 1 and not args.no_split_leg and rec["config"]["matrix_math"] == "f32":
+            del step
+            eng = model = None
+            rec["split_math"] = split_math_leg(args)
         if dp.world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline_leg(args)
             log("cpu baseline done")

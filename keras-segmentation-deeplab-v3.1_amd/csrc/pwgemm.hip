@@ -35,6 +35,7 @@ struct GemmArgs {
   const float *ep_mean, *ep_invstd;
   float *part;
   int mtiles;
+  const void *bp; int nsub;  // split math: weights pre-split into 3 bf16 planes in MFMA fragment order (pack_b_kernel)
 };
 
 constexpr int BK = 16;
@@ -56,6 +57,7 @@ constexpr int BK = 16;
 #ifndef DL3_WGRAD_MS
 #define DL3_WGRAD_MS 16
 #endif
+
 
 // Main loop structure (both kernels): global -> registers -> LDS, double-buffered LDS (ONE barrier per
 // K-tile), MFMA operand fragments prefetched one k-step ahead.  Out-of-range rows / columns are handled by
@@ -306,6 +308,61 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmArgs P) {
   }
 }
 
+// ---- split math (DL3_GEMM_MATH=split): fp32 GEMM on the bf16 matrix pipe ----------------------------------
+// v_mfma_f32_32x32x2_f32 runs at the f32 VECTOR rate, 1/16 of v_mfma_f32_32x32x16_bf16.  An fp32 number is EXACTLY the
+// sum of three bf16 numbers (its 24-bit significand cut into 8 + 8 + 8 bits by truncation: h = top 16 bits of x,
+// m = top 16 bits of x - h, l = x - h - m, every subtraction exact), a bf16 x bf16 product is exact in fp32, and the MFMA
+// accumulates in fp32.  a.b = sum over the nine piece products; the six of order >= 2^-16 are computed, the three
+// dropped ones (m.l, l.m, l.l) are <= 2^-23 |a||b| — the size of ONE fp32 rounding, which the f32 MFMA commits per
+// product anyway.  Six bf16 MFMAs of K=16 (6 x 32 cycles) replace eight f32 MFMAs of K=2 (8 x 64): 2.67x the matrix rate
+// at fp32-roundoff-class accuracy (tests/test_gpu_ops.py::test_split_math_error measures both against float64).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// 8 consecutive-k fp32 values of one lane -> the three bf16x8 MFMA operands
+__device__ __forceinline__ void split3(const f32x4 &v0, const f32x4 &v1, u32x4 &h, u32x4 &m, u32x4 &l) {
+  unsigned hb[8], mb[8], lb[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const float x = e < 4 ? v0[e] : v1[e - 4];
+    const unsigned xh = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(xh);
+    const unsigned xm = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(xm);
+    hb[e] = xh; mb[e] = xm; lb[e] = __float_as_uint(r2);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {  // word q = [element 2q+1 : element 2q], upper halves of both
+    h[q] = __builtin_amdgcn_perm(hb[2 * q + 1], hb[2 * q], 0x07060302u);
+    m[q] = __builtin_amdgcn_perm(mb[2 * q + 1], mb[2 * q], 0x07060302u);
+    l[q] = __builtin_amdgcn_perm(lb[2 * q + 1], lb[2 * q], 0x07060302u);
+  }
+}
+
+// W[K][N] (row stride ldb) -> out[K-tile of 32][k-step s][plane][sub-tile][lane] (16 B each): lane l of sub-tile j holds
+// column 32 j + (l & 31) and k = 32 kt + 16 (l >> 5) + 8 s + 0..7 — the B fragment of v_mfma_f32_32x32x16_bf16 under the
+// stream kernel's k map.  Zero beyond K / N.
+__global__ __launch_bounds__(256) void pack_b_kernel(const float *__restrict__ b, int ldb, int K, int N,
+                                                     u32x4 *__restrict__ out, int ktiles, int nsub) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= ktiles * 2 * nsub * 64) return;
+  const int lane = t & 63, j = (t >> 6) % nsub, ks = ((t >> 6) / nsub) & 1, kt = (t >> 6) / nsub / 2;
+  const int col = j * 32 + (lane & 31), k0 = kt * 32 + 16 * (lane >> 5) + 8 * ks;
+  f32x4 v0, v1;
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const int k = k0 + e;
+    const float x = (k < K && col < N) ? b[(size_t)k * ldb + col] : 0.f;
+    if (e < 4) v0[e] = x; else v1[e - 4] = x;
+  }
+  u32x4 h, m, l;
+  split3(v0, v1, h, m, l);
+  const size_t base = ((size_t)(kt * 2 + ks) * 3 * nsub + j) * 64 + lane;
+  out[base] = h;
+  out[base + (size_t)nsub * 64] = m;
+  out[base + (size_t)2 * nsub * 64] = l;
+}
+
 // Epilogue of the stream kernel for a tile that lies inside the matrix, specialised at compile time on what it has to
 // do.  (The generic version below tests its run-time flags and the bounds on every element; its exec-mask branches and
 // waits cost ~28k cycles per 128x160 tile — two thirds of the main loop of a K=160 GEMM.)  EPX: activation mask from
@@ -363,8 +420,12 @@ __device__ __forceinline__ void stream_epilogue_full(const GemmArgs &P, const f3
 // GEMMs; their interior tiles take the straight-line epilogue and the masked code is not compiled in at all.
 // WN: waves side by side along N (4/WN stacked along M).  WN = 4 gives 32-row tiles for small M (batch 1-4: a
 // 128-row tile leaves most CUs idle and every workgroup a long serial K loop).
-template <int TM, int TN, bool TWO, int KT, int EPI, int WN = 1>
+template <int TM, int TN, bool TWO, int KT, int EPI, int WN = 1, int MATH = 0>
 __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
+  // MATH 1: split math (see split3) — the A registers are split after the operand transform, the weight tile comes
+  // pre-split from pack_b_kernel, six bf16 MFMAs per 16-deep K-tile and 32x32 sub-tile
+  constexpr bool SPL = (MATH == 1);
+  static_assert(!SPL || KT == 32, "split math: two bf16 MFMA k-steps per K-tile");
   // EPI: 0 generic epilogue only, 1 forward (see above).  A straight-line MASKED bwd-data variant was measured too:
   // on top of 80 accumulators its operand registers push long-lived values into scratch and it came out slower.
   constexpr bool FWD = (EPI == 1);
@@ -380,10 +441,16 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
   constexpr int WM = 4 / WN;
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, KH = KT / 2, NJ = KT / 8;
   constexpr int LDB = BN;
-  constexpr int NB = (KT * BN / 4 + 255) / 256;  // float4 B loads per thread per K-tile
-  constexpr int KC = DL3_STREAM_KMAX + KT;       // per-k operand-transform coefficients live in LDS
-  __shared__ float lds[2 * KT * LDB];
-  __shared__ float cf[(TWO ? 3 : 2) * KC];
+  constexpr int NS = KT / 16;                    // split math: bf16 MFMA k-steps per K-tile
+  constexpr int BQ = SPL ? NS * 3 * (BN / 32) * 64 : KT * BN / 4;  // 16-byte pieces of one K-tile's weight tile
+  constexpr int NB = SPL ? 1 : (KT * BN / 4 + 255) / 256;  // float4 B loads per thread per K-tile (f32 path)
+  constexpr int KCS = DL3_STREAM_KMAX + KT;      // per-k operand-transform coefficients live in LDS
+  __shared__ float lds[2 * BQ * 4];
+  // split math: the coefficient vectors are sized by the launch (dynamic LDS, 4 * (2 or 3) * ktiles * KT bytes) so that
+  // two workgroups of the 160-wide tile still fit a CU next to the 60 KB of split weight tiles
+  __shared__ float cf_static[SPL ? 1 : (TWO ? 3 : 2) * KCS];
+  extern __shared__ float cf_dyn[];
+  float *const cf = SPL ? cf_dyn : cf_static;
   __shared__ float eco[PRE ? 4 * BN : 1];  // prefetched epilogue: per-column scale, shift, mean, invstd (n0 is fixed)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -394,6 +461,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
   const int bx = lid % gridDim.x, by = lid / gridDim.x;
   const int n0 = bx * BN;
   const int ktiles = (P.K + KT - 1) / KT;
+  const int KC = SPL ? ktiles * KT : KCS;
   const bool xform = (P.ka != nullptr);
   const int wm = wave / WN, wn = wave % WN;
   const int nw0 = n0 + wn * TN * 32;  // first column of this wave's sub-tile
@@ -505,6 +573,79 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
         for (int j = 0; j < NJ; j++) ac[i][j] = an[i][j];
     };
 
+    if constexpr (SPL) {
+      // K-tile kt: [weights of kt+1 -> LDS by DMA] [MFMAs of k-step 0] [A of kt+1: wait, transform, split; request A of
+      // kt+2] [MFMAs of k-step 1] [barrier].  The A loads have a whole K-tile of MFMAs (x2 waves per SIMD) to arrive.
+      // Slot (k-step s, half h, element e) of a K-tile holds k = 16 h + 8 s + e — each lane's 16 k are consecutive in
+      // memory; pack_b_kernel lays the weights out with the same map.
+      u32x4 ch[NS][TM], cm[NS][TM], cl[NS][TM], nh[NS][TM], nm[NS][TM], nl[NS][TM];
+      auto dma_B = [&](int kt, int buf) {
+        constexpr int PIECES = NS * 3 * (BN / 32);  // 1 KB each: 64 lanes x 16 B, lane-linear in LDS
+        const char *src0 = (const char *)P.bp + (size_t)lane * 16;
+        for (int pc = __builtin_amdgcn_readfirstlane(wave); pc < PIECES; pc += 4) {
+          const int sub = pc % (BN / 32), pl = (pc / (BN / 32)) % 3, ks = pc / (3 * (BN / 32));
+          const int gsub = min(n0 / 32 + sub, P.nsub - 1);
+          const size_t off = (((size_t)(kt * NS + ks) * 3 + pl) * P.nsub + gsub) * 1024;  // wave-uniform
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src0 + off),
+                                           (__attribute__((address_space(3))) void *)(lds + (buf * BQ + pc * 64) * 4), 16, 0, 0);
+        }
+      };
+      auto split_next = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < NS; ks++)
+#pragma unroll
+          for (int i = 0; i < TM; i++) split3(an[i][2 * ks], an[i][2 * ks + 1], nh[ks][i], nm[ks][i], nl[ks][i]);
+      };
+      auto take_next = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < NS; ks++)
+#pragma unroll
+          for (int i = 0; i < TM; i++) { ch[ks][i] = nh[ks][i]; cm[ks][i] = nm[ks][i]; cl[ks][i] = nl[ks][i]; }
+      };
+      auto mfma_step = [&](const float *Bs, int ks) {
+        const u32x4 *Bq = (const u32x4 *)Bs + (ks * 3 * (BN / 32) + wn * TN) * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, Bq[j * 64]);
+          const bf16x8 bm = __builtin_bit_cast(bf16x8, Bq[((BN / 32) + j) * 64]);
+          const bf16x8 bl = __builtin_bit_cast(bf16x8, Bq[(2 * (BN / 32) + j) * 64]);
+#pragma unroll
+          for (int i = 0; i < TM; i++) {
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, ch[ks][i]), am = __builtin_bit_cast(bf16x8, cm[ks][i]),
+                         al = __builtin_bit_cast(bf16x8, cl[ks][i]);
+            f32x16 c = acc[i][j];  // small terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+          }
+        }
+      };
+      load_A(0);
+      __syncthreads();  // the previous row tile is done with the LDS
+      dma_B(0, 0);
+      transform(0);
+      split_next();
+      take_next();
+      if (ktiles > 1) load_A(1);
+      __syncthreads();
+      for (int kt = 0; kt < ktiles; ++kt) {
+        const float *Bs = lds + (kt & 1) * BQ * 4;
+        const bool more = kt + 1 < ktiles;
+        if (more) dma_B(kt + 1, (kt + 1) & 1);
+        mfma_step(Bs, 0);
+        if (more) {
+          transform(kt + 1);
+          split_next();
+          if (kt + 2 < ktiles) load_A(kt + 2);
+        }
+        mfma_step(Bs, 1);
+        __syncthreads();
+        if (more) take_next();
+      }
+    } else {
     load_A(0);
     load_B(0);
     __syncthreads();  // the previous row tile is done with the LDS
@@ -543,6 +684,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
       }
       if (more) adopt();
       __syncthreads();
+    }
+
     }
 
     // ---------------- epilogue (same C/D layout as the LDS-staged kernel)
@@ -968,6 +1111,29 @@ int gemm_grid_y(int M, int N, const GemmCfg &c) {
   return even;
 }
 
+// split math: device scratch for the packed weights of the launch in flight.  Launches on one stream are ordered, so one
+// buffer serves them all; it only ever grows, and a superseded buffer stays allocated (a captured hipGraph may still
+// point at it).  Growing is impossible while the stream is capturing: the engine's first step runs eagerly.
+void *pack_scratch(size_t bytes, hipStream_t st) {
+  static void *buf = nullptr;
+  static size_t cap = 0;
+  if (bytes <= cap) return buf;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cs);
+  if (cs != hipStreamCaptureStatusNone) return nullptr;
+  size_t want = bytes < (32u << 20) ? (32u << 20) : bytes * 2;
+  void *nb = nullptr;
+  if (hipMalloc(&nb, want) != hipSuccess) return nullptr;
+  buf = nb;
+  cap = want;
+  return buf;
+}
+
+bool split_math() {
+  const char *e = getenv("DL3_GEMM_MATH");  // "split": fp32 as 3 x bf16 on the bf16 matrix pipe; default: f32 MFMA
+  return e && e[0] == 's';
+}
+
 template <int TM, int TN, int WM, int WN>
 void launch_gemm(const GemmArgs &A, dim3 grid, hipStream_t st, bool vec) {
   // two instantiations only: 16-byte loads on both operands, or scalar loads on both (tiny GEMMs
@@ -995,6 +1161,37 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   if (stream) {
     dim3 blk(256);
     const bool fwd = !two && !A.ep_x && A.stat_mode != 2 && !(A.ep_add && A.add_div > 1);
+    if (split_math() && c.id != 5 && c.id != 6) {  // (the 32-row small-M tiles keep the f32 MFMA: their split weight tiles exceed the LDS)
+      const unsigned dyn = 4u * (two ? 3 : 2) * (unsigned)dl3_cdiv(A.K, 32) * 32;
+      const int ktiles = dl3_cdiv(A.K, 32);
+      A.nsub = dl3_cdiv(A.N, 32);
+      const size_t pieces = (size_t)ktiles * 2 * 3 * A.nsub * 64;
+      void *ws = pack_scratch(pieces * 16, st);
+      if (!ws) return -1;
+      A.bp = ws;
+      hipLaunchKernelGGL(pack_b_kernel, dim3(dl3_cdiv(ktiles * 2 * A.nsub * 64, 256)), blk, 0, st, A.b, A.ldb, A.K, A.N,
+                         (u32x4 *)ws, ktiles, A.nsub);
+#define DL3_SPLIT(TM_, TN_, WN_)                                                                                     \
+  do {                                                                                                               \
+    if (two) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, true, 32, 0, WN_, 1>), grid, blk, dyn, st, A);        \
+    else if (fwd) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, 32, 1, WN_, 1>), grid, blk, dyn, st, A);  \
+    else hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, 32, 0, WN_, 1>), grid, blk, dyn, st, A);           \
+  } while (0)
+      if (c.id == 4 && pre_ok(A)) {
+        if (two) hipLaunchKernelGGL((pw_gemm_stream_kernel<1, 3, true, 32, 2, 1, 1>), grid, blk, dyn, st, A);
+        else hipLaunchKernelGGL((pw_gemm_stream_kernel<1, 3, false, 32, 2, 1, 1>), grid, blk, dyn, st, A);
+        return (int)grid.y;
+      }
+      switch (c.id) {
+        case 0: DL3_SPLIT(1, 4, 1); break;
+        case 1: DL3_SPLIT(2, 2, 1); break;
+        case 2: DL3_SPLIT(2, 1, 1); break;
+        case 3: DL3_SPLIT(1, 5, 1); break;
+        default: DL3_SPLIT(1, 3, 1); break;
+      }
+#undef DL3_SPLIT
+      return (int)grid.y;
+    }
 #define DL3_STREAM(TM_, TN_, WN_)                                                                                    \
   do {                                                                                                               \
     if (two) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, true, 16, 0, WN_>), grid, blk, 0, st, A);           \
@@ -1134,6 +1331,7 @@ extern "C" int dl3_pwconv_fwd(const float *x, int ldx, const float *in_scale, co
   A.part = stat_partial;
   hipStream_t st = (hipStream_t)stream;
   const int written = run_gemm(A, st);
+  DL3_CHECK_ARG(written >= 0, "pwconv_fwd: split-math weight scratch unavailable (first launch inside a stream capture?)");
   if (stat_partial) pad_partials(stat_partial, M, K, N, written, st);
   DL3_LAUNCH_CHECK("pwconv_fwd");
   return DL3_OK;
@@ -1168,6 +1366,7 @@ extern "C" int dl3_pwconv_bwd_data(const float *g, int ldg, const float *yraw, i
   A.part = dstat_partial;
   hipStream_t st = (hipStream_t)stream;
   const int written = run_gemm(A, st);
+  DL3_CHECK_ARG(written >= 0, "pwconv_bwd_data: split-math weight scratch unavailable (first launch inside a stream capture?)");
   if (dstat_partial) pad_partials(dstat_partial, M, N, K, written, st);
   DL3_LAUNCH_CHECK("pwconv_bwd_data");
   return DL3_OK;

@@ -143,6 +143,14 @@ def test_cfg2_cfg3_mnv2_512_train_step(head):
     _train_parity("mobilenetv2", (512, 512, 3), head, 16, 2, second_oracle=(head == "deeplab"))
 
 
+def test_cfg2_mnv2_512_train_step_split_math(monkeypatch):
+    """the same full-size parity bars with the forward / bwd-data GEMMs in split math (DL3_GEMM_MATH=split: exact 3-way
+    bf16 split of the fp32 operands on the bf16 matrix pipe, csrc/pwgemm.hip split3); B=4: the layers with >= 512 row
+    tiles pick the 128-row tile configurations — the ones with a split instantiation"""
+    monkeypatch.setenv("DL3_GEMM_MATH", "split")
+    _train_parity("mobilenetv2", (512, 512, 3), "deeplab", 16, 4)
+
+
 def test_cfg4_xception_os8_512_forward():
     """BASELINE.json configs[3]: Xception OS=8 at 512x512x21, single-image forward (inference BN statistics)."""
     import dl3_amd  # noqa: F401

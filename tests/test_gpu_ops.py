@@ -227,6 +227,43 @@ def test_pwconv_every_tile_configuration(L, cfg, monkeypatch):
     test_pwconv_bwd_data(L, (256, 320, 256, None, True, 2, True))
 
 
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 6])
+def test_pwconv_split_math(L, cfg, monkeypatch):
+    """DL3_GEMM_MATH=split: fp32 operands cut exactly into three bf16 pieces, six of the nine piece products on
+    v_mfma_f32_32x32x16_bf16 (csrc/pwgemm.hip split3) — same cases, same tolerances as the f32 MFMA path"""
+    monkeypatch.setenv("DL3_GEMM_MATH", "split")
+    if cfg >= 0:
+        monkeypatch.setenv("DL3_GEMM_CFG", str(cfg))
+    test_pwconv_fwd(L, (1000, 160, 960, 0, 0, False, 2))
+    test_pwconv_fwd(L, (96, 64, 384, 64, 0, True, None))
+    test_pwconv_fwd(L, (300, 24, 144, 0, 0, False, 2))
+    test_pwconv_bwd_data(L, (520, 160, 960, 2, True, 1, True))
+    test_pwconv_bwd_data(L, (256, 320, 256, None, True, 2, True))
+    test_pwconv_bwd_data(L, (300, 256, 21, None, False, 0, False))
+    if cfg < 0:
+        test_pwconv_bwd_data(L, (65536 + 200, 960, 160, 2, True, 0, True))
+        test_pwconv_bwd_data(L, (520, 728, 728, 1, True, 1, True))
+
+
+def test_split_math_error(L, monkeypatch):
+    """error of the split-math GEMM against float64, next to the f32 MFMA's: both must be fp32-roundoff class"""
+    M, K, N = 65536, 960, 160   # enough row tiles for the 128-row configurations (the 32-row ones keep the f32 MFMA)
+    rng = np.random.default_rng(11)
+    x = rng.normal(0, 1, (M, K)).astype(np.float32)
+    w = rng.normal(0, 1, (K, N)).astype(np.float32)
+    ref = x.astype(np.float64) @ w.astype(np.float64)
+    scale = np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64)   # sum_k |a||b| per output element
+    errs = {}
+    for mode in ("f32", "split"):
+        monkeypatch.setenv("DL3_GEMM_MATH", mode)
+        y = empty(M, N)
+        call("dl3_pwconv_fwd", ptr(dev(x)), K, None, None, 0, ptr(dev(w)), None, ptr(y), N, M, K, N, None)
+        errs[mode] = float((np.abs(host(y) - ref) / scale).max())
+    print("max |err| / sum|a||b|: f32 MFMA %.3g, split (3 x bf16) %.3g" % (errs["f32"], errs["split"]))
+    assert errs["f32"] < 6e-7 and errs["split"] < 6e-7
+    assert errs["split"] < 3 * errs["f32"]
+
+
 BD_CASES = [
     # M, K, N, act, two-tensor, add mode (0 none, 1 tensor, 2 broadcast), stats
     (256, 16, 96, 2, True, 1, True),
