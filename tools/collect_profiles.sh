@@ -14,9 +14,9 @@ REPO=$(pwd)
 export TMPDIR=/tmp
 mkdir -p $REPO/gpurun_out
 cd /tmp
-timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_${TAG}_bench -o bench -- python $REPO/bench.py --batch $B --no-cpu-baseline --steps 10 --warmup 3 --plan-json $REPO/gpurun_out/prof_${TAG}_plan.json $EXTRA > $REPO/gpurun_out/prof_${TAG}_bench.log 2>&1
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_${TAG}_bench -o bench -- python $REPO/bench.py --batch $B --no-cpu-baseline --no-split-leg --steps 10 --warmup 3 --plan-json $REPO/gpurun_out/prof_${TAG}_plan.json $EXTRA > $REPO/gpurun_out/prof_${TAG}_bench.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $REPO/gpurun_out/prof_${TAG}_pmc_$c -o pmc -- python $REPO/bench.py --batch $B --no-cpu-baseline --no-roofline --no-graph --steps 3 --warmup 2 $EXTRA > $REPO/gpurun_out/prof_${TAG}_pmc_$c.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $REPO/gpurun_out/prof_${TAG}_pmc_$c -o pmc -- python $REPO/bench.py --batch $B --no-cpu-baseline --no-split-leg --no-roofline --no-graph --steps 3 --warmup 2 $EXTRA > $REPO/gpurun_out/prof_${TAG}_pmc_$c.log 2>&1
 done
 cd $REPO
 find gpurun_out/prof_${TAG}_bench -name "*kernel_stats.csv" | head -2

@@ -9,7 +9,7 @@ cd /tmp
 rocprofv3 --list-avail > $REPO/gpurun_out/list_avail.txt 2>&1
 pass() {
   local tag=$1; shift
-  timeout 400 rocprofv3 --kernel-trace --pmc "$@" GRBM_GUI_ACTIVE --output-format csv -d $REPO/gpurun_out/prof_ta_$tag -o ta -- python $REPO/bench.py --batch $B --no-cpu-baseline --no-roofline --no-graph --steps 2 --warmup 2 > $REPO/gpurun_out/prof_ta_$tag.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --pmc "$@" GRBM_GUI_ACTIVE --output-format csv -d $REPO/gpurun_out/prof_ta_$tag -o ta -- python $REPO/bench.py --batch $B --no-cpu-baseline --no-split-leg --no-roofline --no-graph --steps 2 --warmup 2 > $REPO/gpurun_out/prof_ta_$tag.log 2>&1
   cd $REPO; python tools/pmc_kernels.py gpurun_out/prof_ta_$tag 14; cd /tmp
 }
 pass busy TA_TA_BUSY_sum TA_BUSY_avr
