@@ -302,7 +302,7 @@ def cpu_a_leg(args, avail):
 
 
 def split_math_leg(args):
-    """The same K steps with the 1x1-conv forward / bwd-data GEMMs in split math (DL3_GEMM_MATH=split: every fp32 operand
+    """The same K steps with the 1x1-conv GEMMs in split math (DL3_GEMM_MATH=split: every fp32 operand
     cut EXACTLY into three bf16 pieces, six of the nine piece products on v_mfma_f32_32x32x16_bf16, fp32 accumulate;
     csrc/pwgemm.hip split3).  Reported BESIDE the headline, which stays on the f32 MFMA."""
     import gc
@@ -330,9 +330,8 @@ def split_math_leg(args):
         os.environ["DL3_GEMM_MATH"] = "f32"
     log("split-math leg: %.1f ms/step" % (1e3 * dt / args.steps))
     return {"value": args.batch * args.steps / dt, "unit": "img/s", "ms_per_step": 1e3 * dt / args.steps, "final_loss": loss,
-            "what": "same workload, same K steps; forward and bwd-data 1x1-conv GEMMs computed as 6 bf16 MFMAs on exact "
-                    "3-way bf16 splits of the fp32 operands (fp32 accumulate); weight-gradient GEMMs and everything else "
-                    "unchanged",
+            "what": "same workload, same K steps; the 1x1-conv GEMMs (forward, bwd-data, bwd-weight) computed as 6 bf16 MFMAs "
+                    "on exact 3-way bf16 splits of the fp32 operands (fp32 accumulate); everything else unchanged",
             "accuracy": "max |err| / sum|a||b| against float64 at M=65536 K=960 N=160: split 3.3e-7, v_mfma_f32 3.7e-7 "
                         "(tests/test_gpu_ops.py::test_split_math_error); all parity tests pass unchanged in this mode"}
 

@@ -809,9 +809,14 @@ struct WgradArgs {
   int M, K, N, Mper;
 };
 
-template <int TA, int TB, int WA, int WB, bool VEC>
+template <int TA, int TB, int WA, int WB, bool VEC, bool SPL = false>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
   static_assert(WA * WB == 4, "4 waves per workgroup");
+  // SPL: split math (see split3).  The reduction index is the pixel row, and a bf16 MFMA wants 8 CONSECUTIVE reduction
+  // elements per lane: lane (column c, half h) gathers rows 8h..8h+7 of its column from the fp32 stage in LDS (the same
+  // number of ds_read_b32 per pixel as the f32 MFMA's one-per-k-step), splits them in registers, and one 16-row stage is
+  // one k-step of six bf16 MFMAs per 32x32 sub-tile.
+  static_assert(!SPL || DL3_WGRAD_MS == 16, "split math: a stage is one 16-deep bf16 MFMA k-step");
   constexpr int BKT = 32 * TA * WA, BNT = 32 * TB * WB, MS = DL3_WGRAD_MS;
   constexpr int LDX = BKT + 4, LDD = BNT + 4;
   constexpr int XQ = MS * BKT / 4, DQ = MS * BNT / 4;  // float4s per stage
@@ -953,6 +958,50 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
       const float *Ds = Xs + MS * LDX;
       const bool more = (m0 + MS < mend);
       if (more) load_tiles(m0 + MS);
+      if constexpr (SPL) {
+        u32x4 ah[TA], am[TA], al[TA];
+#pragma unroll
+        for (int i = 0; i < TA; i++) {
+          f32x4 v0, v1;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            v0[e] = Xs[(8 * lhi + e) * LDX + (wa * TA + i) * 32 + l31];
+            v1[e] = Xs[(8 * lhi + 4 + e) * LDX + (wa * TA + i) * 32 + l31];
+          }
+          split3(v0, v1, ah[i], am[i], al[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < TB; j++) {
+          f32x4 v0, v1;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            v0[e] = Ds[(8 * lhi + e) * LDD + (wb * TB + j) * 32 + l31];
+            v1[e] = Ds[(8 * lhi + 4 + e) * LDD + (wb * TB + j) * 32 + l31];
+          }
+          u32x4 bh_, bm_, bl_;
+          split3(v0, v1, bh_, bm_, bl_);
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, bh_), bm = __builtin_bit_cast(bf16x8, bm_),
+                       bl = __builtin_bit_cast(bf16x8, bl_);
+#pragma unroll
+          for (int i = 0; i < TA; i++) {
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[i]), xm = __builtin_bit_cast(bf16x8, am[i]),
+                         xl = __builtin_bit_cast(bf16x8, al[i]);
+            f32x16 c = acc[i][j];  // small terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bm, c, 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, c, 0, 0, 0);
+          }
+        }
+        if (more) {
+          float *Xn = lds + (stage ^ 1) * STAGE;
+          store_tiles(m0 + MS, Xn, Xn + MS * LDX);
+        }
+        __syncthreads();
+        continue;
+      }
       float af[2][TA], bf[2][TB];
 #pragma unroll
       for (int i = 0; i < TA; i++) af[0][i] = Xs[lhi * LDX + (wa * TA + i) * 32 + l31];
@@ -1277,7 +1326,9 @@ int colsum_rows(int M) {
 
 template <int TA, int TB, int WA, int WB>
 void launch_wgrad(const WgradArgs &A, dim3 grid, hipStream_t st, bool vec) {
-  if (vec) hipLaunchKernelGGL((pw_wgrad_kernel<TA, TB, WA, WB, true>), grid, dim3(256), 0, st, A);
+  if (vec && split_math() && env_int("DL3_WGRAD_SPLIT") != 0)
+    hipLaunchKernelGGL((pw_wgrad_kernel<TA, TB, WA, WB, true, true>), grid, dim3(256), 0, st, A);
+  else if (vec) hipLaunchKernelGGL((pw_wgrad_kernel<TA, TB, WA, WB, true>), grid, dim3(256), 0, st, A);
   else hipLaunchKernelGGL((pw_wgrad_kernel<TA, TB, WA, WB, false>), grid, dim3(256), 0, st, A);
 }
 

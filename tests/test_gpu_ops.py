@@ -245,6 +245,16 @@ def test_pwconv_split_math(L, cfg, monkeypatch):
         test_pwconv_bwd_data(L, (520, 728, 728, 1, True, 1, True))
 
 
+@pytest.mark.parametrize("cfg", [-1] + list(range(10)))
+def test_pwconv_bwd_weight_split_math(L, cfg, monkeypatch):
+    """the weight-gradient kernel in split math: every tile configuration, same cases and tolerances as the f32 MFMA"""
+    monkeypatch.setenv("DL3_GEMM_MATH", "split")
+    if cfg >= 0:
+        monkeypatch.setenv("DL3_WGRAD_CFG", str(cfg))
+    for case in BW_CASES[:4] + BW_CASES[5:8]:
+        test_pwconv_bwd_weight(L, case)
+
+
 def test_split_math_error(L, monkeypatch):
     """error of the split-math GEMM against float64, next to the f32 MFMA's: both must be fp32-roundoff class"""
     M, K, N = 65536, 960, 160   # enough row tiles for the 128-row configurations (the 32-row ones keep the f32 MFMA)
