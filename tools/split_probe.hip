@@ -8,6 +8,7 @@
 //   4  + A stream: 4 x 16-byte global loads per lane and K-tile, one K-tile ahead, NO transform / split (bit-cast)
 //   5  + operand transform and split3 (the real VALU work)
 //   6  = 5 with a raw s_barrier behind a COUNTED s_waitcnt vmcnt(4): the A request survives the barrier
+//  10  = 3 with all 15 B fragments of a k-step requested before its first MFMA (60 registers)
 //   8  = 3 but the DMA is never waited for (raw s_barrier)      9  = 3 with half the DMA bytes
 //   7  = 6 re-ordered: [A(kt+1): transform, split] [DMA] [request A(kt+2)] [MFMAs] [vmcnt(4); s_barrier]
 // usage: hipcc -O3 --offload-arch=gfx950 tools/split_probe.hip -o /tmp/split_probe && /tmp/split_probe
@@ -74,6 +75,26 @@ __global__ __launch_bounds__(256, 2) void probe(const float *__restrict__ a, int
 
   auto mfma_step = [&](const float *Bs, int ks) {
     const u32x4 *Bq = (const u32x4 *)Bs + (ks * 3 * TN) * 64 + lane;
+    if (STAGE == 10) {  // all 15 fragments of the k-step requested before the first MFMA (60 registers)
+      u32x4 fh[TN], fm[TN], fl[TN];
+#pragma unroll
+      for (int j = 0; j < TN; j++) { fh[j] = Bq[j * 64]; fm[j] = Bq[(TN + j) * 64]; fl[j] = Bq[(2 * TN + j) * 64]; }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const bf16x8 xh = __builtin_bit_cast(bf16x8, fh[j]), xm = __builtin_bit_cast(bf16x8, fm[j]), xl = __builtin_bit_cast(bf16x8, fl[j]);
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, ch[ks]), am = __builtin_bit_cast(bf16x8, cm[ks]),
+                     al = __builtin_bit_cast(bf16x8, cl[ks]);
+        f32x16 c = acc[j];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xm, c, 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh, c, 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; j++) {
       u32x4 h_ = bh[j], m_ = bm[j], l_ = bl[j];
@@ -161,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void probe(const float *__restrict__ a, int
     if (STAGE == 8) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // DMA never waited for (the probe does not care what it reads)
       __builtin_amdgcn_s_barrier();
-    } else if (STAGE == 9) {
+    } else if (STAGE == 9 || STAGE == 10) {
       __syncthreads();
     } else if (STAGE >= 6) {
       // the weight DMA (older) must have landed before the barrier; the four A loads (younger) stay in flight across it
@@ -222,6 +243,7 @@ int main() {
   run<7>(a, lda, bp, coef, out, ktiles, rows);
   run<8>(a, lda, bp, coef, out, ktiles, rows);
   run<9>(a, lda, bp, coef, out, ktiles, rows);
+  run<10>(a, lda, bp, coef, out, ktiles, rows);
   hipDeviceSynchronize();
   return 0;
 }
