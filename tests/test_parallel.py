@@ -66,3 +66,57 @@ def test_two_rank_gradient_allreduce(tmp_path):
     gs = [_flat(O.train_grads(params, x[a:b], labels[a:b], w[a:b], **KW)[1], names) for a, b in ((0, 2), (2, 4))]
     want = (gs[0] + gs[1]) / 2
     assert np.allclose(r0["g"], want, rtol=1e-5, atol=1e-6 * np.abs(want).max())
+
+
+class _StubLib:
+    """stands in for libdl3.so's RCCL binding: the communicator comes up on rank 0 and fails on rank 1"""
+    def __init__(self, rank):
+        self.rank, self.destroyed = rank, 0
+
+    def dl3_comm_unique_id(self, raw):
+        return 0
+
+    def dl3_comm_init(self, handle_ref, idbytes, rank, world):
+        return 0 if rank == 0 else 5
+
+    def dl3_comm_destroy(self, handle):
+        self.destroyed += 1
+        return 0
+
+    def dl3_last_error(self):
+        return b"stub: no communicator on this rank"
+
+
+def _worker_fallback(rank, world, port, out_dir):
+    import warnings
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    os.environ.pop("DL3_DIST_BACKEND", None)
+    import dl3_amd  # noqa: F401
+    from dl3_amd import capi
+    from dl3_amd.parallel import DataParallel
+    stub = _StubLib(rank)
+    capi.lib = lambda: stub
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        dp = DataParallel(backend="rccl")
+    g = torch.full((8,), float(rank + 1))
+    scale = dp.allreduce_grads(g)
+    np.savez(os.path.join(out_dir, "fb%d.npz" % rank), backend=dp.backend, comm=dp.comm is None, g=g.numpy() * scale,
+             warned=any("NOT over RCCL" in str(w.message) for w in rec), destroyed=stub.destroyed)
+    dp.close()
+
+
+def test_ranks_agree_when_the_rccl_communicator_fails_on_one_of_them(tmp_path):
+    """parallel.py _init_rccl: a rank whose communicator came up must not run the RCCL plane alone — both fall back to
+    gloo (with a warning), the healthy rank destroys its communicator, and the exchange still works"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_fallback, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = [np.load(os.path.join(str(tmp_path), "fb%d.npz" % r)) for r in (0, 1)]
+    for r in (r0, r1):
+        assert str(r["backend"]) == "gloo" and bool(r["comm"]) and bool(r["warned"])
+        assert np.allclose(r["g"], 1.5)
+    assert int(r0["destroyed"]) == 1 and int(r1["destroyed"]) == 0
