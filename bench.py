@@ -301,8 +301,13 @@ def cpu_a_leg(args, avail):
                 thread_sweep_img_s={str(k): round(v, 3) for k, v in sweep.items()})
 
 
+def capi_math():
+    from dl3_amd import capi
+    return capi.get_gemm_math()
+
+
 def split_math_leg(args):
-    """The same K steps with the 1x1-conv GEMMs in split math (DL3_GEMM_MATH=split: every fp32 operand
+    """The same K steps with the 1x1-conv GEMMs in split math (dl3_set_gemm_math(DL3_MATH_SPLIT): every fp32 operand
     cut EXACTLY into three bf16 pieces, six of the nine piece products on v_mfma_f32_32x32x16_bf16, fp32 accumulate;
     csrc/pwgemm.hip split3).  Reported BESIDE the headline, which stays on the f32 MFMA."""
     import gc
@@ -310,7 +315,8 @@ def split_math_leg(args):
     gc.collect()
     G.clear_session()
     torch.cuda.empty_cache()
-    os.environ["DL3_GEMM_MATH"] = "split"
+    from dl3_amd import capi
+    capi.set_gemm_math("split")
     try:
         model, eng = build_engine(args)
         for _ in range(max(args.warmup, 2)):
@@ -327,7 +333,7 @@ def split_math_leg(args):
         dt = time.perf_counter() - t0
         loss = float(eng.loss[0].item())
     finally:
-        os.environ["DL3_GEMM_MATH"] = "f32"
+        capi.set_gemm_math(None)
     log("split-math leg: %.1f ms/step" % (1e3 * dt / args.steps))
     return {"value": args.batch * args.steps / dt, "unit": "img/s", "ms_per_step": 1e3 * dt / args.steps, "final_loss": loss,
             "what": "same workload, same K steps; the 1x1-conv GEMMs (forward, bwd-data, bwd-weight) computed as 6 bf16 MFMAs "
@@ -399,7 +405,7 @@ def main():
                        "global_batch": args.batch * dp.world, "per_gpu_batch": args.batch,
                        "parallelism": "dp%d" % dp.world, "hipgraph": eng.graph is not None, "final_loss": loss,
                        "launches_per_step": len(eng.ops_fwd) + len(eng.ops_bwd) + 1,
-                       "matrix_math": "split" if os.environ.get("DL3_GEMM_MATH", "f32").startswith("s") else "f32",
+                       "matrix_math": capi_math(),
                        "gradient_exchange": ("dl3_comm_allreduce_f32 (RCCL), %.2f MB" % (eng.n_param * 4 / 1e6))
                        if dp.comm is not None else ("gloo (host staged)" if dp.world > 1 else None)},
         }

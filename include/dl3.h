@@ -73,6 +73,14 @@ int dl3_dwconv3x3_bwd(const float *g, const float *yraw, const float *cA, const 
                       int C, int stride, int rate, int pad_t, int pad_l, int Ho, int Wo, int impl, void *stream);
 
 /* ---- Conv2D 1x1 = GEMM on fp32 MFMA (deeplabv3p.py:78-79,:175,:194,:377,:385,:406,:420,:438) -- */
+#define DL3_MATH_ENV (-1)  /* follow the environment (DL3_GEMM_MATH=split selects split math); the default */
+#define DL3_MATH_F32 0     /* v_mfma_f32_32x32x2_f32 */
+#define DL3_MATH_SPLIT 1   /* fp32 operands cut exactly into three bf16 pieces, six of the nine piece products on
+                              v_mfma_f32_32x32x16_bf16, fp32 accumulate (same error class as the f32 MFMA) */
+/* matrix math of the dl3_pwconv_* launches issued after the call (process-wide; launches already captured in a
+ * hipGraph keep what they were captured with); dl3_get_gemm_math returns the mode in effect (0 or 1) */
+int dl3_set_gemm_math(int mode);
+int dl3_get_gemm_math(void);
 /* P for the [M,K]x[K,N] GEMM's per-output-channel partials */
 int dl3_pwconv_partials(int M, int K, int N);
 /* y[M,N](ldy) = T(x)[M,K](ldx) . w[K,N] (+bias[N]); stat_partial (nullable) [P][N][2] = sum(y), sum(y^2) */

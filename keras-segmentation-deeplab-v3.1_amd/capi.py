@@ -106,6 +106,22 @@ def protos():
     return _protos
 
 
+MATH_MODES = {None: -1, "env": -1, "f32": 0, "split": 1}
+
+
+def set_gemm_math(mode):
+    """matrix math of the 1x1-conv GEMM launches issued from now on (include/dl3.h dl3_set_gemm_math): 'f32' (the f32
+    MFMA), 'split' (exact 3-way bf16 split on the bf16 MFMA, fp32-roundoff-class error) or None (follow DL3_GEMM_MATH).
+    Process-wide; an engine keeps the mode its hipGraph was captured with."""
+    if mode not in MATH_MODES:
+        raise ValueError("matrix math must be one of 'f32', 'split', None")
+    check(lib().dl3_set_gemm_math(MATH_MODES[mode]), "dl3_set_gemm_math")
+
+
+def get_gemm_math():
+    return "split" if lib().dl3_get_gemm_math() == 1 else "f32"
+
+
 def check(rc, name="dl3"):
     if rc != 0:
         msg = lib().dl3_last_error().decode()

@@ -1178,7 +1178,9 @@ void *pack_scratch(size_t bytes, hipStream_t st) {
   return buf;
 }
 
+int g_gemm_math = -1;  // DL3_MATH_ENV
 bool split_math() {
+  if (g_gemm_math >= 0) return g_gemm_math == 1;
   const char *e = getenv("DL3_GEMM_MATH");  // "split": fp32 as 3 x bf16 on the bf16 matrix pipe; default: f32 MFMA
   return e && e[0] == 's';
 }
@@ -1335,6 +1337,14 @@ void launch_wgrad(const WgradArgs &A, dim3 grid, hipStream_t st, bool vec) {
 }  // namespace
 
 extern "C" int dl3_reduce_partials(const float *partial, int P, int n, float *out, void *stream);
+
+extern "C" int dl3_set_gemm_math(int mode) {
+  DL3_CHECK_ARG(mode >= -1 && mode <= 1, "set_gemm_math: mode must be DL3_MATH_ENV, DL3_MATH_F32 or DL3_MATH_SPLIT");
+  g_gemm_math = mode;
+  return DL3_OK;
+}
+
+extern "C" int dl3_get_gemm_math(void) { return split_math() ? 1 : 0; }
 
 extern "C" int dl3_pwconv_partials(int M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0) return 0;

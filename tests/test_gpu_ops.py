@@ -255,6 +255,25 @@ def test_pwconv_bwd_weight_split_math(L, cfg, monkeypatch):
         test_pwconv_bwd_weight(L, case)
 
 
+def test_gemm_math_api(L, monkeypatch):
+    """dl3_set_gemm_math overrides the environment; DL3_MATH_ENV hands the choice back to it"""
+    from dl3_amd import capi
+    monkeypatch.delenv("DL3_GEMM_MATH", raising=False)
+    assert capi.get_gemm_math() == "f32"
+    capi.set_gemm_math("split")
+    try:
+        assert capi.get_gemm_math() == "split"
+        test_pwconv_fwd(L, (66000, 160, 960, 0, 0, False, 2))
+        monkeypatch.setenv("DL3_GEMM_MATH", "f32")
+        assert capi.get_gemm_math() == "split"
+    finally:
+        capi.set_gemm_math(None)
+    assert capi.get_gemm_math() == "f32"
+    monkeypatch.setenv("DL3_GEMM_MATH", "split")
+    assert capi.get_gemm_math() == "split"
+    assert L.dl3_set_gemm_math(7) != 0
+
+
 def test_split_math_error(L, monkeypatch):
     """error of the split-math GEMM against float64, next to the f32 MFMA's: both must be fp32-roundoff class"""
     M, K, N = 65536, 960, 160   # enough row tiles for the 128-row configurations (the 32-row ones keep the f32 MFMA)
