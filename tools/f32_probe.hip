@@ -9,7 +9,8 @@
 //   6  = 5, but the loop is cut into row tiles of TILE_K K-tiles with the tile epilogue (80 nt stores per lane, BN sums)
 //        and prologue (accumulators zeroed, first K-tile loaded, waited for, staged) between them
 //   7  = 6 with the next tile's first K-tile requested before the epilogue     8  = 7 without the epilogue's stores
-// usage: hipcc -O3 --offload-arch=gfx950 tools/f32_probe.hip -o /tmp/f32_probe && /tmp/f32_probe [K-tiles per row tile]
+// usage: hipcc -O3 --offload-arch=gfx950 tools/f32_probe.hip -o /tmp/f32_probe && /tmp/f32_probe [K-tiles per row tile [K-tiles per workgroup]]
+//        -DPROBE_TN=1 -DPROBE_WN=4: the 32x128 small-M tile (B=2: one row tile of 60 K-tiles per workgroup: `f32_probe 60 60`)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -17,7 +18,14 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int TN = 5, KT = 16, KH = 8, BN = 160, LDB = BN, NB = 3;
+#ifndef PROBE_TN
+#define PROBE_TN 5
+#endif
+#ifndef PROBE_WN
+#define PROBE_WN 1  // waves side by side along N (4: the 32-row small-M tile, every wave streams the same 32 A rows)
+#endif
+constexpr int TN = PROBE_TN, WN = PROBE_WN, KT = 16, KH = 8, BN = 32 * TN * WN, LDB = BN, NB = (KT * BN / 4 + 255) / 256;
+constexpr int MFMA_PER_KT = 8 * TN;
 
 template <int STAGE>
 __global__ __launch_bounds__(256, 2) void probe(const float *__restrict__ a, int lda, const float *__restrict__ b,
@@ -32,7 +40,8 @@ __global__ __launch_bounds__(256, 2) void probe(const float *__restrict__ a, int
     for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
   for (int i = tid; i < 2 * KT * LDB; i += 256) lds[i] = b[i % (KT * BN)];
   __syncthreads();
-  int row = (blockIdx.x * 128 + wave * 32 + l31) % rows;
+  const int wn = WN == 1 ? 0 : wave;
+  int row = (WN == 1 ? blockIdx.x * 128 + wave * 32 + l31 : blockIdx.x * 32 + l31) % rows;
   const float *arow = a + (size_t)row * lda;
   f32x4 an[2], ac[2], rb[NB];
   an[0] = an[1] = ac[0] = ac[1] = f32x4{1.f, 2.f, 3.f, 4.f};
@@ -69,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void probe(const float *__restrict__ a, int
     }
   };
   auto epilogue = [&](int tile) {
-    float *pc = c + ((size_t)((blockIdx.x * 7 + tile) % 4096) * 128 + wave * 32) * BN;
+    float *pc = c + ((size_t)((blockIdx.x * 7 + tile) % 4096) * 128 + (WN == 1 ? wave * 32 : 0)) * BN + wn * TN * 32;
     const unsigned lo = 4 * lhi * BN + l31;
 #pragma unroll
     for (int j = 0; j < TN; j++)
@@ -90,13 +99,13 @@ __global__ __launch_bounds__(256, 2) void probe(const float *__restrict__ a, int
     if (STAGE >= 4) load_B(kt + 1);
     float bf[2][TN];
 #pragma unroll
-    for (int j = 0; j < TN; j++) bf[0][j] = STAGE >= 1 ? Bs[(KH * lhi) * LDB + j * 32 + l31] : 1.f + j;
+    for (int j = 0; j < TN; j++) bf[0][j] = STAGE >= 1 ? Bs[(KH * lhi) * LDB + (wn * TN + j) * 32 + l31] : 1.f + j;
 #pragma unroll
     for (int s_ = 0; s_ < KH; ++s_) {
       const int cur = s_ & 1, nxt = cur ^ 1;
       if (s_ + 1 < KH) {
 #pragma unroll
-        for (int j = 0; j < TN; j++) bf[nxt][j] = STAGE >= 1 ? Bs[(KH * lhi + s_ + 1) * LDB + j * 32 + l31] : 2.f + j;
+        for (int j = 0; j < TN; j++) bf[nxt][j] = STAGE >= 1 ? Bs[(KH * lhi + s_ + 1) * LDB + (wn * TN + j) * 32 + l31] : 2.f + j;
       }
 #pragma unroll
       for (int j = 0; j < TN; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[s_ >> 2][s_ & 3], bf[cur][j], acc[j], 0, 0, 0);
@@ -160,24 +169,24 @@ static void run(const float *a, int lda, const float *b, const float *coef, floa
   float ms = 0.f;
   hipEventElapsedTime(&ms, e0, e1);
   ms /= reps;
-  const double mfma = 512.0 * 4 * ktiles * 40;
+  const double mfma = 512.0 * 4 * ktiles * MFMA_PER_KT;
   const double ideal_ms = mfma * 64 / (1024.0 * 2.4e9) * 1e3;
   printf("stage %d: %.3f ms  (matrix pipe %.0f %% of 64-cycle issue at 2.4 GHz; %.1f TFLOP/s f32)\n", STAGE, ms,
          100.0 * ideal_ms / ms, mfma * 4096.0 / ms / 1e9);
 }
 
 int main(int argc, char **argv) {
-  const int rows = 524288, lda = 960, ktiles = 480, tile_k = argc > 1 ? atoi(argv[1]) : 10;
+  const int rows = 524288, lda = 960, tile_k = argc > 1 ? atoi(argv[1]) : 10, ktiles = argc > 2 ? atoi(argv[2]) : 480;
   float *a, *b, *coef, *c, *out;
   hipMalloc(&a, (size_t)rows * lda * 4);
   hipMalloc(&b, (size_t)9 * KT * BN * 4);
   hipMalloc(&coef, 1024);
-  hipMalloc(&c, (size_t)4096 * 128 * BN * 4);
+  hipMalloc(&c, (size_t)4096 * 128 * 640 * 4);
   hipMalloc(&out, 512 * 256 * 4);
   hipMemset(a, 0, (size_t)rows * lda * 4);
   hipMemset(b, 0, (size_t)9 * KT * BN * 4);
   hipMemset(coef, 0, 1024);
-  printf("row tiles of %d K-tiles (K = %d)\n", tile_k, tile_k * KT);
+  printf("tile 32*%d rows x %d columns, TN = %d; row tiles of %d K-tiles (K = %d), %d K-tiles per workgroup\n", WN == 1 ? 4 : 1, BN, TN, tile_k, tile_k * KT, ktiles);
   run<0>(a, lda, b, coef, c, out, ktiles, rows, tile_k);
   run<1>(a, lda, b, coef, c, out, ktiles, rows, tile_k);
   run<2>(a, lda, b, coef, c, out, ktiles, rows, tile_k);
