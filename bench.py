@@ -78,6 +78,8 @@ def respawn_under_launcher(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     log("spawning %d ranks: %s" % (args.gpus, " ".join(cmd[2:9])))
     env = dict(os.environ)
+    if env.get("DL3_DIST_BACKEND") != "gloo":
+        env.setdefault("DL3_DIST_STRICT", "1")  # an N>1 number must come from RCCL or not at all (see main)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
     sys.exit(subprocess.call(cmd, env=env))
@@ -157,15 +159,18 @@ def insitu_profile(eng, passes=3):
 
 
 def _pmc_traffic(family, args):
-    """HBM bytes per step of a kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-    separate runs, corrected as MI355X_MICROARCH.md prescribes; tools/collect_profiles.sh + tools/pmc_family.py) — only
-    for the configuration they were collected on, else None"""
-    pmc = os.path.join(ROOT, "profiles", "r02_%s_b%d_pmc.json" % (family, args.batch))
-    if os.path.exists(pmc) and args.head == "deeplab" and args.size == 512:
-        pj = json.load(open(pmc))
-        if pj.get("batch") == args.batch and pj.get("backbone") == args.backbone:
-            return pj.get("traffic_bytes_per_step")
-    return None
+    """(HBM bytes per step, source) of a kernel family from the COMMITTED PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE, separate runs, corrected as MI355X_MICROARCH.md prescribes; tools/collect_profiles.sh +
+    tools/pmc_family.py).  It is a constant read from profiles/, not a measurement of this run — the line says so in
+    `traffic_source` — and only reported for the configuration it was collected on, else (None, None)."""
+    for rnd in ("r03", "r02"):
+        rel = os.path.join("profiles", "%s_%s_b%d_pmc.json" % (rnd, family, args.batch))
+        pmc = os.path.join(ROOT, rel)
+        if os.path.exists(pmc) and args.head == "deeplab" and args.size == 512:
+            pj = json.load(open(pmc))
+            if pj.get("batch") == args.batch and pj.get("backbone") == args.backbone:
+                return pj.get("traffic_bytes_per_step"), "%s (committed rocprofv3 PMC pass of this configuration, not this run)" % rel
+    return None, None
 
 
 def roofline_blocks(rows, args):
@@ -188,17 +193,18 @@ def roofline_blocks(rows, args):
             "bound": "mfma", "kernel": "Conv2D 1x1 GEMM family on v_mfma_f32_32x32x2_f32: pw_gemm_stream_kernel (forward, "
             "bwd-data) + pw_wgrad_kernel (bwd-weight), %d launches/step" % g["launches"],
             "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS,
-            "traffic": _pmc_traffic("gemm", args),
+            "traffic": _pmc_traffic("gemm", args)[0], "traffic_source": _pmc_traffic("gemm", args)[1],
             "avg_ms": g["ms"] / g["launches"], "family_ms_per_step": g["ms"], "algorithmic_flops_per_step": g["flops"],
             "algorithmic_bytes_per_step": g["bytes"], "share_of_step": g["ms"] / tot, "note": note % "FLOPs"}
     d = fam.get("dw_dilated")
     if d and d["ms"] > 0:
         gbs = d["bytes"] / d["ms"] / 1e6
-        traffic = _pmc_traffic("dw_dilated", args)
+        traffic, traffic_src = _pmc_traffic("dw_dilated", args)
         out["roofline_hbm"] = {
             "bound": "hbm", "kernel": "DepthwiseConv2D 3x3 rate>1 family: dw_march2_fwd / dw_march_fwd / dw_march_bwd, "
             "%d launches/step" % d["launches"],
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": traffic_src,
             "avg_ms": d["ms"] / d["launches"], "family_ms_per_step": d["ms"], "algorithmic_bytes_per_step": d["bytes"],
             "share_of_step": d["ms"] / tot, "note": note % "bytes"}
         fw = [r for r in rows if r["family"] == "dw_dilated" and r["shape"].startswith("fwd")]
@@ -359,6 +365,10 @@ def main():
         raise SystemExit("bench.py: %d ranks but %d visible GPU(s); RCCL needs one GPU per rank (DL3_DIST_BACKEND=gloo "
                          "oversubscribes a GPU for functional tests only)" % (world, ndev))
     torch.cuda.set_device(local % ndev)
+    if world > 1 and os.environ.get("DL3_DIST_BACKEND") != "gloo":
+        # an N>1 line must never silently be a host-staged gloo number: a failing ncclCommInitRank aborts the run unless
+        # the gloo data plane was asked for explicitly (functional tests on a one-GPU box)
+        os.environ.setdefault("DL3_DIST_STRICT", "1")
     dp = DataParallel()
     log("building engine (batch %d per GPU, %d GPU, data plane %s)" % (args.batch, dp.world, dp.backend if dp.world > 1 else "-"))
     model, eng = build_engine(args)
@@ -371,6 +381,23 @@ def main():
         eng.fwd_bwd()
         scale = dp.allreduce_grads(eng.grads)
         eng.adam(None, scale)
+
+    def allreduce_ms(reps=10):
+        """the gradient exchange on its own (same arena, same stream, same communicator), HIP events around `reps`
+        back-to-back all-reduces after a barrier; max over ranks.  Timed AFTER the timed region and on a scratch copy."""
+        if dp.world == 1:
+            return None
+        scratch = eng.grads.clone()
+        dp.allreduce_grads(scratch)
+        torch.cuda.synchronize()
+        dp.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            dp.allreduce_grads(scratch)
+        e1.record()
+        torch.cuda.synchronize()
+        return dp.max_over_ranks(e0.elapsed_time(e1) / reps)
 
     for i in range(max(args.warmup, 2)):  # >= 2: the first call runs eagerly, the second captures the hipGraph
         step()
@@ -388,6 +415,7 @@ def main():
     dt = dp.max_over_ranks(time.perf_counter() - t0)
     loss = float(eng.loss[0].item())
     log("timed %d steps: %.1f ms/step" % (args.steps, 1e3 * dt / args.steps))
+    ar_ms = allreduce_ms()
 
     if dp.rank == 0:
         imgs = args.batch * dp.world * args.steps
@@ -407,8 +435,12 @@ def main():
                        "launches_per_step": len(eng.ops_fwd) + len(eng.ops_bwd) + 1,
                        "matrix_math": capi_math(),
                        "gradient_exchange": ("dl3_comm_allreduce_f32 (RCCL), %.2f MB" % (eng.n_param * 4 / 1e6))
-                       if dp.comm is not None else ("gloo (host staged)" if dp.world > 1 else None)},
+                       if dp.comm is not None else ("gloo (host staged)" if dp.world > 1 else None),
+                       "rccl_ranks": dp.rccl_ranks(), "dist_strict": os.environ.get("DL3_DIST_STRICT", "0") == "1",
+                       "backward_fork": bool(eng.fork and eng._side)},
         }
+        if ar_ms is not None:
+            rec["allreduce_ms"] = ar_ms  # one exchange of the %d-float arena on its own, max over ranks (part of ms_per_step)
         if not args.no_roofline:
             rows = insitu_profile(eng)
             log("in-situ profile done: %.2f ms for %d launches" % (sum(r["ms"] for r in rows), len(rows)))

@@ -210,6 +210,15 @@ int dl3_resize_bilinear_bwd(const float *dy, int lddy, float *dx, int lddx, int 
 /* Subpixel._phase_shift (subpixel.py:77-88): out[n,ia*r+q,ib*r+p,ch] = in[n,ia,ib,ch*r*r+p*r+q];
  * inverse!=0 applies the inverse permutation (the backward pass) */
 int dl3_phase_shift(const float *in, float *out, int N, int H, int W, int Cout, int r, int inverse, void *stream);
+/* Subpixel with kernel_size > 1 (subpixel.py:42-58: Subpixel IS a Conv2D with any kernel_size; icnr_weights' default
+ * shape is 3x3, subpixel.py:9): the k x k taps of T(x) = act(scale*x+shift), zero outside the image, gathered next to
+ * each other — cols[(n,oy,ox)][(i*k+j)*C + c] = T(x)[n, oy-pad_t+i, ox-pad_l+j, c] (stride 1) — so that the Keras
+ * kernel [k][k][C][F] read as a [k*k*C][F] matrix drives the ordinary 1x1 GEMM entry points.  _bwd is the transpose:
+ * dx[n,iy,ix,c] = sum over taps of dcols (deterministic gather, no atomics). */
+int dl3_conv_taps_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act, float *cols,
+                      int N, int H, int W, int C, int k, int pad_t, int pad_l, int Ho, int Wo, void *stream);
+int dl3_conv_taps_bwd(const float *dcols, float *dx, int N, int H, int W, int C, int k, int pad_t, int pad_l, int Ho,
+                      int Wo, void *stream);
 /* softmax over the last axis (deeplabv3p.py:441,:444) */
 int dl3_softmax_fwd(const float *logits, float *probs, int M, int C, void *stream);
 /* argmax over the last axis -> int32 (first maximum wins, like np.argmax) */
@@ -275,6 +284,9 @@ int dl3_comm_unique_id(void *id128);
 int dl3_comm_init(void **comm, const void *id128, int rank, int world);
 int dl3_comm_allreduce_f32(void *comm, const float *send, float *recv, size_t n, void *stream);
 int dl3_comm_broadcast_f32(void *comm, float *buf, size_t n, int root, void *stream);
+/* number of ranks RCCL itself reports for the communicator (ncclCommCount): lets a benchmark line state which data
+ * plane produced it */
+int dl3_comm_count(void *comm, int *count);
 int dl3_comm_destroy(void *comm);
 
 #ifdef __cplusplus

@@ -22,6 +22,7 @@ struct Rccl {
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
   bool ok = false;
 };
 
@@ -44,6 +45,7 @@ Rccl &rccl() {
   R.AllReduce = (decltype(R.AllReduce))dlsym(R.h, "ncclAllReduce");
   R.Broadcast = (decltype(R.Broadcast))dlsym(R.h, "ncclBroadcast");
   R.GetErrorString = (decltype(R.GetErrorString))dlsym(R.h, "ncclGetErrorString");
+  R.CommCount = (decltype(R.CommCount))dlsym(R.h, "ncclCommCount");
   R.ok = R.GetUniqueId && R.CommInitRank && R.CommDestroy && R.AllReduce && R.Broadcast && R.GetErrorString;
   return R;
 }
@@ -55,7 +57,8 @@ struct Comm {
 
 int need_rccl(const char *who) {
   if (!rccl().ok) {
-    dl3_set_error("%s: librccl.so could not be loaded (%s)", who, dlerror() ? dlerror() : "symbols missing");
+    const char *e = dlerror();  // one call: dlerror() clears the state it reports
+    dl3_set_error("%s: librccl.so could not be loaded (%s)", who, e ? e : "symbols missing");
     return DL3_EUNSUPPORTED;
   }
   return DL3_OK;
@@ -110,6 +113,14 @@ extern "C" int dl3_comm_broadcast_f32(void *comm, float *buf, size_t n, int root
   Comm *c = (Comm *)comm;
   DL3_CHECK_ARG(root >= 0 && root < c->world, "comm_broadcast_f32: bad root");
   DL3_NCCL(rccl().Broadcast(buf, buf, n, ncclFloat, root, c->c, (hipStream_t)stream), "comm_broadcast_f32");
+  return DL3_OK;
+}
+
+extern "C" int dl3_comm_count(void *comm, int *count) {
+  DL3_CHECK_ARG(comm && count, "comm_count: null pointer");
+  Comm *c = (Comm *)comm;
+  DL3_UNSUPPORTED(!rccl().CommCount, "comm_count: this librccl does not export ncclCommCount");
+  DL3_NCCL(rccl().CommCount(c->c, count), "comm_count");
   return DL3_OK;
 }
 

@@ -147,6 +147,51 @@ __global__ __launch_bounds__(256) void phase_shift_kernel(const float *__restric
   }
 }
 
+// k x k taps of T(x) side by side (Subpixel with kernel_size > 1): one thread per (output pixel, tap, channel)
+__global__ __launch_bounds__(256) void conv_taps_fwd_kernel(const float *__restrict__ x, int ldx,
+                                                            const float *__restrict__ sc, const float *__restrict__ sh,
+                                                            int act, float *__restrict__ cols, int N, int H, int W, int C,
+                                                            int k, int pt, int pl, int Ho, int Wo) {
+  const long total = (long)N * Ho * Wo * k * k * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long p = i / C;
+    const int t = (int)(p % (k * k));
+    p /= k * k;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho), n = (int)(p / Ho);
+    const int iy = oy - pt + t / k, ix = ox - pl + t % k;
+    float v = 0.f;
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+      v = x[(((size_t)n * H + iy) * W + ix) * ldx + c];
+      if (sc) v = sc[c] * v + sh[c];
+      v = dl3_act(v, act);
+    }
+    cols[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_taps_bwd_kernel(const float *__restrict__ dcols, float *__restrict__ dx,
+                                                            int N, int H, int W, int C, int k, int pt, int pl, int Ho,
+                                                            int Wo) {
+  const long total = (long)N * H * W * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long p = i / C;
+    const int ix = (int)(p % W);
+    p /= W;
+    const int iy = (int)(p % H), n = (int)(p / H);
+    float s = 0.f;
+    for (int t = 0; t < k * k; t++) {  // fixed tap order: deterministic
+      const int oy = iy + pt - t / k, ox = ix + pl - t % k;
+      if (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo)
+        s += dcols[((((size_t)n * Ho + oy) * Wo + ox) * (k * k) + t) * C + c];
+    }
+    dx[i] = s;
+  }
+}
+
 __global__ __launch_bounds__(256) void softmax_kernel(const float *__restrict__ x, float *__restrict__ p, long M,
                                                       int C) {
   for (long m = (long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long)gridDim.x * 256) {
@@ -506,6 +551,30 @@ extern "C" int dl3_phase_shift(const float *in, float *out, int N, int H, int W,
   hipLaunchKernelGGL(phase_shift_kernel, dim3(ew_blocks((size_t)N * H * W * Cout * r * r)), dim3(256), 0,
                      (hipStream_t)stream, in, out, N, H, W, Cout, r, inverse);
   DL3_LAUNCH_CHECK("phase_shift");
+  return DL3_OK;
+}
+
+extern "C" int dl3_conv_taps_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
+                                 float *cols, int N, int H, int W, int C, int k, int pad_t, int pad_l, int Ho, int Wo,
+                                 void *stream) {
+  DL3_CHECK_ARG(x && cols && N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && Ho > 0 && Wo > 0 && ldx >= C,
+                "conv_taps_fwd: bad argument");
+  DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "conv_taps_fwd: scale/shift must come together");
+  DL3_CHECK_ARG(pad_t >= 0 && pad_l >= 0 && Ho - 1 - pad_t + k - 1 < H + k && Wo - 1 - pad_l + k - 1 < W + k,
+                "conv_taps_fwd: geometry out of range");
+  hipLaunchKernelGGL(conv_taps_fwd_kernel, dim3(ew_blocks((size_t)N * Ho * Wo * k * k * C)), dim3(256), 0,
+                     (hipStream_t)stream, x, ldx, in_scale, in_shift, in_act, cols, N, H, W, C, k, pad_t, pad_l, Ho, Wo);
+  DL3_LAUNCH_CHECK("conv_taps_fwd");
+  return DL3_OK;
+}
+
+extern "C" int dl3_conv_taps_bwd(const float *dcols, float *dx, int N, int H, int W, int C, int k, int pad_t, int pad_l,
+                                 int Ho, int Wo, void *stream) {
+  DL3_CHECK_ARG(dcols && dx && N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && Ho > 0 && Wo > 0 && pad_t >= 0 && pad_l >= 0,
+                "conv_taps_bwd: bad argument");
+  hipLaunchKernelGGL(conv_taps_bwd_kernel, dim3(ew_blocks((size_t)N * H * W * C)), dim3(256), 0, (hipStream_t)stream,
+                     dcols, dx, N, H, W, C, k, pad_t, pad_l, Ho, Wo);
+  DL3_LAUNCH_CHECK("conv_taps_bwd");
   return DL3_OK;
 }
 

@@ -16,6 +16,9 @@
 // half-wave: conflict-free ds_read_b32.
 #include <stdlib.h>
 
+#include <mutex>
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -623,6 +626,10 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
           }
         }
       };
+      // Every wave DMAs only its own pieces of a weight tile and, after the barrier, reads ALL of them: a wave must not
+      // reach the barrier with its DMA still in flight.  s_barrier does not imply it on gfx950 (back-off barriers), so
+      // the vmcnt(0) is spelled out (0x0F70 = vmcnt 0, expcnt / lgkmcnt untouched) instead of left to the fence the
+      // compiler happens to emit for __syncthreads today.
       load_A(0);
       __syncthreads();  // the previous row tile is done with the LDS
       dma_B(0, 0);
@@ -630,6 +637,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
       split_next();
       take_next();
       if (ktiles > 1) load_A(1);
+      __builtin_amdgcn_s_waitcnt(0x0F70);
       __syncthreads();
       for (int kt = 0; kt < ktiles; ++kt) {
         const float *Bs = lds + (kt & 1) * BQ * 4;
@@ -642,6 +650,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
           if (kt + 2 < ktiles) load_A(kt + 2);
         }
         mfma_step(Bs, 1);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
         if (more) take_next();
       }
@@ -1160,22 +1169,34 @@ int gemm_grid_y(int M, int N, const GemmCfg &c) {
   return even;
 }
 
-// split math: device scratch for the packed weights of the launch in flight.  Launches on one stream are ordered, so one
-// buffer serves them all; it only ever grows, and a superseded buffer stays allocated (a captured hipGraph may still
-// point at it).  Growing is impossible while the stream is capturing: the engine's first step runs eagerly.
+// split math: device scratch for the packed weights of the launch in flight, one buffer per (device, stream): launches
+// on one stream are ordered, launches on different streams / devices / host threads never share a buffer.  A buffer only
+// ever grows, and a superseded one stays allocated (a captured hipGraph may still point at it).  Growing is impossible
+// while the stream is capturing: the engine's first step runs eagerly.
 void *pack_scratch(size_t bytes, hipStream_t st) {
-  static void *buf = nullptr;
-  static size_t cap = 0;
-  if (bytes <= cap) return buf;
+  struct Slot { int dev; hipStream_t st; void *buf; size_t cap; };
+  static std::mutex mu;
+  static std::vector<Slot> slots;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  Slot *s = nullptr;
+  for (Slot &q : slots)
+    if (q.dev == dev && q.st == st) { s = &q; break; }
+  if (s && bytes <= s->cap) return s->buf;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(st, &cs);
   if (cs != hipStreamCaptureStatusNone) return nullptr;
   size_t want = bytes < (32u << 20) ? (32u << 20) : bytes * 2;
   void *nb = nullptr;
   if (hipMalloc(&nb, want) != hipSuccess) return nullptr;
-  buf = nb;
-  cap = want;
-  return buf;
+  if (!s) {
+    slots.push_back(Slot{dev, st, nullptr, 0});
+    s = &slots.back();
+  }
+  s->buf = nb;
+  s->cap = want;
+  return nb;
 }
 
 int g_gemm_math = -1;  // DL3_MATH_ENV

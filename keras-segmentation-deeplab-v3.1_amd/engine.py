@@ -81,7 +81,9 @@ def plan_channels(model):
         cin = [phys[id(t)] for t in l.inbound]
         if l.kind == "Conv2D":
             f = l.cfg["filters"]
-            c = f if id(l) in nopad else stored_channels(f)
+            # only 1x1 convolutions widen their output: the dense 3x3 lowering (Conv3Unit) sizes its kernel and buffers
+            # from the logical filter count
+            c = f if (id(l) in nopad or l.cfg["k"] != 1) else stored_channels(f)
         elif l.kind == "Subpixel":
             c = l.cfg["out_filters"]
         elif l.kind == "Concatenate":
@@ -165,7 +167,7 @@ class View:
 
 class Engine:
     def __init__(self, model, batch, training, bn_mode="batch", dropout=True, seed=2, device=None, use_graph=True,
-                 dw_impl=IMPL_AUTO, rank=None, bn_variance="keras224"):
+                 dw_impl=IMPL_AUTO, rank=None, bn_variance="keras224", external_nnz=False):
         if not torch.cuda.is_available():
             raise capi.DL3Error("the dl3 engine needs a GPU (HIP device); there is no CPU fallback")
         self.lib = capi.lib()
@@ -178,11 +180,24 @@ class Engine:
         if bn_variance not in BN_VARIANCE:
             raise ValueError("bn_variance must be one of %s" % sorted(BN_VARIANCE))
         self.bn_variance = bn_variance
+        # data parallel: the loss normaliser count(w != 0) is the GLOBAL batch's (the reference's multi_gpu_model merges
+        # the tower outputs and evaluates ONE loss, utils.py:209-211) — the host writes it before each step instead of
+        # the in-graph dl3_count_nonzero of the local shard (Engine.set_nnz)
+        self.external_nnz = bool(external_nnz)
         self.device = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
         self.use_graph = use_graph
         self.fold_tail = os.environ.get("DL3_FOLD_TAIL", "1") != "0"  # 0: keep the full-resolution dlogits (test aid)
         self.dw_impl = dw_impl
         self.ops_prep, self.ops_fwd, self.ops_bwd = [], [], []
+        # backward fork (round 3): the 1x1-conv weight gradients are off the critical path until Adam — they leave the
+        # backward chain as a second captured stream (event fork behind the launch that completes their dY, one join at
+        # the end), so that the matrix-pipe-bound weight-gradient kernels share the CUs with the HBM-bound depthwise /
+        # BatchNorm launches of the chain instead of queueing between them.  DL3_FORK=0: one stream.
+        self.fork = os.environ.get("DL3_FORK", "1") != "0"
+        self._side = set()          # id(op record) of the launches that run on the side stream
+        self._side_stream = None
+        self.side_scratch_bytes = 0
+        self._side_scratch_users = []
         self.units = []
         self.views = {}
         self.bufs = []
@@ -202,6 +217,10 @@ class Engine:
         self.scratch = self.empty(max(self.scratch_bytes // 4, 4))
         for op in self._scratch_users:
             op[2][op[3]] = self.scratch.data_ptr()
+        if self._side_scratch_users:  # the side stream's launches are ordered among themselves: one workspace of their own
+            self.side_scratch = self.empty(max(self.side_scratch_bytes // 4, 4))
+            for op in self._side_scratch_users:
+                op[2][op[3]] = self.side_scratch.data_ptr()
         self.dirty = True
 
     # ------------------------------------------------------------------ memory
@@ -331,6 +350,44 @@ class Engine:
         lst.append(rec)
         self._scratch_users.append(rec)
         return rec
+
+    def op_ws_side(self, lst, name, nbytes, ws_index, *args):
+        """op_ws for a launch that may leave the backward chain (see self.fork): its workspace is the side stream's"""
+        if not self.fork:
+            return self.op_ws(lst, name, nbytes, ws_index, *args)
+        self.side_scratch_bytes = max(self.side_scratch_bytes, int(nbytes))
+        rec = (name, getattr(self.lib, name), list(args), ws_index)
+        lst.append(rec)
+        self._side_scratch_users.append(rec)
+        self._side.add(id(rec))
+        return rec
+
+    def run_ops_forked(self, lst):
+        """lst with the launches marked in self._side on a second stream: each one waits for the event recorded on the
+        main stream at its position in the plan (everything it reads is complete there and is never written again within
+        the step), the main stream joins the side stream at the end.  Under hipGraph capture this becomes a parallel
+        branch of the graph."""
+        main = torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        side = self._side_stream
+        mst, sst = main.cuda_stream, side.cuda_stream
+        pending = True  # the main stream has moved on since the side stream last synchronised with it
+        for rec in lst:
+            name, fn, args, _ = rec
+            if id(rec) in self._side:
+                if pending:
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                    pending = False
+                rc = fn(*args, sst)
+            else:
+                rc = fn(*args, mst)
+                pending = True
+            if rc != 0:
+                capi.check(rc, name)
+        main.wait_stream(side)
 
     def transpose(self, src_ptr, dst, rows, cols):
         """queue dst[cols][rows] = src[rows][cols]^T for the batched transpose at the head of the backward pass"""
@@ -484,6 +541,7 @@ class Engine:
             v = View(cbuf, 0, v.C)
         Ho, Wo, N = v.shape[1], v.shape[2], self.phys[id(l.output)]
         buf, off = self._new_out(l, Ho, Wo, N)
+        assert off != 0 or buf.ld == N or id(l) in self.placement, (l.name, buf.ld, N)  # stored width == buffer width
         u = PwUnit(self, l, v, View(buf, off, N), want_stat=self.bn_batch and self._bn_follows(l))
         self._register(u, buf, off)
         self.views[id(l.output)] = View(buf, off, N)
@@ -491,6 +549,13 @@ class Engine:
     def _lo_Subpixel(self, l):
         v = self._in(l)
         r, co = l.cfg["r"], l.cfg["out_filters"]
+        k = l.cfg["k"]
+        if l.cfg["stride"] != 1:
+            raise NotImplementedError("Subpixel with strides != 1 (%s)" % l.name)
+        if k != 1:
+            # subpixel.py:42-58: any kernel_size.  The k x k taps of the input are gathered side by side (dl3_conv_taps_fwd)
+            # and the Keras kernel [k][k][Cin][F], read as a [k*k*Cin][F] matrix, drives the same GEMM as the 1x1 case
+            v = self._taps(l, v, k)
         Ho, Wo, N = v.shape[1], v.shape[2], l.cfg["filters"]
         buf = Buf(self, self.B, Ho, Wo, N, l.name)
         self.bufs.append(buf)
@@ -502,6 +567,19 @@ class Engine:
         self.units.append(s)
         self.views[id(l.output)] = View(obuf, 0, co)
 
+    def _taps(self, l, v, k):
+        N_, H, W, C = v.shape
+        if l.cfg["padding"] == "same":
+            Ho, pt = _same_pads(H, k, 1, 1)
+            Wo, pl = _same_pads(W, k, 1, 1)
+        else:
+            Ho, Wo, pt, pl = H - k + 1, W - k + 1, 0, 0
+        cbuf = Buf(self, self.B, Ho, Wo, k * k * C, l.name + "_taps")
+        self.bufs.append(cbuf)
+        out = View(cbuf, 0, k * k * C)
+        self.units.append(TapsUnit(self, v, out, k, pt, pl))
+        return out
+
     def _lo_conv3x3(self, l, v):
         N_, H, W, Cin = v.shape
         s = l.cfg["stride"]
@@ -511,6 +589,7 @@ class Engine:
         else:
             pt, pl = v.pad or (0, 0)
             Ho, Wo = l.output.shape[0], l.output.shape[1]
+        assert self.phys[id(l.output)] == l.cfg["filters"], "dense 3x3 outputs are stored at their logical width"
         buf, off = self._new_out(l, Ho, Wo, l.cfg["filters"])
         u = Conv3Unit(self, l, v, View(buf, off, l.cfg["filters"]), s, pt, pl,
                       want_stat=self.bn_batch and self._bn_follows(l))
@@ -630,7 +709,8 @@ class Engine:
         buf = v.buf
         M, C = buf.M, v.C
         # loss + dlogits (first and only contribution to the logits buffer)
-        self.op(self.ops_fwd, "dl3_count_nonzero", ptr(self.sweights), M, ptr(self.nnz))
+        if not self.external_nnz:
+            self.op(self.ops_fwd, "dl3_count_nonzero", ptr(self.sweights), M, ptr(self.nnz))
         if self.fused_tail is not None and ((buf.W + 2 * self.fused_tail.inv.buf.W) * C + 2 * buf.W) * 4 <= 65536 and self.fold_tail:
             # the full-resolution gradient never exists: the loss kernel folds each output row onto the low-resolution
             # columns, the resize unit's backward folds the rows
@@ -829,6 +909,18 @@ class Engine:
         else:
             self.sweights.copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(sw, np.float32).reshape(-1))).to(self.device))
 
+    def count_nnz(self):
+        """count(w != 0) of the resident sample weights (device count, one scalar read back)"""
+        tmp = torch.zeros(4, dtype=torch.float32, device=self.device)
+        capi.call("dl3_count_nonzero", ptr(self.sweights), self.logits_view.buf.M, ptr(tmp),
+                  torch.cuda.current_stream().cuda_stream)
+        return float(tmp[0].item())
+
+    def set_nnz(self, value):
+        """external_nnz engines: the normaliser the loss kernel divides by (global count / world, see train_step)"""
+        assert self.external_nnz
+        capi.call("dl3_fill", ptr(self.nnz), float(value), 1, torch.cuda.current_stream().cuda_stream)
+
     def seg_counts(self, y):
         """after forward(): per-image, per-class pixel counts [B,3,C] of the argmax mask against labels y
         (dl3_argmax + dl3_seg_counts on the device; utils.Jaccard_from_counts turns them into the metric)"""
@@ -856,7 +948,7 @@ class Engine:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         self.run_ops(self.ops_fwd)
-                        self.run_ops(self.ops_bwd)
+                        self._run_bwd()
                     self.graph = g
                 except Exception as e:  # pragma: no cover - depends on the runtime
                     print("dl3: hipGraph capture failed (%s); running eagerly" % e)
@@ -866,8 +958,26 @@ class Engine:
             self.graph.replay()
         else:
             self.run_ops(self.ops_fwd)
-            self.run_ops(self.ops_bwd)
+            self._run_bwd()
         self._calls += 1
+
+    def _run_bwd(self):
+        # tuning aid: DL3_BWD_GEMM_PY = workgroup target of the backward chain's GEMM launches only (libdl3.so reads
+        # DL3_GEMM_PY per launch; a smaller grid only ever writes fewer partial rows than were planned)
+        bpy, old = os.environ.get("DL3_BWD_GEMM_PY"), os.environ.get("DL3_GEMM_PY")
+        if bpy:
+            os.environ["DL3_GEMM_PY"] = bpy
+        try:
+            if self.fork and self._side:
+                self.run_ops_forked(self.ops_bwd)
+            else:
+                self.run_ops(self.ops_bwd)
+        finally:
+            if bpy:
+                if old is None:
+                    del os.environ["DL3_GEMM_PY"]
+                else:
+                    os.environ["DL3_GEMM_PY"] = old
 
     def adam(self, opt=None, grad_scale=1.0):
         """Keras Adam with decay (notebook cell 2): lr_t = lr/(1+decay*it) * sqrt(1-b2^t)/(1-b1^t)"""
@@ -898,6 +1008,14 @@ class Engine:
     def train_step(self, x, y, sw=None, opt=None, comm=None):
         self.set_input(x)
         self.set_targets(y, sw)
+        if self.external_nnz:
+            # one loss over the global batch: L = sum_all(l*w) / count_all(w != 0).  Every rank divides by
+            # count_all / world; the all-reduce sums the shard gradients and Adam applies 1/world
+            local = self.count_nnz()
+            if comm is not None and comm.world > 1:
+                self.set_nnz(comm.sum_over_ranks(local) / comm.world)
+            else:
+                self.set_nnz(local)
         self.fwd_bwd()
         scale = 1.0
         if comm is not None:
@@ -949,7 +1067,7 @@ class PwUnit(_ConvBase):
         s, t, a = inv.xform()
         if eng.trainable(self.wname()) or (self.bias and eng.trainable(self.bias)):
             ws = eng.lib.dl3_pwconv_bwd_weight_workspace(M, K, N)
-            eng.op_ws(eng.ops_bwd, "dl3_pwconv_bwd_weight", ws, 17, inv.p(), inv.ld, s, t, a, g, ldg, y, ldy, cA, cB, cC,
+            eng.op_ws_side(eng.ops_bwd, "dl3_pwconv_bwd_weight", ws, 17, inv.p(), inv.ld, s, t, a, g, ldg, y, ldy, cA, cB, cC,
                       eng.gptr(self.wname()), eng.gptr(self.bias) if self.bias else None, M, K, N, 0, ws)
         ibuf = inv.buf
         if not ibuf.requires_grad:
@@ -1207,6 +1325,25 @@ class ShuffleUnit:
         assert add is None and not inv.buf.bns
         eng.op(eng.ops_bwd, "dl3_phase_shift", ptr(self.outv.buf.grad), ptr(gout), eng.B, inv.buf.H, inv.buf.W,
                self.co, self.r, 1)
+
+
+class TapsUnit:
+    """k x k taps of T(x) side by side in front of the GEMM of a Subpixel with kernel_size > 1 (subpixel.py:42-58)"""
+
+    def __init__(self, eng, inv, outv, k, pt, pl):
+        self.eng, self.inv, self.outv = eng, inv, outv
+        eng._consume(inv)
+        s, t, a = inv.xform()
+        self.dims = (eng.B, inv.buf.H, inv.buf.W, inv.C, k, pt, pl, outv.buf.H, outv.buf.W)
+        eng.op(eng.ops_fwd, "dl3_conv_taps_fwd", inv.p(), inv.ld, s, t, a, outv.p(), *self.dims)
+
+    def bwd(self):
+        eng, inv = self.eng, self.inv
+        if not inv.buf.requires_grad:
+            return
+        tmp = eng.empty(inv.buf.M * inv.C)
+        eng.op(eng.ops_bwd, "dl3_conv_taps_bwd", ptr(self.outv.buf.grad), ptr(tmp), *self.dims)
+        eng.contrib_elementwise(inv.buf, inv, ptr(tmp), inv.C)
 
 
 class SubsampleUnit:

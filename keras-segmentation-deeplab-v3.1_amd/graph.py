@@ -460,7 +460,11 @@ class Model:
         """keras Model.compile as used by the notebook (cell 2): remembers the optimizer
         hyper-parameters; the loss on the path is always sparse_crossentropy_ignoring_last_label
         with temporal sample weights (utils.py:127-130)."""
-        self._compiled = dict(optimizer=optimizer, loss=loss, metrics=metrics, sample_weight_mode=sample_weight_mode)
+        from .optimizers import as_adam_dict
+        # optimizer: None (the notebook's Adam(lr=7e-4, epsilon=1e-8, decay=1e-6)), a dict of overrides, 'adam', or an
+        # optimizers.Adam / any Keras-style Adam exposing get_config(); anything else raises here, not at the first step
+        self._compiled = dict(optimizer=as_adam_dict(optimizer), optimizer_object=optimizer, loss=loss, metrics=metrics,
+                              sample_weight_mode=sample_weight_mode)
 
     def distribute(self, dp=None):
         """Per-image data parallelism for train_on_batch / fit: this process is one of WORLD_SIZE (one per GPU, launched
@@ -570,12 +574,15 @@ class Model:
         dp = self._dp
         if dp is not None and dp.world > 1:
             n = x.shape[0]
-            if n % dp.world:
-                raise ValueError("global batch %d does not split over %d ranks" % (n, dp.world))
+            if n < dp.world:
+                raise ValueError("global batch of %d images cannot be split over %d ranks" % (n, dp.world))
+            # a ragged batch (the last one of a Sequence) gives its remainder to the last rank, like the reference's
+            # multi_gpu_model towers; the loss is normalised by the GLOBAL count(w != 0) (Engine.train_step)
             lo, hi = dp.shard(n)
             x, y = x[lo:hi], y[lo:hi]
             if sample_weight is not None:
                 sample_weight = sample_weight[lo:hi]
+            engine_kw = dict(engine_kw, external_nnz=True)
         eng = self._engine(x.shape[0], True, **engine_kw)
         opt = (self._compiled or {}).get("optimizer") or {}
         if dp is None or dp.world == 1:
@@ -586,7 +593,7 @@ class Model:
             eng.dirty = True
             self._dp_synced = True
         loss = eng.train_step(x, y, sample_weight, opt, comm=dp)
-        return dp.mean_over_ranks(loss)
+        return dp.mean_over_ranks(loss)  # = sum_all(l*w) / count_all(w != 0): every rank divided by count_all / world
 
     _IGNORED_FIT_KW = ("workers", "use_multiprocessing", "max_queue_size", "shuffle", "initial_epoch")
 

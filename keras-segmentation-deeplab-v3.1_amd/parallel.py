@@ -75,10 +75,21 @@ class DataParallel:
                       % (L.dl3_last_error().decode() if rc else "this rank was fine"))
         self.backend = "gloo"
 
+    def rccl_ranks(self):
+        """number of ranks RCCL itself reports for the data-plane communicator (None when the data plane is not RCCL)"""
+        if self.comm is None:
+            return None
+        from . import capi
+        n = ctypes.c_int(0)
+        capi.check(capi.lib().dl3_comm_count(self.comm, ctypes.byref(n)), "dl3_comm_count")
+        return int(n.value)
+
     def shard(self, n_global):
-        """contiguous image shard [lo, hi) of this rank (global batch = B * world)"""
+        """contiguous image shard [lo, hi) of this rank; a batch that does not divide evenly gives the remainder to the
+        last rank — keras.utils.multi_gpu_model's get_slice (utils.py:209-211) does the same with its last tower"""
         per = n_global // self.world
-        return self.rank * per, (self.rank + 1) * per
+        lo = self.rank * per
+        return lo, (n_global if self.rank == self.world - 1 else lo + per)
 
     def allreduce_grads(self, flat):
         """sum the flat gradient arena over ranks in place; returns the scale the optimizer must apply"""
@@ -114,6 +125,13 @@ class DataParallel:
             return float(value)
         t = torch.tensor([float(value)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, value):
+        if self.world == 1:
+            return float(value)
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
     def mean_over_ranks(self, value):

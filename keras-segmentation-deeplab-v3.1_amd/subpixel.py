@@ -18,6 +18,16 @@ class Subpixel(G.Conv2D):
 
     def __init__(self, filters, kernel_size, r, padding="valid", strides=(1, 1), activation=None, use_bias=True,
                  kernel_initializer="glorot_uniform", name=None, **kw):
+        st = strides[0] if isinstance(strides, (tuple, list)) else strides
+        ks = kernel_size if isinstance(kernel_size, (tuple, list)) else (kernel_size, kernel_size)
+        if int(st) != 1 or len(set(int(q) for q in ks)) != 1 or int(ks[0]) < 1:
+            raise ValueError("Subpixel: square kernels with strides=1 only (got kernel_size=%r, strides=%r); the "
+                             "reference never uses anything else (utils.py:195)" % (kernel_size, strides))
+        if activation is not None:
+            raise ValueError("Subpixel(activation=%r): fused activations are not on the path (utils.py:195 passes none)"
+                             % (activation,))
+        if padding not in ("same", "valid"):
+            raise ValueError("Subpixel: padding must be 'same' or 'valid'")
         super().__init__(r * r * filters, kernel_size, strides=strides, padding=padding, use_bias=use_bias,
                          activation=activation, name=name)
         self.r = int(r)

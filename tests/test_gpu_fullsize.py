@@ -3,8 +3,9 @@ float64 run of the independent torch restatement (oracle/torch_ref.py) on the sa
 
   cfg2  Deeplabv3(mobilenetv2, 512x512x3, 21)            fwd + loss + bwd, B=2   (deeplabv3p.py:315-444)
   cfg3  SegModel heads 'original' / 'subpixel'            fwd + loss + bwd, B=2   (utils.py:169-214, subpixel.py:41-103)
-  cfg4  Deeplabv3(xception, 512x512x3, 21, OS=8)         forward, B=1            (deeplabv3p.py:272-313,:389-402)
-        + the same architecture fwd + loss + bwd at 320x320, B=2 (40x40 ASPP map: rates 12/24/36 all have live taps)
+  cfg4  Deeplabv3(xception, 512x512x3, 21, OS=8)         forward, B=1 (inference BN); fwd + loss + bwd, B=2 (round 3:
+        64x64 ASPP map, rates 12/24/36 all with live side taps in both directions, 736-wide padded storage, concat
+        slices and decoder under gradients; deeplabv3p.py:272-313,:389-429) + the same at 256x256
 
 Bars (north star): logits <= 1e-3 relative, loss 1e-4, argmax masks bit-exact; gradients by relative L2 against the
 float64 run, bounded by TWICE the distance of the oracle's OWN fp32 run to its float64 run (measured on MI355X, round 2:
@@ -12,8 +13,10 @@ cfg2 whole gradient vector 7.4e-3 on the GPU against 8.3e-3 for torch-fp32; aspp
 1e-3 first asked of the late layers is below what ANY fp32 evaluation of these sums reaches, the float64 oracle shows
 it), and never looser than that.
 "Bit-exact" is checked per pixel: the flip COUNT is printed next to the flip count of the oracle's own fp32 run, and a
-GPU flip is accepted only on a pixel whose float64 top-2 margin lies inside the fp32 rounding distance of the ORACLE
-itself (4 x max|oracle_fp32 - oracle_fp64|) — i.e. a tie that fp32 arithmetic cannot resolve in any summation order.
+GPU flip is accepted only on a pixel (i) whose float64 top-2 margin lies inside the fp32 rounding distance of the ORACLE
+itself (1 x max|oracle_fp32 - oracle_fp64|, round 3; it was 4 x) — a tie that fp32 arithmetic cannot resolve in any
+summation order — and (ii) where the GPU's own logits of the two tied classes are no further from float64 than that
+same distance (a sloppy kernel that flips a real tie by a large error is rejected too).
 """
 import os
 
@@ -31,19 +34,28 @@ pytestmark = pytest.mark.gpu
 torch.set_num_threads(min(32, os.cpu_count() or 1))
 
 
-def _flips(mask, ref64, ref32, what):
-    """argmax parity report + assertion (see module docstring)"""
+def _flips(mask, ref64, ref32, what, got=None):
+    """argmax parity report + assertion (see module docstring); got = the GPU logits the mask was taken from"""
     want = ref64.argmax(-1)
     diff = mask != want
     o32 = ref32.argmax(-1) != want
-    noise = 4.0 * float(np.abs(ref32.astype(np.float64) - ref64).max())
+    noise = float(np.abs(ref32.astype(np.float64) - ref64).max())
     srt = np.sort(ref64, axis=-1)
     margin = srt[..., -1] - srt[..., -2]
     worst = float(margin[diff].max()) if diff.any() else 0.0
-    print("%s: argmax flips gpu %d / oracle-fp32 %d of %d pixels; largest margin at a gpu flip %.3e, fp32 noise "
-          "yardstick %.3e (max|logit| %.3f)" % (what, int(diff.sum()), int(o32.sum()), diff.size, worst, noise,
-                                                float(np.abs(ref64).max())))
+    own = 0.0
+    if got is not None and diff.any():
+        # the GPU's own error on the two classes involved in each flip (float64 winner and the class the GPU picked)
+        g64 = np.asarray(got, np.float64)
+        idx = np.nonzero(diff)
+        ew = np.abs(g64[idx + (want[idx],)] - ref64[idx + (want[idx],)])
+        ep = np.abs(g64[idx + (mask[idx],)] - ref64[idx + (mask[idx],)])
+        own = float(np.maximum(ew, ep).max())
+    print("%s: argmax flips gpu %d / oracle-fp32 %d of %d pixels; largest margin at a gpu flip %.3e, largest gpu logit "
+          "error at a flip %.3e, fp32 noise yardstick (1x) %.3e (max|logit| %.3f)" % (
+              what, int(diff.sum()), int(o32.sum()), diff.size, worst, own, noise, float(np.abs(ref64).max())))
     assert worst <= noise, "argmax flipped on a pixel fp32 can resolve: margin %.3e > %.3e" % (worst, noise)
+    assert own <= noise, "gpu logits at a flipped pixel are %.3e from float64 (> the oracle's own fp32 distance %.3e)" % (own, noise)
     return int(diff.sum())
 
 
@@ -68,6 +80,9 @@ LATE = {
 HEAD_W = {"deeplab": "logits_semantic", "original": "conv_upsample", "subpixel": "subpixel_1"}
 
 
+HEAD_SEED = {"deeplab": 1, "original": 7, "subpixel": 1}  # 'original' shares every shape with 'deeplab': own weights and batch
+
+
 def _train_parity(backbone, shape, head, OS, B, second_oracle=False):
     classes = 21
     import dl3_amd  # noqa: F401
@@ -78,9 +93,9 @@ def _train_parity(backbone, shape, head, OS, B, second_oracle=False):
         model = Deeplabv3(weights=None, input_shape=shape, classes=classes, backbone=backbone, OS=OS)
         params = O.init_params(O.param_shapes(backbone, classes), seed=1)
     else:
-        model, params = _build(backbone, shape, classes, head)
+        model, params = _build(backbone, shape, classes, head, seed=HEAD_SEED[head])
     _load(model, params)
-    x, labels, sw = _data(shape, B, classes)
+    x, labels, sw = _data(shape, B, classes, seed=0 if HEAD_SEED[head] == 1 else HEAD_SEED[head])
     kw = dict(backbone=backbone, input_shape=shape, classes=classes, OS=OS, head=head)
     eng = model._engine(B, True, dropout=False, use_graph=False)
     eng.set_input(x)
@@ -110,7 +125,7 @@ def _train_parity(backbone, shape, head, OS, B, second_oracle=False):
         tag, e, relerr(logits32, logits), got_loss, loss))
     assert e < 1e-3
     assert abs(got_loss - loss) < 1e-4 * abs(loss)
-    _flips(got_logits.argmax(-1), logits, logits32, tag)
+    _flips(got_logits.argmax(-1), logits, logits32, tag, got=got_logits)
     assert np.array_equal(eng.argmax(), got_logits.argmax(-1))  # dl3_argmax == np.argmax on the same logits
     num = den = n32 = 0.0
     worst, wname = 0.0, None
@@ -172,7 +187,7 @@ def test_cfg4_xception_os8_512_forward():
     e = relerr(got, ref)
     print("xception OS=8 512x512 forward: logits rel err %.2e (oracle fp32: %.2e)" % (e, relerr(ref32, ref)))
     assert e < 1e-3
-    _flips(model._active.argmax(), ref, ref32, "xception OS=8 512x512 B=1")
+    _flips(model._active.argmax(), ref, ref32, "xception OS=8 512x512 B=1", got=got)
     assert np.allclose(probs.reshape(ref.shape), O.softmax(ref), atol=1e-3 * float(np.abs(ref).max()))
 
 
@@ -181,3 +196,11 @@ def test_cfg4_xception_os8_256_train_step():
     GPU box's host (256x256, B=2: 32x32 ASPP map — the rate-12 and rate-24 branches have live side taps; rate 36 with
     live taps is covered by the 512x512 forward above and by the 64x64x2048 operator cases of test_gpu_ops.py)."""
     _train_parity("xception", (256, 256, 3), "deeplab", 8, 2)
+
+
+def test_cfg4_xception_os8_512_train_step():
+    """BASELINE.json configs[3] at the size it is quoted on, fwd + loss + bwd, B=2 (deeplabv3p.py:272-313,:389-429):
+    the 64x64x2048 ASPP map gives the rate-12/24/36 depthwise branches live side taps forward AND backward inside the
+    model wiring (736-wide padded tensors, zero-copy concat slices, decoder).  The float64 run of the torch oracle
+    takes minutes on the host: the slowest test of the suite by far."""
+    _train_parity("xception", (512, 512, 3), "deeplab", 8, 2)

@@ -607,3 +607,88 @@ def test_learns_a_toy_segmentation_task():
     assert after[1] > 0.9, (before, after)                          # pixel accuracy
     loss, jac, acc = model.evaluate(imgs.astype(np.float32), Yall, batch_size=8)   # inference path stays consistent
     assert np.isfinite(loss) and 0.0 <= jac <= 1.0 and 0.0 <= acc <= 1.0
+
+
+@pytest.mark.parametrize("k,padding", [(3, "same"), (2, "valid"), (3, "valid")])
+def test_subpixel_with_kernel_size_above_one(k, padding):
+    """Subpixel IS a Conv2D with any kernel_size (subpixel.py:42-58; icnr_weights' default shape is 3x3, :9): round 2
+    silently lowered kernel_size != 1 as a 1x1 GEMM.  Forward, loss and every gradient of a small graph
+    conv3x3/s2 -> BN -> relu -> Subpixel(3, k, r=2) -> softmax against a float64 torch-autograd restatement written
+    here (TF SAME padding, the reference's own phase shift, Keras weighted cross-entropy)."""
+    import torch.nn.functional as F
+    import dl3_amd  # noqa: F401
+    from dl3_amd import graph as G
+    from dl3_amd.subpixel import Subpixel, icnr_weights
+    G.clear_session(seed=5)
+    H, W, B, r, classes, mid = 16, 24, 2, 2, 3, 8
+    inp = G.Input(shape=(H, W, 3))
+    x = G.Conv2D(mid, 3, strides=2, padding="same", use_bias=False, name="c0")(inp)
+    x = G.BatchNormalization(name="c0_BN", epsilon=1e-3)(x)
+    x = G.Activation("relu")(x)
+    x = Subpixel(classes, k, r, padding=padding, name="sp")(x)
+    Hs, Ws = x.shape[0], x.shape[1]
+    x = G.Reshape((Hs * Ws, -1))(x)
+    x = G.Activation("softmax", name="pred_mask")(x)
+    model = G.Model(inp, x, name="sp_test")
+    sp = [l for l in model.layers if l.name == "sp"][0]
+    kern, bias = sp.get_weights()
+    assert kern.shape == (k, k, mid, classes * r * r)
+    rng = np.random.default_rng(11)
+    sp.set_weights([icnr_weights(scale=r, shape=kern.shape), rng.normal(0, 0.1, bias.shape).astype(np.float32)])
+    xin = rng.normal(0, 1, (B, H, W, 3)).astype(np.float32)
+    labels = rng.integers(0, classes + 1, (B, Hs * Ws)).astype(np.float32)
+    sw = ((labels < classes) * rng.uniform(0.5, 2.0, labels.shape)).astype(np.float32)
+    eng = model._engine(B, True, dropout=False, use_graph=False)
+    eng.set_input(xin)
+    eng.set_targets(labels, sw)
+    eng.fwd_bwd()
+    torch.cuda.synchronize()
+    # ---- float64 restatement
+    P = {n: torch.tensor(np.asarray(w, np.float64), requires_grad=True) for l in model.layers for n, w in l.weights.items()
+         if "/moving_" not in n}
+    xt = torch.tensor(xin.astype(np.float64)).permute(0, 3, 1, 2)
+    a = F.conv2d(F.pad(xt, (0, 1, 0, 1)), P["c0/kernel:0"].permute(3, 2, 0, 1), stride=2)  # SAME, even size: pad at the end
+    mu, var = a.mean((0, 2, 3), keepdim=True), a.var((0, 2, 3), unbiased=False, keepdim=True)
+    a = (a - mu) / torch.sqrt(var + 1e-3) * P["c0_BN/gamma:0"].view(1, -1, 1, 1) + P["c0_BN/beta:0"].view(1, -1, 1, 1)
+    a = torch.relu(a)
+    if padding == "same":
+        a = F.pad(a, ((k - 1) // 2, k - 1 - (k - 1) // 2) * 2)
+    y = F.conv2d(a, P["sp/kernel:0"].permute(3, 2, 0, 1)) + P["sp/bias:0"].view(1, -1, 1, 1)
+    y = y.permute(0, 2, 3, 1)                                             # [N, a, b, C*r*r]
+    Nn, Ha, Wb, _ = y.shape
+    # out[n, ia*r+q, ib*r+p, ch] = I[n, ia, ib, ch*r*r + p*r + q]  (subpixel.py:77-88)
+    y = y.reshape(Nn, Ha, Wb, classes, r, r).permute(0, 1, 5, 2, 4, 3).reshape(Nn, Ha * r, Wb * r, classes)
+    assert (Ha * r, Wb * r) == (Hs, Ws)
+    logits = y.reshape(Nn, Hs * Ws, classes)
+    t = torch.tensor(labels.astype(np.int64))
+    w = torch.tensor(sw.astype(np.float64))
+    p = torch.softmax(logits, -1)
+    pt = torch.gather(p, 2, t.clamp(max=classes - 1).unsqueeze(-1)).squeeze(-1).clamp(1e-7, 1 - 1e-7)
+    ell = torch.where(t < classes, -torch.log(pt), torch.zeros_like(pt))
+    loss = (ell * w).sum() / (w != 0).sum()
+    loss.backward()
+    got = eng.logits().reshape(Nn, Hs * Ws, classes)
+    assert relerr(got, logits.detach().numpy()) < 1e-4
+    assert abs(float(eng.loss[0].item()) - float(loss)) < 1e-5 * abs(float(loss))
+    for n, pt_ in P.items():
+        e = _l2(eng.grad_of(n), pt_.grad.numpy())
+        print("   %-16s grad rel-L2 %.2e" % (n, e))
+        assert e < 2e-4, (n, e)
+
+
+def test_compile_accepts_the_references_adam_object():
+    """segmentation.ipynb cell 2: compile(optimizer=Adam(lr=7e-4, epsilon=1e-8, decay=1e-6), ...) — the object and the
+    equivalent dict must train identically (bit for bit: same launches, same scalars)."""
+    from dl3_amd.optimizers import Adam
+    rng = np.random.default_rng(4)
+    x = rng.integers(0, 256, (2, 64, 64, 3)).astype(np.float32)
+    y = rng.integers(0, 3, (2, 64 * 64, 1)).astype(np.float32)
+    outs = []
+    for opt in (Adam(lr=7e-4, epsilon=1e-8, decay=1e-6), dict(lr=7e-4, epsilon=1e-8, decay=1e-6)):
+        model, params = _build(input_shape=(64, 64, 3), classes=3)
+        _load(model, params)
+        model.compile(optimizer=opt, sample_weight_mode="temporal", loss="sparse_crossentropy_ignoring_last_label")
+        losses = [model.train_on_batch(x, y, dropout=False) for _ in range(3)]
+        outs.append((losses, model._active.params.cpu().numpy().copy()))
+    assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
+    assert outs[0][0][-1] < outs[0][0][0]

@@ -92,8 +92,11 @@ def test_two_engine_processes_allreduce_equals_mean_of_shards(tmp_path):
     # single-process replay of both shards: step 1 from rank 0's initial weights, then the same Adam update
     x, y, sw = _data()
     model = _model(seed=1)
-    engs = [model._engine(2, True, use_graph=False, rank=r) for r in (0, 1)]
+    # external_nnz: the loss is normalised by the GLOBAL count(w != 0) (one loss over the merged batch, like the
+    # reference's multi_gpu_model): every rank divides by count_all / world
+    engs = [model._engine(2, True, use_graph=False, rank=r, external_nnz=True) for r in (0, 1)]
     shard = lambda r: (x[2 * r:2 * r + 2], y[2 * r:2 * r + 2], sw[2 * r:2 * r + 2])
+    nnz_all = float((sw != 0).sum())
     p0 = engs[1].params.clone()
     for step in range(2):
         g = []
@@ -102,6 +105,8 @@ def test_two_engine_processes_allreduce_equals_mean_of_shards(tmp_path):
             xs, ys, ws = shard(r)
             e.set_input(xs)
             e.set_targets(ys, ws)
+            assert e.count_nnz() == float((ws != 0).sum())
+            e.set_nnz(nnz_all / 2)
             e.fwd_bwd()
             torch.cuda.synchronize()
             g.append(e.grads.cpu().numpy().copy())
@@ -114,6 +119,61 @@ def test_two_engine_processes_allreduce_equals_mean_of_shards(tmp_path):
         e.adam(dict(lr=7e-4), 0.5)
         p0 = e.params.clone()
     assert np.array_equal(r0["params"], p0.cpu().numpy())
+
+
+def _ragged_data():
+    """5 images over 2 ranks (2 + 3), very different void fractions per shard"""
+    rng = np.random.default_rng(3)
+    n = 5
+    x = rng.integers(0, 256, (n,) + SHAPE).astype(np.float32)
+    y = rng.integers(0, CLASSES, (n, SHAPE[0] * SHAPE[1], 1)).astype(np.float32)
+    y[:2][rng.uniform(size=y[:2].shape) < 0.7] = CLASSES      # rank 0's shard: 70 % void
+    y[2:][rng.uniform(size=y[2:].shape) < 0.1] = CLASSES      # rank 1's shard: 10 % void
+    sw = ((y[:, :, 0] < CLASSES) * rng.uniform(0.5, 2.0, y.shape[:2])).astype(np.float32)
+    return x, y, sw
+
+
+def _worker_global_loss(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), DL3_DIST_BACKEND="gloo")
+    torch.cuda.set_device(0)
+    model = _model(seed=1)
+    model.compile(optimizer=dict(lr=7e-4))
+    model.distribute()
+    x, y, sw = _ragged_data()
+    loss = model.train_on_batch(x, y, sw, use_graph=False, bn_mode="frozen", dropout=False)
+    eng = model._active
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "g%d.npz" % rank), grads=eng.grads.cpu().numpy(), loss=np.array([loss]), B=np.array([eng.B]))
+    model._dp.close()
+
+
+def test_data_parallel_loss_is_the_global_batch_loss(tmp_path):
+    """ADVICE r2: the reference's multi_gpu_model merges the towers and evaluates ONE loss, sum(l*w) / count_all(w != 0);
+    with unequal void fractions per shard a per-rank normalisation gives a different gradient.  With frozen BatchNorm
+    (no per-replica batch statistics) the 2-rank step on a RAGGED global batch (5 = 2 + 3 images) must equal the
+    single-process step on the same 5 images: loss and all-reduced gradient (up to fp32 summation order)."""
+    mp.spawn(_worker_global_loss, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = [np.load(str(tmp_path / ("g%d.npz" % r))) for r in (0, 1)]
+    assert (int(r0["B"][0]), int(r1["B"][0])) == (2, 3)
+    assert np.array_equal(r0["grads"], r1["grads"]) and r0["loss"][0] == r1["loss"][0]
+    x, y, sw = _ragged_data()
+    model = _model(seed=1)
+    eng = model._engine(5, True, use_graph=False, bn_mode="frozen", dropout=False)
+    eng.set_input(x)
+    eng.set_targets(y, sw)
+    eng.fwd_bwd()
+    torch.cuda.synchronize()
+    want = eng.grads.cpu().numpy()
+    got = r0["grads"] * np.float32(0.5)   # what Adam applies: the summed arena x 1/world
+    err = np.linalg.norm(got - want) / np.linalg.norm(want)
+    print("2-rank ragged step vs single process: loss %.7f vs %.7f, gradient rel-L2 %.2e" % (
+        float(r0["loss"][0]), float(eng.loss[0].item()), err))
+    assert abs(float(r0["loss"][0]) - float(eng.loss[0].item())) < 1e-5 * abs(float(eng.loss[0].item()))
+    assert err < 1e-4
+    # and it is NOT what per-rank normalisation would give: shard losses weighted by their own counts differ
+    n0, n1 = float((sw[:2] != 0).sum()), float((sw[2:] != 0).sum())
+    assert abs(n0 - n1) > 0.3 * (n0 + n1) / 2
 
 
 def test_rccl_binding_world_of_one():

@@ -261,3 +261,54 @@ def test_stored_channel_plan():
         if l.kind == "Concatenate":
             assert phys[id(l.output)] == l.output.shape[-1]
             assert all(phys[id(t)] == t.shape[-1] for t in l.inbound)
+
+
+def test_adam_shim_and_compile_surface():
+    """segmentation.ipynb cell 2 compiles with keras.optimizers.Adam(lr=7e-4, epsilon=1e-8, decay=1e-6): compile takes
+    the object, a dict, 'adam' or None — and rejects everything else AT compile time"""
+    import dl3_amd  # noqa: F401
+    from dl3_amd import graph as G
+    from dl3_amd.deeplabv3p import Deeplabv3
+    from dl3_amd.optimizers import Adam, as_adam_dict
+    a = Adam(lr=7e-4, epsilon=1e-8, decay=1e-6)
+    assert a.get_config() == dict(lr=7e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-8, decay=1e-6, amsgrad=False)
+    assert Adam().get_config()["epsilon"] == 1e-7 and Adam().lr == 0.001      # Keras 2.2.4 defaults
+    assert Adam.from_config(a.get_config()).get_config() == a.get_config()
+    assert as_adam_dict(None) == {} and as_adam_dict("adam")["lr"] == 0.001
+    assert as_adam_dict(dict(lr=1e-3)) == {"lr": 1e-3}
+    G.clear_session()
+    m = Deeplabv3(weights=None, input_shape=(64, 64, 3), classes=3, backbone="mobilenetv2")
+    m.compile(optimizer=a, sample_weight_mode="temporal", loss="whatever", metrics=[])
+    assert m._compiled["optimizer"] == dict(lr=7e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-8, decay=1e-6)
+    assert m._compiled["optimizer_object"] is a
+    for bad in (object(), 3.0, "sgd", dict(learning_rate=1.0)):
+        with pytest.raises((TypeError, ValueError)):
+            m.compile(optimizer=bad)
+    with pytest.raises(ValueError):
+        Adam(amsgrad=True)
+
+    class SGD:  # a Keras-style optimizer that is not Adam
+        def get_config(self):
+            return dict(lr=0.1)
+    with pytest.raises(ValueError):
+        m.compile(optimizer=SGD())
+
+
+def test_subpixel_constructor_contract():
+    """subpixel.py:42-58: any square kernel_size builds a [k,k,Cin,r*r*filters] kernel (the engine lowers it through the
+    k x k tap gather, tests/test_gpu_model.py::test_subpixel_with_kernel_size_above_one); what is not on the path raises"""
+    import dl3_amd  # noqa: F401
+    from dl3_amd import graph as G
+    from dl3_amd.subpixel import Subpixel
+    G.clear_session()
+    t = G.Input(shape=(8, 8, 5))
+    l = Subpixel(3, 3, 2, padding="same", name="sp3")
+    out = l(t)
+    assert out.shape == (16, 16, 3) and l.weights["sp3/kernel:0"].shape == (3, 3, 5, 12)
+    out = Subpixel(3, (2, 2), 2, padding="valid", name="sp2")(G.Input(shape=(8, 8, 5)))
+    assert out.shape == (14, 14, 3)
+    for kw in (dict(strides=(2, 2)), dict(activation="relu"), dict(padding="causal")):
+        with pytest.raises(ValueError):
+            Subpixel(3, 3, 2, **kw)
+    with pytest.raises(ValueError):
+        Subpixel(3, (3, 1), 2)

@@ -120,3 +120,55 @@ def test_ranks_agree_when_the_rccl_communicator_fails_on_one_of_them(tmp_path):
         assert str(r["backend"]) == "gloo" and bool(r["comm"]) and bool(r["warned"])
         assert np.allclose(r["g"], 1.5)
     assert int(r0["destroyed"]) == 1 and int(r1["destroyed"]) == 0
+
+
+def _ragged():
+    rng = np.random.default_rng(5)
+    x = rng.integers(0, 256, (5, 32, 32, 3)).astype(np.float32)
+    labels = rng.integers(0, 3, (5, 32, 32)).astype(np.float32)
+    labels[:2][rng.uniform(size=labels[:2].shape) < 0.7] = 3   # rank 0's shard is mostly void
+    w = ((labels < 3) * rng.uniform(0.5, 2.0, labels.shape)).astype(np.float32)
+    return x, labels, w
+
+
+def _worker_global_nnz(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import dl3_amd  # noqa: F401
+    from dl3_amd.parallel import DataParallel
+    dp = DataParallel(backend="gloo")
+    x, labels, w = _ragged()
+    lo, hi = dp.shard(x.shape[0])
+    params = O.init_params(O.param_shapes("mobilenetv2", 3), seed=1)
+    names = sorted(n for n in params if "/moving_" not in n)
+    loss, grads, _, _ = O.train_grads(params, x[lo:hi], labels[lo:hi], w[lo:hi], bn_frozen=True, **KW)
+    # what Engine.train_step does with external_nnz: the loss kernel divides by count_all / world instead of the
+    # shard's own count (the oracle normalised by the local count: rescale)
+    local = float((w[lo:hi] != 0).sum())
+    denom = dp.sum_over_ranks(local) / dp.world
+    flat_g = torch.from_numpy(_flat(grads, names) * np.float32(local / denom))
+    scale = dp.allreduce_grads(flat_g)
+    mean_loss = dp.mean_over_ranks(loss * local / denom)
+    np.savez(os.path.join(out_dir, "n%d.npz" % rank), g=flat_g.numpy() * scale, lo=lo, hi=hi, loss=mean_loss)
+    dp.close()
+
+
+def test_global_loss_normalisation_over_a_ragged_batch(tmp_path):
+    """parallel.DataParallel.shard / sum_over_ranks + the rule of Engine.train_step(external_nnz): 5 images over 2
+    ranks (2 + 3, the remainder on the last rank like multi_gpu_model's last tower), unequal void fractions; with
+    frozen BatchNorm the exchanged gradient and the reported loss equal the single-process step on all 5 images."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_global_nnz, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = [np.load(os.path.join(str(tmp_path), "n%d.npz" % r)) for r in (0, 1)]
+    assert (int(r0["lo"]), int(r0["hi"]), int(r1["lo"]), int(r1["hi"])) == (0, 2, 2, 5)
+    assert np.array_equal(r0["g"], r1["g"])
+    x, labels, w = _ragged()
+    params = O.init_params(O.param_shapes("mobilenetv2", 3), seed=1)
+    names = sorted(n for n in params if "/moving_" not in n)
+    loss, grads, _, _ = O.train_grads(params, x, labels, w, bn_frozen=True, **KW)
+    want = _flat(grads, names)
+    assert np.allclose(r0["g"], want, rtol=1e-4, atol=1e-6 * np.abs(want).max())
+    assert abs(float(r0["loss"]) - loss) < 1e-6 * abs(loss)
