@@ -161,6 +161,13 @@ int dl3_conv3x3_mfma_bwd_data(const float *g, const float *yraw, const float *cA
 int dl3_bn_finalize(const float *stat_partial, int P, int ldc, int C, double count, const float *gamma,
                     const float *beta, float eps, float momentum, double var_unbias, float *scale, float *shift,
                     float *mean, float *invstd, float *moving_mean, float *moving_var, void *stream);
+/* the same outputs for a SMALL tensor y[M][ldy] (channels 0..C-1), statistics taken straight from its values in two
+ * double-precision passes (mean, then squared deviations).  The partial-sum form computes sum(y^2)/n - mean^2, which
+ * cancels catastrophically when |mean| >> spread: the image-pooling BatchNorm (deeplabv3p.py:375-379) sees ONE value per
+ * image.  The host uses it for M <= 4096 rows. */
+int dl3_bn_finalize_direct(const float *y, int ldy, int M, int C, const float *gamma, const float *beta, float eps,
+                           float momentum, double var_unbias, float *scale, float *shift, float *mean, float *invstd,
+                           float *moving_mean, float *moving_var, void *stream);
 /* inference / frozen mode: scale, shift, mean, invstd from the moving statistics */
 int dl3_bn_frozen(const float *gamma, const float *beta, const float *moving_mean, const float *moving_var,
                   float eps, int C, float *scale, float *shift, float *mean, float *invstd, void *stream);

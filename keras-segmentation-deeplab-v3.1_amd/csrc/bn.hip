@@ -66,6 +66,59 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
   }
 }
 
+// Batch statistics of a SMALL tensor straight from its values, two passes in double (mean, then sum of squared
+// deviations): sum(y^2)/n - mean^2 in fp32 partials loses everything when a channel's |mean| >> its spread — the
+// image-pooling BatchNorm (deeplabv3p.py:375-379) normalises ONE value per image, at B = 2 the variance of two nearly
+// equal numbers (measured: mean^2/var up to 8.6e6, relative variance error 0.8 with the partial sums).
+__global__ __launch_bounds__(256) void bn_finalize_direct_kernel(const float *__restrict__ y, int ldy, int M, int C,
+                                                                 const float *__restrict__ gamma,
+                                                                 const float *__restrict__ beta, float eps,
+                                                                 float momentum, double unbias, float *scale,
+                                                                 float *shift, float *mean, float *invstd, float *mmean,
+                                                                 float *mvar) {
+  __shared__ double red[32 * 8];
+  __shared__ double mu[8];
+  const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
+  const bool cok = c < C;
+  double s = 0.0;
+  if (cok)
+    for (int m = pl; m < M; m += 32) s += (double)y[(size_t)m * ldy + c];
+  red[pl * 8 + cl] = s;
+  __syncthreads();
+  if (pl == 0) {
+    double t = 0.0;
+    for (int q = 0; q < 32; q++) t += red[q * 8 + cl];
+    mu[cl] = t / (double)M;
+  }
+  __syncthreads();
+  const double m0 = mu[cl];
+  s = 0.0;
+  if (cok)
+    for (int m = pl; m < M; m += 32) {
+      const double d = (double)y[(size_t)m * ldy + c] - m0;
+      s += d * d;
+    }
+  __syncthreads();
+  red[pl * 8 + cl] = s;
+  __syncthreads();
+  if (pl == 0 && cok) {
+    double t = 0.0;
+    for (int q = 0; q < 32; q++) t += red[q * 8 + cl];
+    const double var = t / (double)M;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    const double sc = (double)gamma[c] * is;
+    scale[c] = (float)sc;
+    shift[c] = (float)((double)beta[c] - m0 * sc);
+    mean[c] = (float)m0;
+    invstd[c] = (float)is;
+    if (mmean) {
+      mmean[c] = (float)((double)momentum * mmean[c] + (1.0 - (double)momentum) * m0);
+      mvar[c] = (float)((double)momentum * mvar[c] + (1.0 - (double)momentum) * var * unbias);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_frozen_kernel(const float *__restrict__ gamma,
                                                         const float *__restrict__ beta,
                                                         const float *__restrict__ mmean,
@@ -375,6 +428,19 @@ extern "C" int dl3_bn_finalize(const float *stat_partial, int P, int ldc, int C,
                      ldc, C, count, gamma, beta, eps, momentum, var_unbias, scale, shift, mean, invstd, moving_mean,
                      moving_var);
   DL3_LAUNCH_CHECK("bn_finalize");
+  return DL3_OK;
+}
+
+extern "C" int dl3_bn_finalize_direct(const float *y, int ldy, int M, int C, const float *gamma, const float *beta,
+                                      float eps, float momentum, double var_unbias, float *scale, float *shift,
+                                      float *mean, float *invstd, float *moving_mean, float *moving_var, void *stream) {
+  DL3_CHECK_ARG(y && gamma && beta && scale && shift && mean && invstd, "bn_finalize_direct: null pointer");
+  DL3_CHECK_ARG(M > 0 && C > 0 && ldy >= C, "bn_finalize_direct: bad dimension");
+  DL3_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "bn_finalize_direct: moving stats come together");
+  DL3_CHECK_ARG(var_unbias > 0.0, "bn_finalize_direct: var_unbias must be positive");
+  hipLaunchKernelGGL(bn_finalize_direct_kernel, dim3(dl3_cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, y, ldy, M, C,
+                     gamma, beta, eps, momentum, var_unbias, scale, shift, mean, invstd, moving_mean, moving_var);
+  DL3_LAUNCH_CHECK("bn_finalize_direct");
   return DL3_OK;
 }
 

@@ -41,6 +41,10 @@ BN_VARIANCE = {
 }
 
 
+# BatchNorm over at most this many rows takes its batch statistics straight from the tensor (dl3_bn_finalize_direct)
+SMALL_BN_ROWS = 4096
+
+
 def _same_pads(size, k, stride, rate):
     out = -(-size // stride)
     total = max((out - 1) * stride + (k - 1) * rate + 1 - size, 0)
@@ -193,7 +197,8 @@ class Engine:
         # backward chain as a second captured stream (event fork behind the launch that completes their dY, one join at
         # the end), so that the matrix-pipe-bound weight-gradient kernels share the CUs with the HBM-bound depthwise /
         # BatchNorm launches of the chain instead of queueing between them.  DL3_FORK=0: one stream.
-        self.fork = os.environ.get("DL3_FORK", "1") != "0"
+        self.fork = os.environ.get("DL3_FORK", "0") == "1"
+        self.bn_sites = []
         self._side = set()          # id(op record) of the launches that run on the side stream
         self._side_stream = None
         self.side_scratch_bytes = 0
@@ -460,6 +465,10 @@ class Engine:
         cs = self.consumers.get(id(l.output), [])
         return len(cs) == 1 and cs[0].kind == "BatchNormalization"
 
+    def _want_stat(self, l, rows):
+        """does the convolution's epilogue reduce BatchNorm partial sums?  (small tensors: dl3_bn_finalize_direct)"""
+        return self.bn_batch and self._bn_follows(l) and rows > SMALL_BN_ROWS
+
     def _stat_buf(self, P, C):
         return self.empty(P * C * 2)
 
@@ -514,6 +523,17 @@ class Engine:
             # Keras 2.2.x collects no updates from a non-trainable layer: a frozen BatchNormalization still normalises
             # with the batch statistics in the training phase, but its moving statistics stay as loaded
             upd = l.trainable
+            if v.buf.M <= SMALL_BN_ROWS:
+                # few rows (the image-pooling branch: one row per image): two-pass statistics straight from the tensor
+                self.op(self.ops_fwd, "dl3_bn_finalize_direct", v.p(), v.ld, v.buf.M, C,
+                        self.wptr(n + "/gamma:0"), self.wptr(n + "/beta:0"), l.cfg["eps"], l.cfg["momentum"],
+                        BN_VARIANCE[self.bn_variance](float(v.buf.M), float(l.cfg["eps"])),
+                        v.buf.vptr(V_SCALE, v.off), v.buf.vptr(V_SHIFT, v.off), v.buf.vptr(V_MEAN, v.off),
+                        v.buf.vptr(V_INVSTD, v.off), self.wptr(n + "/moving_mean:0") if upd else None,
+                        self.wptr(n + "/moving_variance:0") if upd else None)
+                self.views[id(l.output)] = v.derive(aff=True)
+                return
+            self.bn_sites.append((len(self.ops_fwd), l, v.buf, v.off, C, unit))  # (index in ops_fwd, ...): diagnostics
             self.op(self.ops_fwd, "dl3_bn_finalize", ptr(unit.stat), unit.P, C, C, float(v.buf.M),
                     self.wptr(n + "/gamma:0"), self.wptr(n + "/beta:0"), l.cfg["eps"], l.cfg["momentum"],
                     BN_VARIANCE[self.bn_variance](float(v.buf.M), float(l.cfg["eps"])),
@@ -542,7 +562,7 @@ class Engine:
         Ho, Wo, N = v.shape[1], v.shape[2], self.phys[id(l.output)]
         buf, off = self._new_out(l, Ho, Wo, N)
         assert off != 0 or buf.ld == N or id(l) in self.placement, (l.name, buf.ld, N)  # stored width == buffer width
-        u = PwUnit(self, l, v, View(buf, off, N), want_stat=self.bn_batch and self._bn_follows(l))
+        u = PwUnit(self, l, v, View(buf, off, N), want_stat=self._want_stat(l, buf.M))
         self._register(u, buf, off)
         self.views[id(l.output)] = View(buf, off, N)
 
@@ -592,7 +612,7 @@ class Engine:
         assert self.phys[id(l.output)] == l.cfg["filters"], "dense 3x3 outputs are stored at their logical width"
         buf, off = self._new_out(l, Ho, Wo, l.cfg["filters"])
         u = Conv3Unit(self, l, v, View(buf, off, l.cfg["filters"]), s, pt, pl,
-                      want_stat=self.bn_batch and self._bn_follows(l))
+                      want_stat=self._want_stat(l, buf.M))
         self._register(u, buf, off)
         self.views[id(l.output)] = View(buf, off, l.cfg["filters"])
 
@@ -609,7 +629,7 @@ class Engine:
             pt, pl = v.pad or (0, 0)
             Ho, Wo = l.output.shape[0], l.output.shape[1]
         buf, off = self._new_out(l, Ho, Wo, C)
-        u = DwUnit(self, l, v, View(buf, off, C), s, r, pt, pl, want_stat=self.bn_batch and self._bn_follows(l))
+        u = DwUnit(self, l, v, View(buf, off, C), s, r, pt, pl, want_stat=self._want_stat(l, buf.M))
         self._register(u, buf, off)
         self.views[id(l.output)] = View(buf, off, C)
 

@@ -13,10 +13,11 @@ cfg2 whole gradient vector 7.4e-3 on the GPU against 8.3e-3 for torch-fp32; aspp
 1e-3 first asked of the late layers is below what ANY fp32 evaluation of these sums reaches, the float64 oracle shows
 it), and never looser than that.
 "Bit-exact" is checked per pixel: the flip COUNT is printed next to the flip count of the oracle's own fp32 run, and a
-GPU flip is accepted only on a pixel (i) whose float64 top-2 margin lies inside the fp32 rounding distance of the ORACLE
-itself (1 x max|oracle_fp32 - oracle_fp64|, round 3; it was 4 x) — a tie that fp32 arithmetic cannot resolve in any
-summation order — and (ii) where the GPU's own logits of the two tied classes are no further from float64 than that
-same distance (a sloppy kernel that flips a real tie by a large error is rejected too).
+GPU flip is accepted only on a pixel where the GPU's OWN logits of the two classes involved (the float64 winner and the
+class the GPU picked) are no further from float64 than eps = max|oracle_fp32 - oracle_fp64|, the largest error the
+oracle's own fp32 run commits anywhere (round 3; round 2 compared the margin with 4 eps and never looked at the GPU's
+error).  A flip needs err_winner + err_picked >= margin, so this bounds the margin of every accepted flip by 2 eps — a
+tie an fp32 evaluation as good as the oracle's cannot resolve — and rejects a kernel that flips a tie by being sloppy.
 """
 import os
 
@@ -54,8 +55,9 @@ def _flips(mask, ref64, ref32, what, got=None):
     print("%s: argmax flips gpu %d / oracle-fp32 %d of %d pixels; largest margin at a gpu flip %.3e, largest gpu logit "
           "error at a flip %.3e, fp32 noise yardstick (1x) %.3e (max|logit| %.3f)" % (
               what, int(diff.sum()), int(o32.sum()), diff.size, worst, own, noise, float(np.abs(ref64).max())))
-    assert worst <= noise, "argmax flipped on a pixel fp32 can resolve: margin %.3e > %.3e" % (worst, noise)
-    assert own <= noise, "gpu logits at a flipped pixel are %.3e from float64 (> the oracle's own fp32 distance %.3e)" % (own, noise)
+    if got is not None:
+        assert own <= noise, "gpu logits at a flipped pixel are %.3e from float64 (> the oracle's own fp32 distance %.3e)" % (own, noise)
+    assert worst <= 2.0 * noise, "argmax flipped on a pixel fp32 can resolve: margin %.3e > 2 x %.3e" % (worst, noise)
     return int(diff.sum())
 
 
@@ -129,6 +131,7 @@ def _train_parity(backbone, shape, head, OS, B, second_oracle=False):
     assert np.array_equal(eng.argmax(), got_logits.argmax(-1))  # dl3_argmax == np.argmax on the same logits
     num = den = n32 = 0.0
     worst, wname = 0.0, None
+    ratios = {}
     for name, g in grads.items():
         if g is None or np.abs(g).max() < 1e-9:
             continue
@@ -137,11 +140,21 @@ def _train_parity(backbone, shape, head, OS, B, second_oracle=False):
         n32 += float(np.sum((grads32[name].astype(np.float64) - g) ** 2))
         den += float(np.sum(g ** 2))
         el = _l2(got, g)
+        e32 = _l2(grads32[name], g)
+        if e32 > 0:
+            ratios[name] = el / e32
         if el > worst and np.linalg.norm(g) > 1e-6 * np.sqrt(den):
             worst, wname = el, name
     whole, whole32 = np.sqrt(num / den), np.sqrt(n32 / den)
     print("%s: gradient rel-L2 whole vector gpu %.2e / oracle-fp32 %.2e; worst tensor %s %.2e" % (
         tag, whole, whole32, wname, worst))
+    # is the GPU a systematically worse fp32 evaluation than torch-fp32, or another draw of the same rounding noise?
+    # per-tensor ratio (gpu distance to float64) / (torch-fp32 distance to float64), by kind of weight
+    for kind in ("/gamma:0", "/beta:0", "/kernel:0", "/depthwise_kernel:0"):
+        r = np.array([v for k, v in ratios.items() if k.endswith(kind)])
+        if r.size:
+            print("   per-tensor error ratio gpu / oracle-fp32, %-20s n=%3d  geo-mean %.2f  median %.2f  max %.2f  (>2x: %d)" % (
+                kind, r.size, float(np.exp(np.log(r).mean())), float(np.median(r)), float(r.max()), int((r > 2).sum())))
     late = LATE[backbone] + [HEAD_W[head] + "/kernel:0", HEAD_W[head] + "/bias:0"]
     for name in late:
         el = _l2(eng.grad_of(name), grads[name])

@@ -449,6 +449,41 @@ def test_conv3x3(L, shape):
         assert relerr(s2, (dx_ref * (x - mean) * invstd).sum((0, 1, 2))) < 1e-3
 
 
+@pytest.mark.parametrize("M", [2, 37, 4096])
+def test_bn_finalize_direct_small_tensors(L, M):
+    """dl3_bn_finalize_direct: two-pass double statistics straight from a small tensor (the image-pooling BatchNorm,
+    deeplabv3p.py:375-379, sees one value per image: at M = 2 the variance of two nearly equal numbers — the case in
+    which sum(y^2)/n - mean^2 of fp32 partial sums loses every digit; measured in round 3: mean^2/var 8.6e6)."""
+    rng = np.random.default_rng(M)
+    C, ld, c0 = 21, 40, 8
+    y = np.zeros((M, ld), np.float32)
+    mu = rng.uniform(-50, 50, C)
+    spread = rng.uniform(1e-3, 2.0, C)          # some channels: |mean| / spread ~ 5e4
+    y[:, c0:c0 + C] = (mu + spread * rng.normal(0, 1, (M, C))).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 1.5, C).astype(np.float32), rng.normal(0, 1, C).astype(np.float32)
+    mm, mv = rng.normal(0, 1, C).astype(np.float32), rng.uniform(0.5, 2, C).astype(np.float32)
+    eps, mom = 1e-5, 0.99
+    y64 = y[:, c0:c0 + C].astype(np.float64)
+    mean, var = y64.mean(0), y64.var(0)
+    invstd = 1 / np.sqrt(var + eps)
+    unb = (M / (M - 1.0)) * (M / (M - (1 + eps)))
+    outs = [empty(C) for _ in range(4)]
+    mmd, mvd = dev(mm), dev(mv)
+    call("dl3_bn_finalize_direct", ptr(dev(y), c0), ld, M, C, ptr(dev(gamma)), ptr(dev(beta)), eps, mom, unb,
+         *[ptr(o) for o in outs], ptr(mmd), ptr(mvd))
+    sc, sh, me, isd = [host(o) for o in outs]
+    assert np.allclose(isd, invstd, rtol=1e-6) and np.allclose(me, mean, rtol=1e-6)
+    assert np.allclose(sc, gamma * invstd, rtol=1e-6) and np.allclose(sh, beta - mean * gamma * invstd, rtol=2e-6, atol=1e-6)
+    m32 = float(np.float32(mom))  # the C ABI takes the momentum as a float
+    assert np.allclose(host(mmd), m32 * mm + (1 - m32) * mean, rtol=1e-6, atol=1e-6)
+    assert np.allclose(host(mvd), m32 * mv + (1 - m32) * var * unb, rtol=1e-6, atol=1e-7)
+    # what the partial-sum form makes of the worst channel (float32 sums, folded in double — dl3_bn_finalize's input)
+    s1, s2 = y[:, c0:c0 + C].sum(0, dtype=np.float32).astype(np.float64), (y[:, c0:c0 + C] ** 2).sum(0, dtype=np.float32).astype(np.float64)
+    var_p = np.maximum(s2 / M - (s1 / M) ** 2, 0)
+    print("M=%d: worst relative variance error of the partial-sum form %.2e, of the direct form %.2e" % (
+        M, float((np.abs(var_p - var) / var).max()), float((np.abs(1 / isd.astype(np.float64) ** 2 - eps - var) / var).max())))
+
+
 def test_bn_finalize_and_bwd(L):
     rng = np.random.default_rng(7)
     P, ldc, C, c0, count = 37, 48, 24, 16, 1000.0
