@@ -70,6 +70,8 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--worker", default=None)
     ap.add_argument("--xception", action="store_true")
+    ap.add_argument("--kinds", default="fwd,dgrad,wgrad")
+    ap.add_argument("--cfgs", default=None, help="comma list of forced configs to time next to auto (default: all)")
     args = ap.parse_args()
     if args.xception or os.environ.get("DL3_TUNE_XCEPTION"):
         SHAPES[:] = XCEPTION_SHAPES
@@ -78,8 +80,11 @@ if __name__ == "__main__":
         worker(args.batch, args.worker)
         sys.exit(0)
     for kind, var, ncfg in (("fwd", "DL3_GEMM_CFG", 7), ("dgrad", "DL3_GEMM_CFG", 7), ("wgrad", "DL3_WGRAD_CFG", 10)):
+        if kind not in args.kinds.split(","):
+            continue
         res = {}
-        for cfg in [-1] + list(range(ncfg)):
+        cfgs = list(range(ncfg)) if args.cfgs is None else [int(c) for c in args.cfgs.split(",")]
+        for cfg in [-1] + cfgs:
             env = dict(os.environ)
             env[var] = str(cfg)
             r = subprocess.run([sys.executable, __file__, "--batch", str(args.batch), "--worker", kind], env=env,
@@ -91,9 +96,9 @@ if __name__ == "__main__":
         print("== %s (ms; auto | cfg0..): shape M/img,K,N" % kind)
         tot_auto = tot_best = 0.0
         for i, sh in enumerate(SHAPES):
-            row = [res[c][i] if res[c] else float("nan") for c in [-1] + list(range(ncfg))]
+            row = [res[c][i] if res[c] else float("nan") for c in [-1] + cfgs]
             best = min(range(1, len(row)), key=lambda j: row[j])
             tot_auto += row[0]
-            tot_best += row[best]
-            print("%-18s auto %.3f | %s | best cfg%d %.3f" % (sh, row[0], " ".join("%.3f" % t for t in row[1:]), best - 1, row[best]))
+            tot_best += min(row[best], row[0])
+            print("%-18s auto %.3f | %s | best cfg%d %.3f" % (sh, row[0], " ".join("%.3f" % t for t in row[1:]), cfgs[best - 1], row[best]))
         print("sum auto %.3f ms, sum best %.3f ms" % (tot_auto, tot_best))
