@@ -39,7 +39,18 @@ struct GemmArgs {
   float *part;
   int mtiles;
   const void *bp; int nsub;  // split math: weights pre-split into 3 bf16 planes in MFMA fragment order (pack_b_kernel)
+#ifdef DL3_PHASE_TIMING
+  long long *dbg;  // probe build (tools/r3/phase_probe.py): per-workgroup cycles in prologue / K loop / epilogue
+#endif
 };
+
+// probe builds only (-DDL3_PHASE_TIMING: build_variants/libdl3_timing.so, tools/r3/phase_probe.py)
+#ifdef DL3_PHASE_TIMING
+long long *g_phase_dbg = nullptr;
+#define DL3_T(x) x
+#else
+#define DL3_T(x)
+#endif
 
 constexpr int BK = 16;
 #ifndef DL3_STREAM_KMAX
@@ -408,9 +419,15 @@ __device__ __forceinline__ void stream_epilogue_full(const GemmArgs &P, const f3
         float v = acc[i][j][r] + bias;
         if (EPX) v *= dl3_act_mask(es * xr_[r] + et, P.ep_act);
         if (ADD) v += ad[r];
+#ifndef DL3_DBG_NOSTORE
         __builtin_nontemporal_store(v, &(pc + (size_t)((r & 3) + 8 * (r >> 2)) * P.ldc)[lo_c]);
+#else
+        if (v == 1.2345e30f) __builtin_nontemporal_store(v, &(pc + (size_t)((r & 3) + 8 * (r >> 2)) * P.ldc)[lo_c]);
+#endif
+#ifndef DL3_DBG_NOSTAT
         st1[j] += v;
         st2[j] += MODE2 ? v * ((xr_[r] - mu) * is) : v * v;
+#endif
       }
       // keep the sub-tiles apart: interleaving them would hold several sub-tiles' operands live on top of the
       // accumulators (spills)
@@ -493,7 +510,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
   }
   __syncthreads();
 
+  DL3_T(long long tp0 = 0; long long tp1 = 0; long long tp2 = 0; long long tq0 = 0; long long tq1 = 0; long long tq2 = 0; int ntl = 0;)
   for (int mt = by; mt < P.mtiles; mt += gridDim.y) {
+    DL3_T(tq0 = clock64(); ntl++;)
     const int m0 = mt * BM;
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -662,6 +681,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
     transform(0);
     adopt();
     __syncthreads();
+    DL3_T(tq1 = clock64();)
     for (int kt = 0; kt < ktiles; ++kt) {
       const float *Bs = lds + (kt & 1) * KT * LDB;
       const bool more = kt + 1 < ktiles;
@@ -698,9 +718,11 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
     }
 
     // ---------------- epilogue (same C/D layout as the LDS-staged kernel)
+    DL3_T(tq2 = clock64(); tp0 += tq1 - tq0; tp1 += tq2 - tq1;)
     if (FWD && full) {
       if (!P.ep_add) stream_epilogue_full<TM, TN, false, false, false>(P, acc, m0, nw0, wm, l31, lhi, st1, st2);
       else stream_epilogue_full<TM, TN, false, true, false>(P, acc, m0, nw0, wm, l31, lhi, st1, st2);
+      DL3_T(tp2 += clock64() - tq2;)
       continue;
     }
     if constexpr (PRE) {
@@ -721,6 +743,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
             st2[j] += mode2 ? v * ((xv - mu) * is) : v * v;
           }
         }
+        DL3_T(tp2 += clock64() - tq2;)
         continue;
       }
     }
@@ -774,7 +797,14 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
         }
       }
     }
+    DL3_T(tp2 += clock64() - tq2;)
   }
+#ifdef DL3_PHASE_TIMING
+  if (P.dbg && lane == 0) {
+    long long *d = P.dbg + ((size_t)b * 4 + wave) * 4;
+    d[0] = tp0; d[1] = tp1; d[2] = tp2; d[3] = ntl;
+  }
+#endif
 
   if (P.stat_mode != 0) {
     float *sred = lds;  // [WM][BN][2]
@@ -1226,6 +1256,7 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   GemmCfg c = pick_gemm(A.M, A.K, A.N, two, stream);
   if (stream && pre_ok(A) && pre_wanted(A)) c = kGemmCfgs[4];
   A.mtiles = dl3_cdiv(A.M, c.BM);
+  DL3_T(A.dbg = g_phase_dbg;)
   dim3 grid(dl3_cdiv(A.N, c.BN), gemm_grid_y(A.M, A.N, c));
   // stream-A kernel: 10-25 % faster than the LDS-staged kernel on every layer shape, forward and bwd-data
   // (tools/gemm_tune.py).  The two-tensor bwd-data operand uses 16-deep K-tiles so that its register budget does not
@@ -1358,6 +1389,13 @@ void launch_wgrad(const WgradArgs &A, dim3 grid, hipStream_t st, bool vec) {
 }  // namespace
 
 extern "C" int dl3_reduce_partials(const float *partial, int P, int n, float *out, void *stream);
+
+#ifdef DL3_PHASE_TIMING
+extern "C" int dl3_debug_phase_buffer(long long *buf) {
+  g_phase_dbg = buf;
+  return DL3_OK;
+}
+#endif
 
 extern "C" int dl3_set_gemm_math(int mode) {
   DL3_CHECK_ARG(mode >= -1 && mode <= 1, "set_gemm_math: mode must be DL3_MATH_ENV, DL3_MATH_F32 or DL3_MATH_SPLIT");
