@@ -70,12 +70,16 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--worker", default=None)
     ap.add_argument("--xception", action="store_true")
+    ap.add_argument("--shapes", default=os.environ.get("DL3_TUNE_SHAPES"), help="px x K x N, comma separated (overrides the table)")
     ap.add_argument("--kinds", default="fwd,dgrad,wgrad")
     ap.add_argument("--cfgs", default=None, help="comma list of forced configs to time next to auto (default: all)")
     args = ap.parse_args()
     if args.xception or os.environ.get("DL3_TUNE_XCEPTION"):
         SHAPES[:] = XCEPTION_SHAPES
         os.environ["DL3_TUNE_XCEPTION"] = "1"
+    if args.shapes:
+        SHAPES[:] = [tuple(int(q) for q in t.split("x")) for t in args.shapes.split(",")]
+        os.environ["DL3_TUNE_SHAPES"] = args.shapes
     if args.worker:
         worker(args.batch, args.worker)
         sys.exit(0)

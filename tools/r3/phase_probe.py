@@ -6,7 +6,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-os.environ["DL3_LIBPATH"] = os.path.join(ROOT, "build_variants", "libdl3_timing.so")
+os.environ["DL3_LIBPATH"] = os.path.join(ROOT, "build_variants", os.environ.get("PROBE_LIB", "libdl3_timing.so"))
 import ctypes  # noqa: E402
 
 import numpy as np  # noqa: E402
@@ -23,11 +23,14 @@ f = lambda *s: torch.randn(*s, device="cuda")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 SHAPES = [(4096, 64, 384), (4096, 384, 64), (4096, 96, 576), (4096, 576, 96), (4096, 160, 960), (4096, 960, 160),
           (4096, 960, 320), (16384, 24, 144), (16384, 144, 24), (65536, 16, 96)]
+if os.environ.get("PROBE_SHAPES"):
+    SHAPES = [tuple(int(q) for q in t.split("x")) for t in os.environ["PROBE_SHAPES"].split(",")]
+KINDS = os.environ.get("PROBE_KINDS", "fwd,dgrad").split(",")
 dbg = torch.zeros(4096 * 16, dtype=torch.int64, device="cuda")
 print("%-22s %-6s %8s | per row tile and wave, microseconds at the measured clock: prologue  K-loop  epilogue | tiles/wg  wgs  t_mfma/tile" % ("shape (px,K,N)", "kind", "ms"))
 for px, K, N in SHAPES:
     M = px * B
-    for kind in ("fwd", "dgrad"):
+    for kind in KINDS:
         if kind == "fwd":
             a, b, c, sc, sh = f(M, K), f(K, N), f(M, N), f(K), f(K)
             pp = f(L.dl3_pwconv_partials(M, K, N), N, 2)
