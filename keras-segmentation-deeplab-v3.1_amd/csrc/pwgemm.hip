@@ -510,7 +510,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
   }
   __syncthreads();
 
-  DL3_T(long long tp0 = 0; long long tp1 = 0; long long tp2 = 0; long long tq0 = 0; long long tq1 = 0; long long tq2 = 0; int ntl = 0;)
+  DL3_T(long long tp0 = 0; long long tp1 = 0; long long tp2 = 0; long long tq0 = 0; long long tq1 = 0; long long tq2 = 0; int ntl = 0;
+        long long tw_vm = 0; long long tw_bar = 0;)
   for (int mt = by; mt < P.mtiles; mt += gridDim.y) {
     DL3_T(tq0 = clock64(); ntl++;)
     const int m0 = mt * BM;
@@ -707,12 +708,15 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
         // next tile's weight tile -> LDS and operand transform while the last DL3_STREAM_TAIL k-steps' MFMAs are
         // still to be issued: their VALU / LDS work hides behind the matrix pipe instead of trailing it
         if (s_ == KH - 1 - DL3_STREAM_TAIL && more) {
+          DL3_T(const long long w0 = clock64(); __builtin_amdgcn_s_waitcnt(0x0F70); tw_vm += clock64() - w0;)
           store_B(lds + ((kt + 1) & 1) * KT * LDB);
           transform(kt + 1);
         }
       }
       if (more) adopt();
+      DL3_T(const long long w1 = clock64();)
       __syncthreads();
+      DL3_T(tw_bar += clock64() - w1;)
     }
 
     }
@@ -801,8 +805,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
   }
 #ifdef DL3_PHASE_TIMING
   if (P.dbg && lane == 0) {
-    long long *d = P.dbg + ((size_t)b * 4 + wave) * 4;
-    d[0] = tp0; d[1] = tp1; d[2] = tp2; d[3] = ntl;
+    long long *d = P.dbg + ((size_t)b * 4 + wave) * 8;
+    d[0] = tp0; d[1] = tp1; d[2] = tp2; d[3] = ntl; d[4] = tw_vm; d[5] = tw_bar;
   }
 #endif
 

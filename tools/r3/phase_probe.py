@@ -26,7 +26,7 @@ SHAPES = [(4096, 64, 384), (4096, 384, 64), (4096, 96, 576), (4096, 576, 96), (4
 if os.environ.get("PROBE_SHAPES"):
     SHAPES = [tuple(int(q) for q in t.split("x")) for t in os.environ["PROBE_SHAPES"].split(",")]
 KINDS = os.environ.get("PROBE_KINDS", "fwd,dgrad").split(",")
-dbg = torch.zeros(4096 * 16, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(4096 * 32, dtype=torch.int64, device="cuda")
 print("%-22s %-6s %8s | per row tile and wave, microseconds at the measured clock: prologue  K-loop  epilogue | tiles/wg  wgs  t_mfma/tile" % ("shape (px,K,N)", "kind", "ms"))
 for px, K, N in SHAPES:
     M = px * B
@@ -59,12 +59,13 @@ for px, K, N in SHAPES:
         run()
         torch.cuda.synchronize()
         L.dl3_debug_phase_buffer(None)
-        d = dbg.cpu().numpy().reshape(-1, 4)
+        d = dbg.cpu().numpy().reshape(-1, 8)
         d = d[d[:, 3] > 0]
         nw = d.shape[0]
         tot = d[:, :3].sum(1).astype(np.float64)
         clk = tot.mean() / (ms * 1e-3)  # cycles per second, assuming a wave is busy for the whole launch
         per = d[:, :3].sum(0) / d[:, 3].sum() / clk * 1e6
         # fp32 MFMA time of one tile on one SIMD: 64 cycles per 32x32x2 MFMA at 2.4 GHz
-        print("%-22s %-6s %8.3f | %8.2f %8.2f %8.2f | %6.1f %6d   clk %.2f GHz" % (
-            (px, K, N), kind, ms, per[0], per[1], per[2], d[:, 3].mean(), nw // 4, clk / 1e9))
+        wv = d[:, 4:6].sum(0) / d[:, 3].sum() / clk * 1e6
+        print("%-22s %-6s %8.3f | %8.2f %8.2f %8.2f | %6.1f %6d   clk %.2f GHz | in the K loop: waiting for the operand loads %.2f us, at the barrier %.2f us per tile" % (
+            (px, K, N), kind, ms, per[0], per[1], per[2], d[:, 3].mean(), nw // 4, clk / 1e9, wv[0], wv[1]))
