@@ -692,3 +692,31 @@ def test_compile_accepts_the_references_adam_object():
         outs.append((losses, model._active.params.cpu().numpy().copy()))
     assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
     assert outs[0][0][-1] < outs[0][0][0]
+
+
+def test_backward_fork_is_bit_identical(monkeypatch):
+    """DL3_FORK=1 (engine.Engine.run_ops_forked: the 1x1 weight gradients on a second stream / parallel hipGraph branch,
+    round 3 — measured slower and off by default) computes exactly what the single-stream plan computes, eagerly and as
+    a captured graph."""
+    model, params = _build(input_shape=(64, 64, 3), classes=3)
+    _load(model, params)
+    rng = np.random.default_rng(12)
+    x = rng.integers(0, 256, (2, 64, 64, 3)).astype(np.float32)
+    y = rng.integers(0, 4, (2, 64 * 64)).astype(np.float32)
+    sw = (y < 3).astype(np.float32)
+    got = {}
+    for fork in ("0", "1"):
+        monkeypatch.setenv("DL3_FORK", fork)
+        for use_graph in (False, True):
+            eng = model._engine(2, True, dropout=False, use_graph=use_graph, seed=100 + int(fork))  # distinct engine keys
+            assert eng.fork == (fork == "1") and bool(eng._side) == (fork == "1")
+            eng.set_input(x)
+            eng.set_targets(y, sw)
+            for _ in range(3 if use_graph else 1):   # the graph is captured on the second call
+                eng.fwd_bwd()
+            torch.cuda.synchronize()
+            assert (eng.graph is not None) == use_graph
+            got[(fork, use_graph)] = (eng.grads.cpu().numpy().copy(), float(eng.loss[0].item()))
+    ref = got[("0", False)]
+    for k, v in got.items():
+        assert v[1] == ref[1] and np.array_equal(v[0], ref[0]), k
