@@ -1203,12 +1203,15 @@ int gemm_grid_y(int M, int N, const GemmCfg &c) {
   return even;
 }
 
-// split math: device scratch for the packed weights of the launch in flight, one buffer per (device, stream): launches
-// on one stream are ordered, launches on different streams / devices / host threads never share a buffer.  A buffer only
-// ever grows, and a superseded one stays allocated (a captured hipGraph may still point at it).  Growing is impossible
-// while the stream is capturing: the engine's first step runs eagerly.
+// split math (opt-in): device scratch for the packed weights of the launch in flight, one buffer per DEVICE.  Launches on
+// one stream are ordered, so one buffer serves them all — split-math launches of a device must not be issued from two
+// streams at once (the engine issues them on one stream, eagerly or under capture; the weight-gradient kernels, the
+// only launches that may run on a second stream, split in registers and do not use it).  Keying by stream as well
+// (tried in round 3) breaks hipGraph capture: the capture stream is not the stream the eager warm-up step grew the
+// buffer on, and nothing can be allocated while capturing.  A buffer only ever grows, and a superseded one stays
+// allocated (a captured hipGraph may still point at it).
 void *pack_scratch(size_t bytes, hipStream_t st) {
-  struct Slot { int dev; hipStream_t st; void *buf; size_t cap; };
+  struct Slot { int dev; void *buf; size_t cap; };
   static std::mutex mu;
   static std::vector<Slot> slots;
   int dev = 0;
@@ -1216,7 +1219,7 @@ void *pack_scratch(size_t bytes, hipStream_t st) {
   std::lock_guard<std::mutex> lock(mu);
   Slot *s = nullptr;
   for (Slot &q : slots)
-    if (q.dev == dev && q.st == st) { s = &q; break; }
+    if (q.dev == dev) { s = &q; break; }
   if (s && bytes <= s->cap) return s->buf;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(st, &cs);
@@ -1225,7 +1228,7 @@ void *pack_scratch(size_t bytes, hipStream_t st) {
   void *nb = nullptr;
   if (hipMalloc(&nb, want) != hipSuccess) return nullptr;
   if (!s) {
-    slots.push_back(Slot{dev, st, nullptr, 0});
+    slots.push_back(Slot{dev, nullptr, 0});
     s = &slots.back();
   }
   s->buf = nb;

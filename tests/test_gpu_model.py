@@ -720,3 +720,36 @@ def test_backward_fork_is_bit_identical(monkeypatch):
     ref = got[("0", False)]
     for k, v in got.items():
         assert v[1] == ref[1] and np.array_equal(v[0], ref[0]), k
+
+
+def test_split_math_under_hipgraph_capture():
+    """DL3_GEMM_MATH=split through a captured hipGraph (bench.py's split_math leg): the packed-weight scratch grown by the
+    eager first step must serve the capture stream too (round 3: a per-stream scratch made the capture fail); the
+    replayed graph reproduces the eager split-math step bit for bit and stays within fp32 round-off of the f32 MFMA."""
+    from dl3_amd import capi
+    model, params = _build(input_shape=(128, 128, 3), classes=3)
+    _load(model, params)
+    rng = np.random.default_rng(13)
+    B = 16   # 128-row tiles (the split instantiations) need >= 512 row tiles on the early layers
+    x = rng.integers(0, 256, (B, 128, 128, 3)).astype(np.float32)
+    y = rng.integers(0, 4, (B, 128 * 128)).astype(np.float32)
+    sw = (y < 3).astype(np.float32)
+    out = {}
+    for math in ("f32", "split"):
+        capi.set_gemm_math(None if math == "f32" else "split")
+        try:
+            for use_graph in (False, True):
+                eng = model._engine(B, True, dropout=False, use_graph=use_graph, seed=200 + (math == "split"))
+                eng.set_input(x)
+                eng.set_targets(y, sw)
+                for _ in range(3 if use_graph else 1):
+                    eng.fwd_bwd()
+                torch.cuda.synchronize()
+                assert (eng.graph is not None) == use_graph, "hipGraph capture failed in %s math" % math
+                out[(math, use_graph)] = eng.grads.cpu().numpy().copy()
+        finally:
+            capi.set_gemm_math(None)
+    assert np.array_equal(out[("split", True)], out[("split", False)])
+    assert np.array_equal(out[("f32", True)], out[("f32", False)])
+    assert not np.array_equal(out[("split", False)], out[("f32", False)])   # it really is another arithmetic
+    assert _l2(out[("split", False)], out[("f32", False)]) < 2e-2           # ... within what separates two fp32 orders

@@ -661,9 +661,12 @@ def test_subsample(L):
     assert np.array_equal(host(dx), ref)
 
 
-def test_phase_shift(L):
+@pytest.mark.parametrize("N,H,W,co,r", [(2, 5, 6, 3, 4), (2, 4, 13, 21, 8), (1, 3, 5, 7, 3), (1, 2, 3, 600, 8), (2, 3, 9, 5, 1)])
+def test_phase_shift(L, N, H, W, co, r):
+    """Subpixel._phase_shift (subpixel.py:77-88) and its inverse, bit-exact (a permutation): the LDS-transposing kernel
+    (full and ragged pixel blocks, the SegModel head's 21 x 8 x 8, odd r) and the generic fallback (a pixel too large
+    for the LDS tile: co = 600 at r = 8)"""
     rng = np.random.default_rng(12)
-    N, H, W, co, r = 2, 5, 6, 3, 4
     x = rng.normal(0, 1, (N, H, W, co * r * r)).astype(np.float32)
     ref = O.phase_shift(x, r)
     y = empty(*ref.shape)
