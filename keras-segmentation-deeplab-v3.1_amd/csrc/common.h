@@ -45,7 +45,11 @@ static inline int dl3_cdiv(int a, int b) { return (a + b - 1) / b; }
 __device__ __forceinline__ float dl3_act(float v, int act) {
   const float lo = (act != DL3_ACT_NONE) ? 0.f : -__builtin_inff();
   const float hi = (act == DL3_ACT_RELU6) ? 6.f : __builtin_inff();
+#ifdef DL3_ACT_MINMAX
   return fminf(fmaxf(v, lo), hi);
+#else
+  return __builtin_amdgcn_fmed3f(v, lo, hi);  // v_med3_f32: the clamp in ONE VALU instruction (lo <= hi always)
+#endif
 }
 // derivative mask of the activation at pre-activation z: 1 inside the open interval (lo, hi)
 __device__ __forceinline__ float dl3_act_mask(float z, int act) {

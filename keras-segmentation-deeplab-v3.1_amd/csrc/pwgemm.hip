@@ -59,9 +59,6 @@ constexpr int BK = 16;
 #ifndef DL3_STREAM_KT_FWD
 #define DL3_STREAM_KT_FWD 16  // K-tile depth of the forward instantiation (32 measured in round 2: see DESIGN.md)
 #endif
-#ifndef DL3_STREAM_TAIL
-#define DL3_STREAM_TAIL 2
-#endif
 #ifndef DL3_WGRAD_WGS_DEFAULT
 #define DL3_WGRAD_WGS_DEFAULT 1024
 #endif
@@ -575,7 +572,10 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
         if (NB * 256 == KT * BN / 4 || idx < KT * BN / 4) st4(&Bs[(idx / (BN / 4)) * LDB + (idx % (BN / 4)) * 4], rb[i]);
       }
     };
-    // loaded registers of K-tile kt -> MFMA operand values, in place (an <- T(an))
+    // loaded registers of K-tile kt -> MFMA operand values.  f32 path: straight into the operand registers ac, AFTER the
+    // last MFMA of the running K-tile has been issued (round 3: a wave's own VALU work does not overlap its own MFMAs, so
+    // there is nothing to gain from placing it earlier, and the separate copy an -> ac cost 8 v_mov per K-tile);
+    // split path: in place (an <- T(an)), split3 reads it
     auto transform = [&](int kt) {
 #pragma unroll
       for (int j = 0; j < NJ; j++) {
@@ -585,15 +585,10 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
         for (int i = 0; i < TM; i++) {
           f32x4 v = fa * an[i][j] + fc;
           if (TWO) v += ld4(cf + 2 * KC + k) * an2[i][j];
-          an[i][j] = dl3_act4(v, P.a_act);
+          if constexpr (SPL) an[i][j] = dl3_act4(v, P.a_act);
+          else ac[i][j] = dl3_act4(v, P.a_act);
         }
       }
-    };
-    auto adopt = [&]() {
-#pragma unroll
-      for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < NJ; j++) ac[i][j] = an[i][j];
     };
 
     if constexpr (SPL) {
@@ -680,7 +675,6 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
     __syncthreads();  // the previous row tile is done with the LDS
     store_B(lds);
     transform(0);
-    adopt();
     __syncthreads();
     DL3_T(tq1 = clock64();)
     for (int kt = 0; kt < ktiles; ++kt) {
@@ -705,15 +699,13 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
 #pragma unroll
           for (int j = 0; j < TN; j++)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[i][s_ >> 2][s_ & 3], bf[cur][j], acc[i][j], 0, 0, 0);
-        // next tile's weight tile -> LDS and operand transform while the last DL3_STREAM_TAIL k-steps' MFMAs are
-        // still to be issued: their VALU / LDS work hides behind the matrix pipe instead of trailing it
-        if (s_ == KH - 1 - DL3_STREAM_TAIL && more) {
-          DL3_T(const long long w0 = clock64(); __builtin_amdgcn_s_waitcnt(0x0F70); tw_vm += clock64() - w0;)
-          store_B(lds + ((kt + 1) & 1) * KT * LDB);
-          transform(kt + 1);
-        }
       }
-      if (more) adopt();
+      // next tile's weight tile -> LDS and operand transform, behind the last MFMA of this K-tile
+      if (more) {
+        DL3_T(const long long w0 = clock64(); __builtin_amdgcn_s_waitcnt(0x0F70); tw_vm += clock64() - w0;)
+        store_B(lds + ((kt + 1) & 1) * KT * LDB);
+        transform(kt + 1);
+      }
       DL3_T(const long long w1 = clock64();)
       __syncthreads();
       DL3_T(tw_bar += clock64() - w1;)
