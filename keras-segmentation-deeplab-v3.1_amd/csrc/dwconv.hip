@@ -725,9 +725,11 @@ DwPlan dw_plan(int N, int H, int W, int C, int stride, int rate, int Ho, int Wo,
     p.nxseg = dl3_cdiv(W, p.two ? 64 : 32);
     p.nphase = rate < H ? rate : H;
     const int Kmax = dl3_cdiv(H, rate);
-    // rows per block: as long as possible (halo re-read = 2/TK) while keeping >= ~2048 blocks
+    // rows per block: as long as possible (halo re-read = 2/TK) while keeping >= ~1024 blocks (round 3, Xception OS=8 at
+    // B=16, 64x64x736 rate 2: 2048 -> row chunks of 8 with 25 % halo, in-situ 0.573 of 8 TB/s; 1024 -> chunks of 16:
+    // 0.591; 512: 0.591; 3072 / 4096: 0.543; larger batches never chunk)
     int TK = Kmax;
-    long want = 2048;  // workgroups per launch to aim for (DL3_DW_BLOCKS: tuning aid)
+    long want = 1024;  // workgroups per launch to aim for (DL3_DW_BLOCKS: tuning aid)
     if (const char *eb = getenv("DL3_DW_BLOCKS")) want = atol(eb) > 0 ? atol(eb) : want;
     while (TK > 8 && (long)N * p.nslab * p.nxseg * p.nphase * dl3_cdiv(Kmax, TK) < want) TK = (TK + 1) / 2;
     p.TK = TK;
