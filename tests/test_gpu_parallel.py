@@ -217,6 +217,9 @@ def test_bench_self_spawns_its_ranks():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["config"]["global_batch"] == 4
     assert rec["config"]["hipgraph"] is True and rec["config"]["parallelism"] == "dp2"
+    # round 3: the line says which data plane produced it and what the exchange costs on its own
+    assert rec["config"]["gradient_exchange"] == "gloo (host staged)" and rec["config"]["rccl_ranks"] is None
+    assert rec["allreduce_ms"] > 0 and rec["config"]["dist_strict"] is False
     assert abs(rec["value"] - 4 * 3 / (rec["ms_per_step"] * 3e-3)) < 1e-6 * rec["value"]
     # a launcher environment that disagrees with --gpus is refused, not silently reinterpreted
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
