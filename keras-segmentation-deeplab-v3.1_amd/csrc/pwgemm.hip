@@ -644,7 +644,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
       // Every wave DMAs only its own pieces of a weight tile and, after the barrier, reads ALL of them: a wave must not
       // reach the barrier with its DMA still in flight.  s_barrier does not imply it on gfx950 (back-off barriers), so
       // the vmcnt(0) is spelled out (0x0F70 = vmcnt 0, expcnt / lgkmcnt untouched) instead of left to the fence the
-      // compiler happens to emit for __syncthreads today.
+      // compiler happens to emit for __syncthreads today.  (Waiting for LESS — a counted vmcnt that keeps the operand
+      // request of K-tile kt+2 in flight across a raw s_barrier — was measured in round 3: split math 1 235-1 245 img/s
+      // either way.)
       load_A(0);
       __syncthreads();  // the previous row tile is done with the LDS
       dma_B(0, 0);
@@ -654,6 +656,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
       if (ktiles > 1) load_A(1);
       __builtin_amdgcn_s_waitcnt(0x0F70);
       __syncthreads();
+      DL3_T(tq1 = clock64();)
       for (int kt = 0; kt < ktiles; ++kt) {
         const float *Bs = lds + (kt & 1) * BQ * 4;
         const bool more = kt + 1 < ktiles;

@@ -18,6 +18,8 @@ from dl3_amd.capi import ptr  # noqa: E402
 
 L = capi.lib()
 L.dl3_debug_phase_buffer.argtypes = [ctypes.c_void_p]
+if os.environ.get("PROBE_MATH") == "split":
+    capi.set_gemm_math("split")
 st = torch.cuda.current_stream().cuda_stream
 f = lambda *s: torch.randn(*s, device="cuda")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
