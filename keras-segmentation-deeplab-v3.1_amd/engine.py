@@ -201,6 +201,7 @@ class Engine:
         self.bn_sites = []
         self._side = set()          # id(op record) of the launches that run on the side stream
         self._side_stream = None
+        self._fork_events = []
         self.side_scratch_bytes = 0
         self._side_scratch_users = []
         self.units = []
@@ -378,11 +379,15 @@ class Engine:
         side = self._side_stream
         mst, sst = main.cuda_stream, side.cuda_stream
         pending = True  # the main stream has moved on since the side stream last synchronised with it
+        nev = 0
         for rec in lst:
             name, fn, args, _ = rec
             if id(rec) in self._side:
                 if pending:
-                    ev = torch.cuda.Event()
+                    if nev == len(self._fork_events):
+                        self._fork_events.append(torch.cuda.Event())
+                    ev = self._fork_events[nev]
+                    nev += 1
                     ev.record(main)
                     side.wait_event(ev)
                     pending = False
@@ -982,22 +987,10 @@ class Engine:
         self._calls += 1
 
     def _run_bwd(self):
-        # tuning aid: DL3_BWD_GEMM_PY = workgroup target of the backward chain's GEMM launches only (libdl3.so reads
-        # DL3_GEMM_PY per launch; a smaller grid only ever writes fewer partial rows than were planned)
-        bpy, old = os.environ.get("DL3_BWD_GEMM_PY"), os.environ.get("DL3_GEMM_PY")
-        if bpy:
-            os.environ["DL3_GEMM_PY"] = bpy
-        try:
-            if self.fork and self._side:
-                self.run_ops_forked(self.ops_bwd)
-            else:
-                self.run_ops(self.ops_bwd)
-        finally:
-            if bpy:
-                if old is None:
-                    del os.environ["DL3_GEMM_PY"]
-                else:
-                    os.environ["DL3_GEMM_PY"] = old
+        if self.fork and self._side:
+            self.run_ops_forked(self.ops_bwd)
+        else:
+            self.run_ops(self.ops_bwd)
 
     def adam(self, opt=None, grad_scale=1.0):
         """Keras Adam with decay (notebook cell 2): lr_t = lr/(1+decay*it) * sqrt(1-b2^t)/(1-b1^t)"""
