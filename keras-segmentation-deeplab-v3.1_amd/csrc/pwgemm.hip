@@ -845,6 +845,9 @@ struct WgradArgs {
   const float *cA, *cB, *cC;
   float *ws;  // [S][K][N]
   int M, K, N, Mper;
+#ifdef DL3_PHASE_TIMING
+  long long *dbg;
+#endif
 };
 
 template <int TA, int TB, int WA, int WB, bool VEC, bool SPL = false>
@@ -986,6 +989,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
     }
   };
 
+  DL3_T(long long tw_vm = 0; long long tw_bar = 0; int nst = 0; const long long tstart = clock64();)
   if (mbeg < mend) {
     load_tiles(mbeg);
     store_tiles(mbeg, lds, lds + MS * LDX);
@@ -1062,11 +1066,20 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
       }
       if (more) {
         float *Xn = lds + (stage ^ 1) * STAGE;
+        DL3_T(const long long w0 = clock64(); __builtin_amdgcn_s_waitcnt(0x0F70); tw_vm += clock64() - w0;)
         store_tiles(m0 + MS, Xn, Xn + MS * LDX);
       }
+      DL3_T(const long long w1 = clock64();)
       __syncthreads();
+      DL3_T(tw_bar += clock64() - w1; nst++;)
     }
   }
+#ifdef DL3_PHASE_TIMING
+  if (P.dbg && lane == 0) {
+    long long *d = P.dbg + ((size_t)lin * 4 + wave) * 8;
+    d[0] = 0; d[1] = clock64() - tstart; d[2] = 0; d[3] = nst; d[4] = tw_vm; d[5] = tw_bar;
+  }
+#endif
   float *out = P.ws + (size_t)bz * P.K * P.N;
 #pragma unroll
   for (int i = 0; i < TA; i++)
@@ -1528,6 +1541,7 @@ extern "C" int dl3_pwconv_bwd_weight(const float *x, int ldx, const float *in_sc
   A.ws = (float *)workspace;
   A.M = M; A.K = K; A.N = N;
   A.Mper = dl3_cdiv(dl3_cdiv(M, S), DL3_WGRAD_MS) * DL3_WGRAD_MS;
+  DL3_T(A.dbg = g_phase_dbg;)
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(dl3_cdiv(N, c.BNT), dl3_cdiv(K, c.BKT), S);
   const bool xvec = (K % 4 == 0) && (ldx % 4 == 0) && al16(x);

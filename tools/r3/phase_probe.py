@@ -28,7 +28,7 @@ SHAPES = [(4096, 64, 384), (4096, 384, 64), (4096, 96, 576), (4096, 576, 96), (4
 if os.environ.get("PROBE_SHAPES"):
     SHAPES = [tuple(int(q) for q in t.split("x")) for t in os.environ["PROBE_SHAPES"].split(",")]
 KINDS = os.environ.get("PROBE_KINDS", "fwd,dgrad").split(",")
-dbg = torch.zeros(4096 * 32, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(8192 * 32, dtype=torch.int64, device="cuda")
 print("%-22s %-6s %8s | per row tile and wave, microseconds at the measured clock: prologue  K-loop  epilogue | tiles/wg  wgs  t_mfma/tile" % ("shape (px,K,N)", "kind", "ms"))
 for px, K, N in SHAPES:
     M = px * B
@@ -38,6 +38,14 @@ for px, K, N in SHAPES:
             pp = f(L.dl3_pwconv_partials(M, K, N), N, 2)
             run = lambda: capi.call("dl3_pwconv_fwd", ptr(a), K, ptr(sc), ptr(sh), 2, ptr(b), None, ptr(c), N, M, K, N, ptr(pp), st)
             red, outw = K, N
+        elif kind == "wgrad":
+            x, g, y, dw = f(M, K), f(M, N), f(M, N), f(K, N)
+            v = [f(max(K, N)) for _ in range(5)]
+            nb = L.dl3_pwconv_bwd_weight_workspace(M, K, N)
+            ws = torch.empty(nb // 4 + 4, device="cuda")
+            run = lambda: capi.call("dl3_pwconv_bwd_weight", ptr(x), K, ptr(v[0]), ptr(v[1]), 2, ptr(g), N, ptr(y), N,
+                                    ptr(v[2]), ptr(v[3]), ptr(v[4]), ptr(dw), None, M, K, N, ptr(ws), nb, st)
+            red, outw = M, N
         else:
             g, y, wT, dx, x = f(M, N), f(M, N), f(N, K), f(M, K), f(M, K)
             v = [f(max(K, N)) for _ in range(7)]
@@ -68,6 +76,15 @@ for px, K, N in SHAPES:
         clk = tot.mean() / (ms * 1e-3)  # cycles per second, assuming a wave is busy for the whole launch
         per = d[:, :3].sum(0) / d[:, 3].sum() / clk * 1e6
         # fp32 MFMA time of one tile on one SIMD: 64 cycles per 32x32x2 MFMA at 2.4 GHz
+        if kind == "wgrad":
+            # d[1] = whole kernel cycles of the wave, d[3] = stages of 16 pixel rows, d[4] / d[5] = waits
+            tot = d[:, 1].astype(np.float64)
+            clk = tot.mean() / (ms * 1e-3)
+            st_us = d[:, 1].sum() / d[:, 3].sum() / clk * 1e6
+            wv = d[:, 4:6].sum(0) / d[:, 3].sum() / clk * 1e6
+            print("%-22s %-6s %8.3f | per 16-row stage and wave: %.3f us (MFMA time of one wave at 2.4 GHz: see tile), waiting for the loads %.3f us, at the barrier %.3f us | stages/wg %.0f  wgs %d  clk %.2f GHz" % (
+                (px, K, N), kind, ms, st_us, wv[0], wv[1], d[:, 3].mean(), nw // 4, clk / 1e9))
+            continue
         wv = d[:, 4:6].sum(0) / d[:, 3].sum() / clk * 1e6
         print("%-22s %-6s %8.3f | %8.2f %8.2f %8.2f | %6.1f %6d   clk %.2f GHz | in the K loop: waiting for the operand loads %.2f us, at the barrier %.2f us per tile" % (
             (px, K, N), kind, ms, per[0], per[1], per[2], d[:, 3].mean(), nw // 4, clk / 1e9, wv[0], wv[1]))
