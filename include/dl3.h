@@ -217,6 +217,14 @@ int dl3_resize_bilinear_bwd(const float *dy, int lddy, float *dx, int lddx, int 
 /* Subpixel._phase_shift (subpixel.py:77-88): out[n,ia*r+q,ib*r+p,ch] = in[n,ia,ib,ch*r*r+p*r+q];
  * inverse!=0 applies the inverse permutation (the backward pass) */
 int dl3_phase_shift(const float *in, float *out, int N, int H, int W, int Cout, int r, int inverse, void *stream);
+/* Subpixel head, training tail (utils.py:195-198 + the loss): softmax cross-entropy evaluated on the UNshuffled output u
+ * [N,H,W,C*r*r] of the Subpixel convolution — labels / weights live at the shuffled resolution [N, H*r, W*r] — writing
+ * du in u's own layout, so that neither the shuffled logits nor the shuffled gradient nor the two phase-shift passes
+ * exist.  loss_partial [P], P = dl3_shuffle_xent_partials(...) (0: shape not supported, fall back to dl3_phase_shift +
+ * dl3_softmax_xent).  C <= 32. */
+int dl3_shuffle_xent_partials(int N, int H, int W, int C, int r);
+int dl3_shuffle_softmax_xent(const float *u, const float *labels, const float *weights, const float *nnz, float *du,
+                             float *loss_partial, int N, int H, int W, int C, int r, void *stream);
 /* Subpixel with kernel_size > 1 (subpixel.py:42-58: Subpixel IS a Conv2D with any kernel_size; icnr_weights' default
  * shape is 3x3, subpixel.py:9): the k x k taps of T(x) = act(scale*x+shift), zero outside the image, gathered next to
  * each other — cols[(n,oy,ox)][(i*k+j)*C + c] = T(x)[n, oy-pad_t+i, ox-pad_l+j, c] (stride 1) — so that the Keras

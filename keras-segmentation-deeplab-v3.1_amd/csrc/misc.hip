@@ -194,6 +194,84 @@ __global__ __launch_bounds__(256) void phase_shift_lds_kernel(const float *__res
   }
 }
 
+// Subpixel head, training tail in one pass (round 3): softmax cross-entropy evaluated straight on the UNshuffled output
+// of the Subpixel convolution.  out[n, ia*r+q, ib*r+p, ch] = u[n, ia, ib, ch*r*r + p*r + q] (subpixel.py:81-87), so the C
+// logits of one output pixel sit r*r floats apart in u: a workgroup stages PB consecutive pixels of one row (n, ia) of u
+// in LDS (coalesced; element (pixel, ch, pq) at pixel*C*(r*r+1) + ch*(r*r+1) + pq as in phase_shift_lds_kernel), every
+// thread evaluates output pixels (pixel, pq) from there (lanes = consecutive pq: conflict-free), writes the gradient
+// back into the same LDS cells, and the tile leaves coalesced as du in u's own layout — the shuffled logits, the
+// shuffled gradient and both phase-shift passes (4 x 2.8 GB at 128 x 512 x 512 x 21) never touch HBM.
+template <int MAXC>
+__global__ __launch_bounds__(256) void shuffle_xent_kernel(const float *__restrict__ u, const float *__restrict__ labels,
+                                                           const float *__restrict__ weights,
+                                                           const float *__restrict__ nnz, float *__restrict__ du,
+                                                           float *__restrict__ loss_part, int H, int W, int C, int r,
+                                                           int PB) {
+  extern __shared__ float tile[];
+  __shared__ float red[4];
+  const int rr = r * r, P = C * rr, LP = C * (rr + 1);
+  const int wblocks = (W + PB - 1) / PB;
+  const int ib0 = (blockIdx.x % wblocks) * PB;
+  const long row = blockIdx.x / wblocks;  // n * H + ia
+  const int ia = (int)(row % H);
+  const long n = row / H;
+  const int pb = min(PB, W - ib0);
+  const size_t flat = ((size_t)row * W + ib0) * P;
+  for (int t = threadIdx.x; t < pb * P; t += 256) {
+    const int px = t / P, e = t % P;
+    tile[px * LP + (e / rr) * (rr + 1) + e % rr] = u[flat + t];
+  }
+  __syncthreads();
+  const float inv_nnz = 1.f / fmaxf(*nnz, 1.f);
+  const int Wr = W * r;
+  float lsum = 0.f;
+  for (int o = threadIdx.x; o < pb * rr; o += 256) {
+    const int px = o / rr, pq = o % rr, pp = pq / r, q = pq % r;
+    float *cell = tile + px * LP + pq;
+    float z[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) z[c] = cell[min(c, C - 1) * (rr + 1)];
+    float mx = z[0];
+#pragma unroll
+    for (int c = 1; c < MAXC; c++) mx = fmaxf(mx, (c < C) ? z[c] : z[0]);
+    float ssum = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+      z[c] = (c < C) ? expf(z[c] - mx) : 0.f;
+      ssum += z[c];
+    }
+    const float inv = 1.f / ssum;
+    const size_t m = ((size_t)n * H * r + (size_t)ia * r + q) * Wr + (size_t)(ib0 + px) * r + pp;  // output pixel
+    const int t = (int)labels[m];
+    const float w = (t >= 0 && t < C) ? (weights ? weights[m] : 1.f) : 0.f;  // void rows: zero loss and gradient
+    float psum = 0.f, pt = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+      z[c] *= inv;
+      psum += z[c];
+      pt = (c == t) ? z[c] : pt;
+    }
+    if (t >= 0 && t < C) {
+      float qq = pt / psum;
+      qq = fminf(fmaxf(qq, 1e-7f), 1.f - 1e-7f);
+      lsum += -logf(qq) * w * inv_nnz;
+    }
+    const float gs = w * inv_nnz;
+#pragma unroll
+    for (int c = 0; c < MAXC; c++)
+      if (c < C) cell[c * (rr + 1)] = (z[c] - (c == t ? 1.f : 0.f)) * gs;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < pb * P; t += 256) {
+    const int px = t / P, e = t % P;
+    du[flat + t] = tile[px * LP + (e / rr) * (rr + 1) + e % rr];
+  }
+  lsum = wave_sum(lsum);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) loss_part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
 // k x k taps of T(x) side by side (Subpixel with kernel_size > 1): one thread per (output pixel, tap, channel)
 __global__ __launch_bounds__(256) void conv_taps_fwd_kernel(const float *__restrict__ x, int ldx,
                                                             const float *__restrict__ sc, const float *__restrict__ sh,
@@ -609,6 +687,42 @@ extern "C" int dl3_phase_shift(const float *in, float *out, int N, int H, int W,
                        (hipStream_t)stream, in, out, N, H, W, Cout, r, inverse);
   }
   DL3_LAUNCH_CHECK("phase_shift");
+  return DL3_OK;
+}
+
+static int shuffle_xent_pb(int W, int C, int r) {
+  const size_t per_px = (size_t)C * (r * r + 1) * sizeof(float);
+  int PB = (int)((48u << 10) / per_px);
+  if (PB > 8) PB = 8;
+  if (PB > W) PB = W;
+  return PB;
+}
+
+extern "C" int dl3_shuffle_xent_partials(int N, int H, int W, int C, int r) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || r <= 0) return 0;
+  const int PB = shuffle_xent_pb(W, C, r);
+  if (PB < 1) return 0;
+  const long blocks = (long)N * H * dl3_cdiv(W, PB);
+  return blocks < (1L << 30) ? (int)blocks : 0;
+}
+
+extern "C" int dl3_shuffle_softmax_xent(const float *u, const float *labels, const float *weights, const float *nnz,
+                                        float *du, float *loss_partial, int N, int H, int W, int C, int r,
+                                        void *stream) {
+  DL3_CHECK_ARG(u && labels && nnz && du && loss_partial && N > 0 && H > 0 && W > 0 && C > 0 && r > 0,
+                "shuffle_softmax_xent: bad argument");
+  DL3_UNSUPPORTED(C > 32, "shuffle_softmax_xent: C=%d > 32 (use phase_shift + softmax_xent)", C);
+  const int P = dl3_shuffle_xent_partials(N, H, W, C, r);
+  DL3_UNSUPPORTED(P <= 0, "shuffle_softmax_xent: a pixel of %d x %d x %d floats does not fit the LDS tile", C, r, r);
+  const int PB = shuffle_xent_pb(W, C, r);
+  const size_t lds = (size_t)PB * C * (r * r + 1) * sizeof(float);
+  if (C <= 24)
+    hipLaunchKernelGGL(shuffle_xent_kernel<24>, dim3(P), dim3(256), lds, (hipStream_t)stream, u, labels, weights, nnz, du,
+                       loss_partial, H, W, C, r, PB);
+  else
+    hipLaunchKernelGGL(shuffle_xent_kernel<32>, dim3(P), dim3(256), lds, (hipStream_t)stream, u, labels, weights, nnz, du,
+                       loss_partial, H, W, C, r, PB);
+  DL3_LAUNCH_CHECK("shuffle_softmax_xent");
   return DL3_OK;
 }
 

@@ -715,6 +715,16 @@ class Engine:
             self.fused_tail = last
             self._resize_op = self.ops_fwd.pop()
             assert self._resize_op[0] == "dl3_resize_bilinear_fwd"
+        # Subpixel head in training: the loss is evaluated straight on the unshuffled output of the Subpixel convolution
+        # (dl3_shuffle_softmax_xent): neither phase-shift pass nor the shuffled logits / gradient touch HBM; the forward
+        # phase shift is kept for logits() on demand
+        self.fused_shuffle = None
+        if (self.training and self.fused_tail is None and isinstance(last, ShuffleUnit) and last.outv.buf is v.buf
+                and os.environ.get("DL3_FUSE_SHUFFLE", "1") != "0"
+                and self.lib.dl3_shuffle_xent_partials(self.B, last.inv.buf.H, last.inv.buf.W, last.co, last.r) > 0 and C <= 32):
+            self.fused_shuffle = last
+            self._shuffle_op = self.ops_fwd.pop()
+            assert self._shuffle_op[0] == "dl3_phase_shift"
         M = v.buf.M
         self.probs = self.empty(M * C)
         self.out_shape = (self.B,) + tuple(l.output.shape)
@@ -736,7 +746,16 @@ class Engine:
         # loss + dlogits (first and only contribution to the logits buffer)
         if not self.external_nnz:
             self.op(self.ops_fwd, "dl3_count_nonzero", ptr(self.sweights), M, ptr(self.nnz))
-        if self.fused_tail is not None and ((buf.W + 2 * self.fused_tail.inv.buf.W) * C + 2 * buf.W) * 4 <= 65536 and self.fold_tail:
+        if self.fused_shuffle is not None:
+            su = self.fused_shuffle
+            ub = su.inv.buf
+            ub.grad = self.empty(ub.M * ub.ld)
+            self.lossP = self.lib.dl3_shuffle_xent_partials(self.B, ub.H, ub.W, su.co, su.r)
+            self.loss_part = self.zeros(self.lossP)
+            self.op(self.ops_fwd, "dl3_shuffle_softmax_xent", su.inv.p(), ptr(self.labels), ptr(self.sweights), ptr(self.nnz),
+                    ptr(ub.grad), ptr(self.loss_part), self.B, ub.H, ub.W, su.co, su.r)
+            su.fused = True
+        elif self.fused_tail is not None and ((buf.W + 2 * self.fused_tail.inv.buf.W) * C + 2 * buf.W) * 4 <= 65536 and self.fold_tail:
             # the full-resolution gradient never exists: the loss kernel folds each output row onto the low-resolution
             # columns, the resize unit's backward folds the rows
             lo = self.fused_tail.inv
@@ -907,6 +926,8 @@ class Engine:
         v = self.logits_view
         if getattr(self, "fused_tail", None) is not None:
             self.run_ops([self._resize_op])  # the fused training tail never materialises them
+        if getattr(self, "fused_shuffle", None) is not None:
+            self.run_ops([self._shuffle_op])  # nor does the fused Subpixel tail
         return v.buf.t.cpu().numpy().reshape(self.B, v.buf.H, v.buf.W, v.C)
 
     def argmax(self):
@@ -1332,8 +1353,14 @@ class ShuffleUnit:
         eng._consume(inv)
         eng.op(eng.ops_fwd, "dl3_phase_shift", inv.p(), outv.p(), eng.B, inv.buf.H, inv.buf.W, co, r, 0)
 
+    fused = False  # training: the loss kernel wrote the gradient in the unshuffled layout already (Engine._lo_softmax)
+
     def bwd(self):
         eng, inv = self.eng, self.inv
+        if self.fused:
+            assert inv.buf.grad is not None and not inv.buf.bns
+            inv.buf.done += 1
+            return
         gout, add, last = eng.contrib_kernel(inv.buf)
         assert add is None and not inv.buf.bns
         eng.op(eng.ops_bwd, "dl3_phase_shift", ptr(self.outv.buf.grad), ptr(gout), eng.B, inv.buf.H, inv.buf.W,

@@ -753,3 +753,30 @@ def test_split_math_under_hipgraph_capture():
     assert np.array_equal(out[("f32", True)], out[("f32", False)])
     assert not np.array_equal(out[("split", False)], out[("f32", False)])   # it really is another arithmetic
     assert _l2(out[("split", False)], out[("f32", False)]) < 2e-2           # ... within what separates two fp32 orders
+
+
+def test_subpixel_head_fused_loss_equals_unfused(monkeypatch):
+    """SegModel 'subpixel' head in training: dl3_shuffle_softmax_xent (loss on the unshuffled Subpixel output, no phase
+    shift in either direction) against the unfused plan (DL3_FUSE_SHUFFLE=0: phase shift, softmax_xent, inverse shift):
+    same loss, same gradients (same arithmetic per pixel; only the order of the loss partial sums differs)"""
+    model, params = _build(input_shape=(64, 64, 3), classes=3, head="subpixel")
+    _load(model, params)
+    rng = np.random.default_rng(21)
+    x = rng.integers(0, 256, (2, 64, 64, 3)).astype(np.float32)
+    y = rng.integers(0, 4, (2, 64 * 64)).astype(np.float32)
+    sw = ((y < 3) * rng.uniform(0.5, 2.0, y.shape)).astype(np.float32)
+    out = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("DL3_FUSE_SHUFFLE", fuse)
+        eng = model._engine(2, True, dropout=False, use_graph=False, seed=300 + int(fuse))
+        assert (eng.fused_shuffle is not None) == (fuse == "1")
+        names = [o[0] for o in eng.ops_fwd + eng.ops_bwd]
+        assert ("dl3_phase_shift" in names) == (fuse == "0") and ("dl3_shuffle_softmax_xent" in names) == (fuse == "1")
+        eng.set_input(x)
+        eng.set_targets(y, sw)
+        eng.fwd_bwd()
+        torch.cuda.synchronize()
+        out[fuse] = (eng.grads.cpu().numpy().copy(), float(eng.loss[0].item()), eng.logits().copy())
+    assert np.array_equal(out["1"][2], out["0"][2])                     # logits() on demand in the fused engine
+    assert abs(out["1"][1] - out["0"][1]) < 1e-6 * abs(out["0"][1])
+    assert _l2(out["1"][0], out["0"][0]) < 1e-6

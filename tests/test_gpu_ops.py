@@ -709,6 +709,40 @@ def test_softmax_argmax_xent(L, C, void_w):
     assert abs(host(lp).astype(np.float64).sum() - loss_ref) < 1e-5 * abs(loss_ref)
     assert relerr(host(probs), p_ref[0]) < 1e-5
 
+@pytest.mark.parametrize("N,H,W,C,r,void_w", [(2, 4, 13, 21, 8, False), (2, 4, 13, 21, 8, True), (1, 3, 5, 7, 3, False),
+                                              (2, 5, 6, 3, 4, True), (1, 2, 9, 30, 2, False)])
+def test_shuffle_softmax_xent(L, N, H, W, C, r, void_w):
+    """dl3_shuffle_softmax_xent == the reference's phase shift (subpixel.py:77-88) followed by the loss (utils.py:127-130),
+    with the gradient handed back in the layout of the Subpixel convolution's own output (full and ragged pixel blocks,
+    the SegModel head's 21 x 8 x 8, odd r, C > 24)"""
+    rng = np.random.default_rng(17)
+    u = rng.normal(0, 2, (N, H, W, C * r * r)).astype(np.float32)
+    M = N * H * r * W * r
+    labels = rng.integers(0, C + 1, M).astype(np.float32)
+    w = _sample_weights(rng, labels, C, void_w)
+    shuffled = O.phase_shift(u.astype(np.float64), r).reshape(1, M, C)
+    loss_ref, dl_ref, _ = O.loss_sparse_xent_ignoring_last_label(shuffled, labels[None], w.astype(np.float64)[None])
+    # the inverse permutation of the reference gradient: du[n, ia, ib, ch*r*r + p*r + q] = dl[n, ia*r+q, ib*r+p, ch]
+    dl4 = dl_ref.reshape(N, H, r, W, r, C)                       # [n, ia, q, ib, p, ch]
+    du_ref = dl4.transpose(0, 1, 3, 5, 4, 2).reshape(N, H, W, C * r * r)   # [n, ia, ib, ch, p, q]
+    nnz = empty(1)
+    call("dl3_count_nonzero", ptr(dev(w)), M, ptr(nnz))
+    P = L.dl3_shuffle_xent_partials(N, H, W, C, r)
+    assert P > 0
+    du, lp = empty(*u.shape), empty(P)
+    call("dl3_shuffle_softmax_xent", ptr(dev(u)), ptr(dev(labels)), ptr(dev(w)), ptr(nnz), ptr(du), ptr(lp), N, H, W, C, r)
+    assert relerr(host(du), du_ref) < 1e-5
+    assert abs(host(lp).astype(np.float64).sum() - loss_ref) < 1e-5 * abs(loss_ref)
+    # and the composition of the two existing entry points gives the same numbers
+    y, dl = empty(N, H * r, W * r, C), empty(M, C)
+    lp2 = empty(L.dl3_rows_partials(M))
+    call("dl3_phase_shift", ptr(dev(u)), ptr(y), N, H, W, C, r, 0)
+    call("dl3_softmax_xent", ptr(y), ptr(dev(labels)), ptr(dev(w)), ptr(nnz), None, ptr(dl), ptr(lp2), M, C)
+    back = empty(*u.shape)
+    call("dl3_phase_shift", ptr(dl), ptr(back), N, H, W, C, r, 1)
+    assert relerr(host(du), host(back)) < 1e-6
+    assert L.dl3_shuffle_xent_partials(1, 2, 3, 600, 8) == 0   # a pixel too large for the LDS tile: caller falls back
+
 
 @pytest.mark.parametrize("void_w", [False, True])
 def test_fused_upsample_xent(L, void_w):
