@@ -199,6 +199,8 @@ class Engine:
         # BatchNorm launches of the chain instead of queueing between them.  DL3_FORK=0: one stream.
         self.fork = os.environ.get("DL3_FORK", "0") == "1"
         self.bn_sites = []
+        self.add_of_buf = {}        # id(Add output Buf) -> AddUnit
+        self.prestat = {}           # id(Buf) -> (dpart, P, ld): BatchNorm-backward sums already reduced by a producer's epilogue
         self._side = set()          # id(op record) of the launches that run on the side stream
         self._side_stream = None
         self._fork_events = []
@@ -649,6 +651,7 @@ class Engine:
         buf = Buf(self, self.B, H, W, C, l.name)
         self.bufs.append(buf)
         self.units.append(AddUnit(self, a, b, View(buf, 0, C)))
+        self.add_of_buf[id(buf)] = self.units[-1]
         self.views[id(l.output)] = View(buf, 0, C)
 
     def _lo_Concatenate(self, l):
@@ -794,6 +797,7 @@ class Engine:
             rec = ("dl3_transpose_batched", getattr(self.lib, "dl3_transpose_batched"),
                    [self._tdesc.data_ptr(), len(rows), t0], None)
             self.ops_bwd.insert(first_bwd, rec)
+        assert not self.prestat, "BatchNorm-backward sums reduced early but never folded"
         for b in self.bufs:
             if b.requires_grad and b.expected and b.done != b.expected:
                 raise RuntimeError("gradient accounting broken for buffer %s (%d/%d)" % (b.name, b.done, b.expected))
@@ -848,7 +852,11 @@ class Engine:
             buf.done += 1
             if buf.expected == 1:
                 buf.grad = g  # alias
-                if buf.bns:
+                if buf.bns and id(buf) in self.prestat:
+                    # the kernel that completed g already reduced sum(g), sum(g * x_hat) of THIS BatchNorm in its epilogue
+                    dpart, P, ld = self.prestat.pop(id(buf))
+                    self.finish_bn_bwd(buf, dpart, P, ld)
+                elif buf.bns:
                     P = self.lib.dl3_rows_partials(buf.M)
                     dpart = self.empty(P * buf.ld * 2)
                     self.op(self.ops_bwd, "dl3_grad_finish", ptr(g), buf.ld, 1, 1.0, ptr(g), buf.ld, None, 0,
@@ -859,6 +867,21 @@ class Engine:
                 buf.addend = g
             return
         self.contrib_elementwise(buf, view, ptr(g), buf.ld)
+
+    def alias_stats_target(self, ibuf):
+        """ibuf is the output of a residual Add whose gradient is about to be completed by a GEMM epilogue.  The Add's
+        backward hands that very tensor on, unchanged, to its inputs; for an input that is a BatchNorm'ed convolution
+        output with no other consumer (the project conv of the block, deeplabv3p.py:194-201) the BatchNorm-backward sums
+        over the gradient can be reduced right there instead of by a separate dl3_grad_finish pass over g and y
+        (round 3).  Returns that input's Buf or None."""
+        add = self.add_of_buf.get(id(ibuf))
+        if add is None or os.environ.get("DL3_FUSE_ADDSTAT", "1") == "0":
+            return None
+        hits = [v for v in (add.a, add.b)
+                if v.buf.requires_grad and v.buf.bns and v.buf.expected == 1 and v.buf.done == 0 and v.buf.grad is None
+                and v.buf.addend is None and v.act == ACT_NONE and v.off == 0 and v.C == v.buf.ld == ibuf.ld
+                and v.buf.M == ibuf.M and len(v.buf.bns) == 1 and v.buf.bns[0][1] == 0 and v.buf.bns[0][2] == v.buf.ld]
+        return hits[0].buf if len(hits) == 1 else None
 
     def grad_operand(self, out_view):
         """(g, ldg, yraw, ldy, cA, cB, cC) of a conv whose output is out_view"""
@@ -1115,6 +1138,18 @@ class PwUnit(_ConvBase):
         if need_stat and (inv.off != 0 or inv.C != ibuf.ld):
             raise NotImplementedError("BN-backward statistics through a channel slice")
         need_x = a != ACT_NONE or need_stat
+        tgt = None
+        if last and not need_x and inv.off == 0 and inv.C == ibuf.ld:
+            # the epilogue's forward-input slot is free (no mask, no BatchNorm on the Add output): use it for the sums of
+            # the BatchNorm this gradient reaches unchanged through the residual Add
+            tgt = eng.alias_stats_target(ibuf)
+        if tgt is not None:
+            dpart = eng.empty(P * tgt.ld * 2)
+            eng.op(eng.ops_bwd, "dl3_pwconv_bwd_data", g, ldg, y, ldy, cA, cB, cC, ptr(wT), ptr(gout), ibuf.ld,
+                   ptr(tgt.t), tgt.ld, None, None, ACT_NONE, ptr(add), ibuf.ld, 1, 1.0,
+                   tgt.vptr(V_MEAN), tgt.vptr(V_INVSTD), ptr(dpart), M, K, N)
+            eng.prestat[id(tgt)] = (dpart, P, tgt.ld)
+            return
         eng.op(eng.ops_bwd, "dl3_pwconv_bwd_data", g, ldg, y, ldy, cA, cB, cC, ptr(wT),
                gout.data_ptr() + 4 * inv.off, ibuf.ld, inv.p() if need_x else None, inv.ld,
                s if a != ACT_NONE else None, t if a != ACT_NONE else None, a,
