@@ -110,7 +110,7 @@ def build_engine(args):
 def _work(name, a):
     """(family, shape string, algorithmic FLOPs, algorithmic bytes) of one C-ABI launch; None = not accounted"""
     nz = lambda p: p is not None and p != 0
-    if name == "dl3_pwconv_fwd":
+    if name in ("dl3_pwconv_fwd", "dl3_pwconv_fwd_add"):
         M, K, N = a[9], a[10], a[11]
         return "gemm", "fwd M=%d K=%d N=%d" % (M, K, N), 2.0 * M * K * N, 4.0 * (M * K + M * N + K * N)
     if name == "dl3_pwconv_bwd_data":

@@ -87,6 +87,12 @@ int dl3_pwconv_partials(int M, int K, int N);
 int dl3_pwconv_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
                    const float *w, const float *bias, float *y, int ldy, int M, int K, int N,
                    float *stat_partial, void *stream);
+/* the same with an addend: y[m,:] += add[(m / add_div) * ldadd + :] — add_div = 1: a residual tensor; add_div = H*W: one
+ * row per image, i.e. the contribution of channels that are constant over the image (the ASPP image-pooling branch,
+ * deeplabv3p.py:375-382,:402-406: the broadcast 1x1 feature never has to be materialised or multiplied per pixel) */
+int dl3_pwconv_fwd_add(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
+                       const float *w, const float *bias, float *y, int ldy, int M, int K, int N,
+                       float *stat_partial, const float *add, int ldadd, int add_div, void *stream);
 /* dx[M,K](lddx) = mask_{in_act}(dY[M,N] . wT[N,K]) + add_scale*dx_add ; dY = cA*g + cB*yraw + cC.
  * x/in_scale/in_shift/in_act describe the FORWARD input (needed for the mask and x_hat);
  * dx_add row address = dx_add + (m / add_div)*ldadd (add_div = H*W broadcasts a per-image vector);

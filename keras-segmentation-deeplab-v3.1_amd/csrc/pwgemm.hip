@@ -408,8 +408,15 @@ __device__ __forceinline__ void stream_epilogue_full(const GemmArgs &P, const f3
         for (int r = 0; r < 16; r++) xr_[r] = (px + (size_t)((r & 3) + 8 * (r >> 2)) * P.ld_epx)[lo_x];
       }
       if (ADD) {
+        if (P.add_div > 1) {
+          // one addend row per image (run_gemm only sends a launch here when 32-row blocks never straddle two images)
+          const float a0 = P.add_scale * P.ep_add[(urow / (size_t)P.add_div) * P.ld_add + ucol + l31];
 #pragma unroll
-        for (int r = 0; r < 16; r++) ad[r] = P.add_scale * (pa + (size_t)((r & 3) + 8 * (r >> 2)) * P.ld_add)[lo_a];
+          for (int r = 0; r < 16; r++) ad[r] = a0;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; r++) ad[r] = P.add_scale * (pa + (size_t)((r & 3) + 8 * (r >> 2)) * P.ld_add)[lo_a];
+        }
       }
 #pragma unroll
       for (int r = 0; r < 16; r++) {
@@ -774,7 +781,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
 #pragma unroll
           for (int r = 0; r < 16; r++) {
             const int row = min(rbase + (r & 3) + 8 * (r >> 2), P.M - 1);
-            const int arow_ = (!FWD && P.add_div > 1) ? row / P.add_div : row;
+            const int arow_ = (P.add_div > 1) ? row / P.add_div : row;
             ad[r] = P.add_scale * P.ep_add[(size_t)arow_ * P.ld_add + colc];
           }
         } else {
@@ -1278,7 +1285,9 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   // spill.  DL3_GEMM_IMPL=0 forces the staged kernel (which also serves unaligned operands).
   if (stream) {
     dim3 blk(256);
-    const bool fwd = !two && !A.ep_x && A.stat_mode != 2 && !(A.ep_add && A.add_div > 1);
+    // (a per-image addend stays on the forward instantiation when its straight-line epilogue can take it: 32-row blocks
+    // inside one image)
+    const bool fwd = !two && !A.ep_x && A.stat_mode != 2 && !(A.ep_add && A.add_div > 1 && A.add_div % 32 != 0);
     if (split_math() && c.id != 5 && c.id != 6) {  // (the 32-row small-M tiles keep the f32 MFMA: their split weight tiles exceed the LDS)
       const unsigned dyn = 4u * (two ? 3 : 2) * (unsigned)dl3_cdiv(A.K, 32) * 32;
       const int ktiles = dl3_cdiv(A.K, 32);
@@ -1469,6 +1478,30 @@ extern "C" int dl3_pwconv_fwd(const float *x, int ldx, const float *in_scale, co
   DL3_CHECK_ARG(written >= 0, "pwconv_fwd: split-math weight scratch unavailable (first launch inside a stream capture?)");
   if (stat_partial) pad_partials(stat_partial, M, K, N, written, st);
   DL3_LAUNCH_CHECK("pwconv_fwd");
+  return DL3_OK;
+}
+
+extern "C" int dl3_pwconv_fwd_add(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
+                                  const float *w, const float *bias, float *y, int ldy, int M, int K, int N,
+                                  float *stat_partial, const float *add, int ldadd, int add_div, void *stream) {
+  int rc = gemm_common_check("pwconv_fwd_add", M, K, N);
+  if (rc) return rc;
+  DL3_CHECK_ARG(x && w && y && add, "pwconv_fwd_add: null pointer");
+  DL3_CHECK_ARG(ldx >= K && ldy >= N && ldadd >= N && add_div >= 1, "pwconv_fwd_add: bad leading dimension / add_div");
+  DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "pwconv_fwd_add: scale/shift must come together");
+  GemmArgs A{};
+  A.a = x; A.lda = ldx; A.a2 = nullptr; A.lda2 = 0;
+  A.ka = in_scale; A.kb = nullptr; A.kc = in_shift; A.a_act = in_act;
+  A.b = w; A.ldb = N; A.bias = bias; A.c = y; A.ldc = ldy;
+  A.M = M; A.K = K; A.N = N;
+  A.ep_add = add; A.ld_add = ldadd; A.add_div = add_div; A.add_scale = 1.f;
+  A.stat_mode = stat_partial ? 1 : 0;
+  A.part = stat_partial;
+  hipStream_t st = (hipStream_t)stream;
+  const int written = run_gemm(A, st);
+  DL3_CHECK_ARG(written >= 0, "pwconv_fwd_add: split-math weight scratch unavailable (first launch inside a stream capture?)");
+  if (stat_partial) pad_partials(stat_partial, M, K, N, written, st);
+  DL3_LAUNCH_CHECK("pwconv_fwd_add");
   return DL3_OK;
 }
 

@@ -423,6 +423,8 @@ class Engine:
                 self.consumers.setdefault(id(t), []).append(l)
         self.placement = {}
         self.concat_bufs = {}
+        self.bcast_resize = {}   # id(ResizeBilinear layer) -> the Concatenate it feeds as a per-image constant
+        self.bcast_src = {}      # id(concat Buf) -> (View of the 1x1 source, channels)
         for l in topo:
             if l.kind == "Concatenate":
                 self._place_concat(l)
@@ -438,13 +440,34 @@ class Engine:
             l = l.inbound[0].layer
         return l
 
+    def _bcast_input(self, l):
+        """the first input of Concatenate l if it is the bilinear 'resize' of a 1x1 map — a per-image constant, e.g. the
+        ASPP image-pooling branch (deeplabv3p.py:375-382) — and the Concatenate feeds exactly one 1x1 convolution: that
+        branch is then never materialised; the convolution adds its contribution once per image (PwUnit img_add)"""
+        if os.environ.get("DL3_FUSE_BCAST", "1") == "0":
+            return None
+        t = l.inbound[0]
+        p = self._producer_of(t)
+        cs = self.consumers.get(id(l.output), [])
+        if (p.kind == "ResizeBilinear" and p is t.layer and tuple(p.inbound[0].shape[:2]) == (1, 1) and len(l.inbound) > 1
+                and len(cs) == 1 and cs[0].kind == "Conv2D" and cs[0].cfg["k"] == 1 and cs[0].cfg["stride"] == 1
+                and len(self.consumers.get(id(t), [])) == 1):
+            return p
+        return None
+
     def _place_concat(self, l):
         H, W, C = l.output.shape
+        bc = self._bcast_input(l)
+        if bc is not None:
+            self.bcast_resize[id(bc)] = l
+            C -= l.inbound[0].shape[2]
         buf = Buf(self, self.B, H, W, C, l.name)
         self.bufs.append(buf)
         self.concat_bufs[id(l)] = buf
         off = 0
         for t in l.inbound:
+            if bc is not None and t is l.inbound[0]:
+                continue
             p = self._producer_of(t)
             ok = (p.kind in ("Conv2D",) and p.cfg["k"] == 1 and p.cfg["stride"] == 1) or p.kind == "ResizeBilinear"
             if p.kind == "Dropout" or not ok:
@@ -569,7 +592,18 @@ class Engine:
         Ho, Wo, N = v.shape[1], v.shape[2], self.phys[id(l.output)]
         buf, off = self._new_out(l, Ho, Wo, N)
         assert off != 0 or buf.ld == N or id(l) in self.placement, (l.name, buf.ld, N)  # stored width == buffer width
-        u = PwUnit(self, l, v, View(buf, off, N), want_stat=self._want_stat(l, buf.M))
+        if id(v.buf) in self.bcast_src:
+            # Concatenate([broadcast of a 1x1 map, per-pixel branches]) -> 1x1 convolution: rows 0..Cb-1 of the kernel meet a
+            # per-image constant: a GEMM of B rows whose result is added once per image; the other rows run per pixel
+            sv, Cb = self.bcast_src[id(v.buf)]
+            if v.off != 0 or v.C != v.buf.ld:
+                raise NotImplementedError("convolution over a slice of a Concatenate with a broadcast input")
+            ib = Buf(self, self.B, 1, 1, N, l.name + "_per_image")
+            self.bufs.append(ib)
+            self.units.append(PwUnit(self, l, sv, View(ib, 0, N), want_stat=False, wrow0=0, use_bias=False))
+            u = PwUnit(self, l, v, View(buf, off, N), want_stat=self._want_stat(l, buf.M), wrow0=Cb, img_add=ib)
+        else:
+            u = PwUnit(self, l, v, View(buf, off, N), want_stat=self._want_stat(l, buf.M))
         self._register(u, buf, off)
         self.views[id(l.output)] = View(buf, off, N)
 
@@ -659,6 +693,11 @@ class Engine:
         acts = set()
         for t in l.inbound:
             v = self.views[id(t)]
+            if v is None and id(buf) in self.bcast_src:
+                sv = self.bcast_src[id(buf)][0]
+                if sv.act != ACT_NONE:
+                    acts.add(sv.act)
+                continue
             if v.buf is not buf:
                 raise NotImplementedError("concat input %s was not placed" % t.layer.name)
             if v.act != ACT_NONE:
@@ -680,6 +719,11 @@ class Engine:
 
     def _lo_ResizeBilinear(self, l):
         v = self._in(l)
+        if id(l) in self.bcast_resize:
+            cat = self.bcast_resize[id(l)]
+            self.bcast_src[id(self.concat_bufs[id(cat)])] = (v, v.C)
+            self.views[id(l.output)] = None  # never materialised (Engine._bcast_input)
+            return
         Ho, Wo = l.cfg["size"]
         buf, off = self._new_out(l, Ho, Wo, v.C)
         nonneg = v.act in (ACT_RELU, ACT_RELU6) or v.buf.nonneg
@@ -1104,33 +1148,67 @@ class _ConvBase:
 
 
 class PwUnit(_ConvBase):
-    """Conv2D 1x1 (+bias): dl3_pwconv_fwd / _bwd_weight / _bwd_data"""
+    """Conv2D 1x1 (+bias): dl3_pwconv_fwd / _bwd_weight / _bwd_data.
+    wrow0: first row of the layer's [K_total][N] kernel this unit multiplies with (its K = inv.C rows from there);
+    img_add: Buf [B,1,1,N] added per image (dl3_pwconv_fwd_add) — together they split a convolution over a Concatenate
+    whose first input is the broadcast of a 1x1 map (the ASPP image-pooling branch) into a per-image GEMM of B rows and
+    a per-pixel GEMM over the remaining channels (Engine._lo_Conv2D)."""
 
-    def __init__(self, eng, layer, inv, outv, want_stat):
+    def __init__(self, eng, layer, inv, outv, want_stat, wrow0=0, img_add=None, use_bias=True):
         super().__init__(eng, layer, inv, outv, want_stat)
         self.M, self.K, self.N = inv.buf.M, inv.C, outv.C
-        self.bias = layer.name + "/bias:0" if layer.cfg["use_bias"] else None
+        self.wrow0, self.img_add = int(wrow0), img_add
+        self.bias = layer.name + "/bias:0" if (layer.cfg["use_bias"] and use_bias) else None
         if want_stat:
             self.P = eng.lib.dl3_pwconv_partials(self.M, self.K, self.N)
             self.stat = eng.empty(self.P * self.N * 2)
         s, t, a = inv.xform()
-        eng.op(eng.ops_fwd, "dl3_pwconv_fwd", inv.p(), inv.ld, s, t, a, eng.wptr(self.wname()),
-               eng.wptr(self.bias) if self.bias else None, outv.p(), outv.ld, self.M, self.K, self.N, ptr(self.stat))
+        w = eng.wptr(self.wname()) + 4 * self.wrow0 * self.N
+        if img_add is None:
+            eng.op(eng.ops_fwd, "dl3_pwconv_fwd", inv.p(), inv.ld, s, t, a, w,
+                   eng.wptr(self.bias) if self.bias else None, outv.p(), outv.ld, self.M, self.K, self.N, ptr(self.stat))
+        else:
+            assert img_add.M == eng.B and img_add.ld == self.N and self.M % eng.B == 0
+            eng._consume(View(img_add, 0, self.N))
+            eng.op(eng.ops_fwd, "dl3_pwconv_fwd_add", inv.p(), inv.ld, s, t, a, w,
+                   eng.wptr(self.bias) if self.bias else None, outv.p(), outv.ld, self.M, self.K, self.N, ptr(self.stat),
+                   ptr(img_add.t), self.N, self.M // eng.B)
+
+    def _bwd_img_add(self, g, ldg, y, ldy, cA, cB, cC):
+        """gradient of the per-image addend: S[img, n] = sum over the image's pixels of dY[m, n], dY = cA*g + cB*y + cC
+        (two per-image column sums with the coefficients folded in, then their sum)"""
+        eng, N, B = self.eng, self.N, self.eng.B
+        HW = self.M // B
+        ab = self.img_add
+        gout, add, last = eng.contrib_kernel(ab)
+        assert add is None and last and not ab.bns
+        if cA is None:
+            eng.op(eng.ops_bwd, "dl3_gap_fwd", g, ldg, None, None, ACT_NONE, ptr(gout), B, HW, N, 1.0)
+            return
+        sg, sy, zero = eng.empty(B * N), eng.empty(B * N), eng.zeros(N)
+        eng.op(eng.ops_bwd, "dl3_gap_fwd", g, ldg, cA, cC, ACT_NONE, ptr(sg), B, HW, N, 1.0)
+        eng.op(eng.ops_bwd, "dl3_gap_fwd", y, ldy, cB, ptr(zero), ACT_NONE, ptr(sy), B, HW, N, 1.0)
+        eng.op(eng.ops_bwd, "dl3_affine_add", ptr(sg), N, None, None, ACT_NONE, ptr(sy), N, None, None, ACT_NONE,
+               ptr(gout), N, B, N, 0.0, 0, None)
 
     def bwd(self):
         eng, inv, outv = self.eng, self.inv, self.outv
         M, K, N = self.M, self.K, self.N
         g, ldg, y, ldy, cA, cB, cC = eng.grad_operand(outv)
         s, t, a = inv.xform()
+        wsrc = eng.wptr(self.wname()) + 4 * self.wrow0 * N
         if eng.trainable(self.wname()) or (self.bias and eng.trainable(self.bias)):
             ws = eng.lib.dl3_pwconv_bwd_weight_workspace(M, K, N)
             eng.op_ws_side(eng.ops_bwd, "dl3_pwconv_bwd_weight", ws, 17, inv.p(), inv.ld, s, t, a, g, ldg, y, ldy, cA, cB, cC,
-                      eng.gptr(self.wname()), eng.gptr(self.bias) if self.bias else None, M, K, N, 0, ws)
+                      eng.gptr(self.wname()) + (4 * self.wrow0 * N if eng.trainable(self.wname()) else 0),
+                      eng.gptr(self.bias) if self.bias else None, M, K, N, 0, ws)
+        if self.img_add is not None:
+            self._bwd_img_add(g, ldg, y, ldy, cA, cB, cC)
         ibuf = inv.buf
         if not ibuf.requires_grad:
             return
         wT = eng.empty(K * N)
-        eng.transpose(eng.wptr(self.wname()), wT, K, N)
+        eng.transpose(wsrc, wT, K, N)
         gout, add, last = eng.contrib_kernel(ibuf)
         need_stat = last and bool(ibuf.bns)
         P = eng.lib.dl3_pwconv_partials(M, N, K)

@@ -449,6 +449,27 @@ def test_conv3x3(L, shape):
         assert relerr(s2, (dx_ref * (x - mean) * invstd).sum((0, 1, 2))) < 1e-3
 
 
+@pytest.mark.parametrize("M,K,N,div", [(4 * 96, 40, 48, 96), (3 * 4096, 256, 256, 4096), (2 * 50, 24, 21, 50), (300, 64, 160, 1)])
+def test_pwconv_fwd_add(L, M, K, N, div):
+    """dl3_pwconv_fwd_add: y = act(s*x+t) . w + bias + add[m // div] — a residual tensor (div = 1) or one row per image
+    (the ASPP image-pooling branch as a per-image term): the straight-line epilogue (32-row blocks inside one image),
+    the predicated one (div = 50), full and ragged tiles; BatchNorm partial sums include the addend"""
+    rng = np.random.default_rng(M + N)
+    x = rng.normal(0, 1, (M, K)).astype(np.float32)
+    w = rng.normal(0, 0.2, (K, N)).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, K).astype(np.float32), rng.normal(0, 0.3, K).astype(np.float32)
+    bias = rng.normal(0, 0.5, N).astype(np.float32)
+    add = rng.normal(0, 1, (M // div, N)).astype(np.float32)
+    ref = np_act(x.astype(np.float64) * sc + sh, 2) @ w.astype(np.float64) + bias + np.repeat(add.astype(np.float64), div, axis=0)
+    P = L.dl3_pwconv_partials(M, K, N)
+    y, part = empty(M, N), empty(P, N, 2)
+    call("dl3_pwconv_fwd_add", ptr(dev(x)), K, ptr(dev(sc)), ptr(dev(sh)), 2, ptr(dev(w)), ptr(dev(bias)), ptr(y), N, M, K, N,
+         ptr(part), ptr(dev(add)), N, div)
+    assert relerr(host(y), ref) < 2e-5
+    s1, s2 = fold_partials(part, P, N)
+    assert relerr(s1, ref.sum(0)) < 1e-4 and relerr(s2, (ref ** 2).sum(0)) < 1e-4
+
+
 @pytest.mark.parametrize("M", [2, 37, 4096])
 def test_bn_finalize_direct_small_tensors(L, M):
     """dl3_bn_finalize_direct: two-pass double statistics straight from a small tensor (the image-pooling BatchNorm,
