@@ -193,10 +193,10 @@ class Engine:
         self.fold_tail = os.environ.get("DL3_FOLD_TAIL", "1") != "0"  # 0: keep the full-resolution dlogits (test aid)
         self.dw_impl = dw_impl
         self.ops_prep, self.ops_fwd, self.ops_bwd = [], [], []
-        # backward fork (round 3): the 1x1-conv weight gradients are off the critical path until Adam — they leave the
-        # backward chain as a second captured stream (event fork behind the launch that completes their dY, one join at
-        # the end), so that the matrix-pipe-bound weight-gradient kernels share the CUs with the HBM-bound depthwise /
-        # BatchNorm launches of the chain instead of queueing between them.  DL3_FORK=0: one stream.
+        # backward fork (round 3, opt-in: DL3_FORK=1): the 1x1-conv weight gradients are off the critical path until Adam —
+        # they leave the backward chain as a second captured stream (event fork behind the launch that completes their dY,
+        # one join at the end).  Measured SLOWER at every batch size (two 256-VGPR workgroups fill a CU), so
+        # the default is one stream; kept because it is tested bit-identical and documents the experiment.
         self.fork = os.environ.get("DL3_FORK", "0") == "1"
         self.bn_sites = []
         self.add_of_buf = {}        # id(Add output Buf) -> AddUnit
@@ -591,7 +591,7 @@ class Engine:
             v = View(cbuf, 0, v.C)
         Ho, Wo, N = v.shape[1], v.shape[2], self.phys[id(l.output)]
         buf, off = self._new_out(l, Ho, Wo, N)
-        assert off != 0 or buf.ld == N or id(l) in self.placement, (l.name, buf.ld, N)  # stored width == buffer width
+        assert id(l) in self.placement or buf.ld == N, (l.name, buf.ld, N)  # an own buffer is exactly as wide as stored
         if id(v.buf) in self.bcast_src:
             # Concatenate([broadcast of a 1x1 map, per-pixel branches]) -> 1x1 convolution: rows 0..Cb-1 of the kernel meet a
             # per-image constant: a GEMM of B rows whose result is added once per image; the other rows run per pixel
