@@ -197,7 +197,11 @@ class Engine:
         # they leave the backward chain as a second captured stream (event fork behind the launch that completes their dY,
         # one join at the end).  Measured SLOWER at every batch size (two 256-VGPR workgroups fill a CU), so
         # the default is one stream; kept because it is tested bit-identical and documents the experiment.
-        self.fork = os.environ.get("DL3_FORK", "0") == "1"
+        self.fork = os.environ.get("DL3_FORK", "0") in ("1", "2")
+        # DL3_FORK=2 (experiment): only the weight gradient that can run next to an HBM-bound depthwise backward launch
+        # leaves the chain, and the chain's next GEMM waits for it: matrix-bound and HBM-bound kernels overlap, two GEMMs never do
+        self.fork_pairs = os.environ.get("DL3_FORK", "0") == "2"
+        self._join_before = set()   # id(op record): the main stream waits for the side stream before this launch
         self.bn_sites = []
         self.add_of_buf = {}        # id(Add output Buf) -> AddUnit
         self.prestat = {}           # id(Buf) -> (dpart, P, ld): BatchNorm-backward sums already reduced by a producer's epilogue
@@ -384,6 +388,8 @@ class Engine:
         nev = 0
         for rec in lst:
             name, fn, args, _ = rec
+            if id(rec) in self._join_before:
+                main.wait_stream(side)
             if id(rec) in self._side:
                 if pending:
                     if nev == len(self._fork_events):
@@ -841,10 +847,44 @@ class Engine:
             rec = ("dl3_transpose_batched", getattr(self.lib, "dl3_transpose_batched"),
                    [self._tdesc.data_ptr(), len(rows), t0], None)
             self.ops_bwd.insert(first_bwd, rec)
+        if self.fork_pairs:
+            self._pair_wgrads_with_depthwise()
         assert not self.prestat, "BatchNorm-backward sums reduced early but never folded"
         for b in self.bufs:
             if b.requires_grad and b.expected and b.done != b.expected:
                 raise RuntimeError("gradient accounting broken for buffer %s (%d/%d)" % (b.name, b.done, b.expected))
+
+    def _pair_wgrads_with_depthwise(self):
+        """DL3_FORK=2: every depthwise backward launch takes the nearest earlier 1x1 weight gradient with it (moved to just
+        in front of it, on the side stream); every other weight gradient stays in the chain; the next 1x1 GEMM of the chain
+        waits for the side stream."""
+        ops = self.ops_bwd
+        side_all = [r for r in ops if id(r) in self._side]
+        paired = set()
+        j = 0
+        while j < len(ops):
+            if ops[j][0] == "dl3_dwconv3x3_bwd":
+                i = j - 1
+                while i >= 0 and not (ops[i][0] == "dl3_pwconv_bwd_weight" and id(ops[i]) in self._side and id(ops[i]) not in paired):
+                    if ops[i][0] == "dl3_dwconv3x3_bwd":
+                        i = -1
+                        break
+                    i -= 1
+                if i >= 0:
+                    rec = ops.pop(i)
+                    ops.insert(j - 1, rec)   # directly in front of the depthwise launch (behind it measured no gain at all)
+                    paired.add(id(rec))
+            j += 1
+        for p, rec in enumerate(ops):
+            if id(rec) in paired:
+                k = p + 1
+                while k < len(ops) and (id(ops[k]) in paired or not ops[k][0].startswith("dl3_pwconv_")):
+                    k += 1
+                if k < len(ops):
+                    self._join_before.add(id(ops[k]))
+        for r in side_all:
+            if id(r) not in paired:
+                self._side.discard(id(r))
 
     # ---- gradient contribution protocol ---------------------------------------------
     def contrib_kernel(self, buf):

@@ -705,11 +705,12 @@ def test_backward_fork_is_bit_identical(monkeypatch):
     y = rng.integers(0, 4, (2, 64 * 64)).astype(np.float32)
     sw = (y < 3).astype(np.float32)
     got = {}
-    for fork in ("0", "1"):
+    for fork in ("0", "1", "2"):   # 2 = only the weight gradients paired with a depthwise backward launch leave the chain
         monkeypatch.setenv("DL3_FORK", fork)
         for use_graph in (False, True):
             eng = model._engine(2, True, dropout=False, use_graph=use_graph, seed=100 + int(fork))  # distinct engine keys
-            assert eng.fork == (fork == "1") and bool(eng._side) == (fork == "1")
+            assert eng.fork == (fork != "0") and bool(eng._side) == (fork != "0")
+            assert bool(eng._join_before) == (fork == "2")
             eng.set_input(x)
             eng.set_targets(y, sw)
             for _ in range(3 if use_graph else 1):   # the graph is captured on the second call
