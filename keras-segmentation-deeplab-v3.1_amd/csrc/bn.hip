@@ -14,18 +14,33 @@
 
 namespace {
 
+constexpr int FOLD_U = 8;
+
 // sum over P partial rows of two interleaved values per channel; 8 channels x 32 row lanes
 // per block, fixed order, double accumulation.  Result valid for threads with pl == 0.
 __device__ __forceinline__ void fold2(const float *part, int P, int ldc, int c, bool cok, double &o1, double &o2,
                                       double *red /* [32][8][2] */) {
   const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
   double s1 = 0.0, s2 = 0.0;
-  if (cok)
-    for (int p = pl; p < P; p += 32) {
-      const float *q = part + ((size_t)p * ldc + c) * 2;
-      s1 += (double)q[0];
-      s2 += (double)q[1];
+  if (cok) {
+    // FOLD_U rows per trip: their loads (clamped row index, always in bounds) are issued together and added in row
+    // order afterwards — the same sum as a one-row loop, without one exposed L2 round trip per row (P/32 = 8-43 of
+    // them made these launches 8-10 us each; a rows-past-the-end slot adds +0.0)
+    for (int p0 = pl; p0 < P; p0 += 32 * FOLD_U) {
+      float2 v[FOLD_U];
+#pragma unroll
+      for (int u = 0; u < FOLD_U; u++) {
+        const int p = p0 + 32 * u;
+        v[u] = *reinterpret_cast<const float2 *>(part + ((size_t)min(p, P - 1) * ldc + c) * 2);
+        if (p >= P) v[u] = make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < FOLD_U; u++) {
+        s1 += (double)v[u].x;
+        s2 += (double)v[u].y;
+      }
     }
+  }
   red[(pl * 8 + cl) * 2 + 0] = s1;
   red[(pl * 8 + cl) * 2 + 1] = s2;
   __syncthreads();
@@ -47,21 +62,28 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
   const int c = blockIdx.x * 8 + (threadIdx.x & 7);
   const bool cok = c < C;
   double s1, s2;
+  // per-channel operands requested before the fold (its barrier keeps them there): their round trips overlap the fold's
+  // (unconditional, clamped index, a stand-in pointer when there are no moving statistics: a predicated load gets its
+  // own exec-masked block and an s_waitcnt vmcnt(0) behind it)
+  const bool fin = (threadIdx.x >> 3) == 0 && cok;
+  const int cc = min(c, C - 1);
+  const float ga = gamma[cc], be = beta[cc];
+  const float mm0 = (mmean ? mmean : gamma)[cc], mv0 = (mmean ? mvar : gamma)[cc];
   fold2(part, P, ldc, c, cok, s1, s2, red);
-  if ((threadIdx.x >> 3) == 0 && cok) {
+  if (fin) {
     const double m = s1 / count;
     double var = s2 / count - m * m;
     if (var < 0.0) var = 0.0;
     const double is = 1.0 / sqrt(var + (double)eps);
-    const double sc = (double)gamma[c] * is;
+    const double sc = (double)ga * is;
     scale[c] = (float)sc;
-    shift[c] = (float)((double)beta[c] - m * sc);
+    shift[c] = (float)((double)be - m * sc);
     mean[c] = (float)m;
     invstd[c] = (float)is;
     if (mmean) {
       const double unb = var * unbias;  // the framework's sample-variance factor (see dl3_bn_finalize in dl3.h)
-      mmean[c] = (float)((double)momentum * mmean[c] + (1.0 - (double)momentum) * m);
-      mvar[c] = (float)((double)momentum * mvar[c] + (1.0 - (double)momentum) * unb);
+      mmean[c] = (float)((double)momentum * mm0 + (1.0 - (double)momentum) * m);
+      mvar[c] = (float)((double)momentum * mv0 + (1.0 - (double)momentum) * unb);
     }
   }
 }
@@ -145,18 +167,21 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__res
   const int c = blockIdx.x * 8 + (threadIdx.x & 7);
   const bool cok = c < C;
   double s1, s2;
+  const bool fin = (threadIdx.x >> 3) == 0 && cok;  // operands requested before the fold (see bn_finalize_kernel)
+  const int cc = min(c, C - 1);
+  const float ga = gamma[cc], is0 = invstd[cc], mu0 = mean[cc];
   fold2(part, P, ldc, c, cok, s1, s2, red);
-  if ((threadIdx.x >> 3) == 0 && cok) {
+  if (fin) {
     // s1 = sum g = dbeta ; s2 = sum g * x_hat = dgamma
     if (dbeta) dbeta[c] = (float)s1;
     if (dgamma) dgamma[c] = (float)s2;
-    const double a = (double)gamma[c] * (double)invstd[c];
+    const double a = (double)ga * (double)is0;
     if (batch_mode) {
       // dy = a*(g - s1/M - x_hat*s2/M), x_hat = (y - mean)*invstd
-      const double b = -a * (double)invstd[c] * s2 / count;
+      const double b = -a * (double)is0 * s2 / count;
       cA[c] = (float)a;
       cB[c] = (float)b;
-      cC[c] = (float)(-a * s1 / count - b * (double)mean[c]);
+      cC[c] = (float)(-a * s1 / count - b * (double)mu0);
     } else {
       cA[c] = (float)a;
       cB[c] = 0.f;
@@ -175,7 +200,17 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__res
   const long col = (long)blockIdx.x * COLS + cl;
   float s = 0.f;
   if (col < n)
-    for (int p = pl; p < P; p += PL) s += part[(size_t)p * n + col];
+    for (int p0 = pl; p0 < P; p0 += PL * FOLD_U) {  // loads of FOLD_U rows in flight, added in row order (see fold2)
+      float v[FOLD_U];
+#pragma unroll
+      for (int u = 0; u < FOLD_U; u++) {
+        const int p = p0 + PL * u;
+        v[u] = part[(size_t)min(p, P - 1) * n + col];
+        if (p >= P) v[u] = 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < FOLD_U; u++) s += v[u];
+    }
   red[pl * COLS + cl] = s;
   __syncthreads();
   if (pl == 0 && col < n) {

@@ -1,16 +1,16 @@
 #!/bin/bash
-# same-call A/B of two builds of libdl3.so on the headline config: build_variants/libdl3_base.so against the in-tree library
+# same-call A/B of two builds of libdl3.so: build_variants/libdl3_base.so against the in-tree library, B = 128 / 16 / 2
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-out=$REPO/gpurun_out/r3ab; mkdir -p $out
+out=$REPO/gpurun_out/r3ab; mkdir -p $out; rm -f $out/b*.json
 cd $REPO
-timeout 900 python -m pytest tests/test_gpu_ops.py -q -x -k "xent" > $out/t.log 2>&1; echo "test rc $?" >> $out/t.log
+timeout 900 python -m pytest tests/test_gpu_ops.py -q -x -k "${AB_TESTS:-bn or reduce or partial}" > $out/t.log 2>&1; echo "test rc $?" >> $out/t.log
 B="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-split-leg --no-roofline"
-for rep in 1 2 3; do
-  DL3_LIBPATH=$REPO/build_variants/libdl3_base.so timeout 600 $B > $out/b_base_$rep.json 2> $out/b_base_$rep.err
-  timeout 600 $B > $out/b_new_$rep.json 2> $out/b_new_$rep.err
+for rep in 1 2; do
+  for b in 128 16 2; do
+    DL3_LIBPATH=$REPO/build_variants/libdl3_base.so timeout 600 $B --batch $b > $out/b${b}_base_$rep.json 2> $out/b${b}_base_$rep.err
+    timeout 600 $B --batch $b > $out/b${b}_new_$rep.json 2> $out/b${b}_new_$rep.err
+  done
 done
-timeout 600 $B --batch 16 > $out/b16_new.json 2>/dev/null
-DL3_LIBPATH=$REPO/build_variants/libdl3_base.so timeout 600 $B --batch 16 > $out/b16_base.json 2>/dev/null
 python - <<'PY' > $out/summary.txt
 import json, glob, os
 for p in sorted(glob.glob(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpurun_out/r3ab/b*.json"))):
