@@ -132,6 +132,10 @@ def _work(name, a):
         out_e, in_e = N * Ho * Wo * C, N * H * W * C
         by = out_e * (2 if nz(a[1]) else 1) + in_e * (1 + (1 if nz(a[10]) else 0) + (1 if nz(a[11]) else 0)) + 18 * C
         return fam, "bwd %dx%dx%dx%d s%d r%d" % (N, H, W, C, stride, rate), 2.0 * 2 * 9 * out_e, 4.0 * by
+    if name == "dl3_reduce_partials_batched":
+        # every weight-gradient slab fold of the pass in one launch: charged to the GEMM family (no FLOPs), as the fold
+        # behind each dl3_pwconv_bwd_weight launch used to be (a few of its entries are depthwise weight gradients)
+        return "gemm", "slab folds x%d" % a[1], 0.0, 0.0
     return "other", "", 0.0, 0.0
 
 

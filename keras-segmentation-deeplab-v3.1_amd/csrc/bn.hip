@@ -192,12 +192,11 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__res
 
 // out[i] = sum_p part[p][i]; COLS columns x PL row lanes per block
 template <int COLS, int PL>
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ part, int P, int n,
-                                                              float *__restrict__ out) {
+__device__ __forceinline__ void reduce_partials_block(const float *__restrict__ part, int P, int n,
+                                                      float *__restrict__ out, int block, float *red /* [256] */) {
   static_assert(COLS * PL == 256, "256 threads");
-  __shared__ float red[256];
   const int cl = threadIdx.x % COLS, pl = threadIdx.x / COLS;
-  const long col = (long)blockIdx.x * COLS + cl;
+  const long col = (long)block * COLS + cl;
   float s = 0.f;
   if (col < n)
     for (int p0 = pl; p0 < P; p0 += PL * FOLD_U) {  // loads of FOLD_U rows in flight, added in row order (see fold2)
@@ -218,6 +217,30 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__res
     for (int q = 0; q < PL; q++) t += red[q * COLS + cl];
     out[col] = t;
   }
+}
+
+template <int COLS, int PL>
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ part, int P, int n,
+                                                              float *__restrict__ out) {
+  __shared__ float red[256];
+  reduce_partials_block<COLS, PL>(part, P, n, out, blockIdx.x, red);
+}
+
+// columns per workgroup of a fold over P partial rows (few rows: wide blocks; many rows: more row lanes)
+__host__ __device__ inline int reduce_cols(int P) { return P <= 32 ? 64 : (P <= 256 ? 32 : 8); }
+
+// several folds in one launch: desc[m] = {partial, out, P, n, first workgroup}
+__global__ __launch_bounds__(256) void reduce_partials_batched_kernel(const long long *__restrict__ desc, int m) {
+  __shared__ float red[256];
+  int e = 0;
+  while (e + 1 < m && (long long)blockIdx.x >= desc[(e + 1) * 5 + 4]) ++e;  // m is a few dozen
+  const float *part = (const float *)desc[e * 5 + 0];
+  float *out = (float *)desc[e * 5 + 1];
+  const int P = (int)desc[e * 5 + 2], n = (int)desc[e * 5 + 3], block = blockIdx.x - (int)desc[e * 5 + 4];
+  const int cols = reduce_cols(P);
+  if (cols == 64) reduce_partials_block<64, 4>(part, P, n, out, block, red);
+  else if (cols == 32) reduce_partials_block<32, 8>(part, P, n, out, block, red);
+  else reduce_partials_block<8, 32>(part, P, n, out, block, red);
 }
 
 // out = act_a(sa*a+ta) + act_b(sb*b+tb), optional dropout; one thread per element, channel fastest
@@ -503,13 +526,26 @@ extern "C" int dl3_bn_bwd_finalize(const float *dstat_partial, int P, int ldc, i
 extern "C" int dl3_reduce_partials(const float *partial, int P, int n, float *out, void *stream) {
   DL3_CHECK_ARG(partial && out && P > 0 && n > 0, "reduce_partials: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  if (P <= 32)
+  const int cols = reduce_cols(P);
+  if (cols == 64)
     hipLaunchKernelGGL((reduce_partials_kernel<64, 4>), dim3(dl3_cdiv(n, 64)), dim3(256), 0, st, partial, P, n, out);
-  else if (P <= 256)
+  else if (cols == 32)
     hipLaunchKernelGGL((reduce_partials_kernel<32, 8>), dim3(dl3_cdiv(n, 32)), dim3(256), 0, st, partial, P, n, out);
   else
     hipLaunchKernelGGL((reduce_partials_kernel<8, 32>), dim3(dl3_cdiv(n, 8)), dim3(256), 0, st, partial, P, n, out);
   DL3_LAUNCH_CHECK("reduce_partials");
+  return DL3_OK;
+}
+
+extern "C" int dl3_reduce_partials_blocks(int P, int n) {
+  if (P <= 0 || n <= 0) return 0;
+  return dl3_cdiv(n, reduce_cols(P));
+}
+
+extern "C" int dl3_reduce_partials_batched(const long long *desc, int m, int total_blocks, void *stream) {
+  DL3_CHECK_ARG(desc && m > 0 && total_blocks > 0, "reduce_partials_batched: bad argument");
+  hipLaunchKernelGGL(reduce_partials_batched_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, desc, m);
+  DL3_LAUNCH_CHECK("reduce_partials_batched");
   return DL3_OK;
 }
 

@@ -21,6 +21,7 @@ namespace {
 
 struct DwGeom {
   int N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo;
+  int prows;  // rows of the caller's partial buffers (dl3_dwconv3x3_partials); the launch writes gridDim.y of them
 };
 
 // ---- block reduction over the 32 pixel lanes that share a channel quad -----------------
@@ -58,6 +59,17 @@ __device__ __forceinline__ void write_stat_partial(float *part, int p, int C, in
   d[4] = s1.z; d[5] = s2.z; d[6] = s1.w; d[7] = s2.w;
 }
 
+// The partial buffers are sized for the larger of the forward and backward decompositions: the owner of row p also zeroes
+// rows p + written, p + 2 * written, ... < rows (instead of a memset node behind the launch).
+__device__ __forceinline__ void pad_stat_partial(float *part, int p, int written, int rows, int C, int c) {
+  for (int q = p + written; q < rows; q += written) write_stat_partial(part, q, C, c, splat4(0.f), splat4(0.f));
+}
+__device__ __forceinline__ void pad_w_partial(float *wpart, int p, int written, int rows, int C, int c) {
+  for (int q = p + written; q < rows; q += written)
+#pragma unroll
+    for (int i = 0; i < 9; i++) st4(wpart + ((size_t)q * 9 + i) * C + c, splat4(0.f));
+}
+
 // Workgroup -> tile decode for the march kernels.  The grid is 1-D and padded to a multiple of 8: hardware hands
 // consecutive workgroup ids to the 8 XCDs round-robin, so id L runs on XCD L%8.  Virtual id v = (L%8)*chunk + L/8
 // makes consecutive v share an XCD (and its 4 MB L2) at about the same time; with the x segment as the fastest
@@ -83,7 +95,7 @@ __global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x,
                                                     const float *__restrict__ w, float *__restrict__ y,
                                                     int H, int W, int C, int r, int nchunk, int TK, int nxseg,
                                                     int nphase, int ppb, int nslab, int ny, int N, int xcd,
-                                                    float *__restrict__ part) {
+                                                    float *__restrict__ part, int prows) {
   __shared__ float red[4 * 8 * 8];
   const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
   DwTile tile;
@@ -170,6 +182,7 @@ __global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x,
       const int p = (n * ny + pc) * nxseg + xs;
       f32x4 r1 = {v[0], v[1], v[2], v[3]}, r2 = {v[4], v[5], v[6], v[7]};
       write_stat_partial(part, p, C, c, r1, r2);
+      pad_stat_partial(part, p, N * ny * nxseg, prows, C, c);
     }
   }
 }
@@ -187,7 +200,7 @@ __global__ __launch_bounds__(256) void dw_march2_fwd(const float *__restrict__ x
                                                      const float *__restrict__ w, float *__restrict__ y,
                                                      int H, int W, int C, int r, int nchunk, int TK, int nxseg,
                                                      int nphase, int ppb, int nslab, int ny, int N, int xcd,
-                                                     float *__restrict__ part) {
+                                                     float *__restrict__ part, int prows) {
   __shared__ float red[4 * 8 * 8];
   const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
   DwTile tile;
@@ -268,6 +281,7 @@ __global__ __launch_bounds__(256) void dw_march2_fwd(const float *__restrict__ x
       const int p = (n * ny + pc) * nxseg + xs;
       f32x4 r1 = {v[0], v[1], v[2], v[3]}, r2 = {v[4], v[5], v[6], v[7]};
       write_stat_partial(part, p, C, c, r1, r2);
+      pad_stat_partial(part, p, N * ny * nxseg, prows, C, c);
     }
   }
 }
@@ -476,6 +490,7 @@ __global__ __launch_bounds__(256) void dw_gather_fwd(const float *__restrict__ x
     if (tid < 8 && cok) {
       f32x4 r1 = {v[0], v[1], v[2], v[3]}, r2 = {v[4], v[5], v[6], v[7]};
       write_stat_partial(part, blockIdx.y, G.C, c, r1, r2);
+      pad_stat_partial(part, blockIdx.y, gridDim.y, G.prows, G.C, c);
     }
   }
 }
@@ -565,6 +580,7 @@ __global__ __launch_bounds__(256) void dw_gather_bwd(
         f32x4 o = {v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]};
         st4(wpart + ((size_t)blockIdx.y * 9 + i) * G.C + c, o);
       }
+      pad_w_partial(wpart, blockIdx.y, gridDim.y, G.prows, G.C, c);
     }
   }
   if (dpart) {
@@ -573,6 +589,7 @@ __global__ __launch_bounds__(256) void dw_gather_bwd(
     if (tid < 8 && cok) {
       f32x4 r1 = {v[0], v[1], v[2], v[3]}, r2 = {v[4], v[5], v[6], v[7]};
       write_stat_partial(dpart, blockIdx.y, G.C, c, r1, r2);
+      pad_stat_partial(dpart, blockIdx.y, gridDim.y, G.prows, G.C, c);
     }
   }
 }
@@ -680,6 +697,7 @@ __global__ __launch_bounds__(256) void dw_s2_bwd(
         f32x4 o = {v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]};
         st4(wpart + ((size_t)blockIdx.y * 9 + i) * G.C + c, o);
       }
+      pad_w_partial(wpart, blockIdx.y, gridDim.y, G.prows, G.C, c);
     }
   }
   if (dpart) {
@@ -688,6 +706,7 @@ __global__ __launch_bounds__(256) void dw_s2_bwd(
     if (tid < 8 && cok) {
       f32x4 r1 = {v[0], v[1], v[2], v[3]}, r2 = {v[4], v[5], v[6], v[7]};
       write_stat_partial(dpart, blockIdx.y, G.C, c, r1, r2);
+      pad_stat_partial(dpart, blockIdx.y, gridDim.y, G.prows, G.C, c);
     }
   }
 }
@@ -799,27 +818,22 @@ extern "C" int dl3_dwconv3x3_fwd(const float *x, const float *in_scale, const fl
   DL3_UNSUPPORTED(im < 0, "dwconv3x3_fwd: march impl needs stride 1, pad == rate, Ho == H, Wo == W");
   DwPlan p = dw_plan(N, H, W, C, stride, rate, Ho, Wo, im, false);
   hipStream_t st = (hipStream_t)stream;
+  // the caller sized the partial buffer with dl3_dwconv3x3_partials (the larger of the forward and the backward
+  // decomposition; the two-pixel forward writes half the backward's rows): the kernels zero the rows nobody owns
+  const int Pmax = dl3_dwconv3x3_partials(N, H, W, C, stride, rate, Ho, Wo, im);
   if (im == DL3_IMPL_MARCH) {
     dim3 grid(march_grid(p, N));
     if (p.two)
       hipLaunchKernelGGL(dw_march2_fwd, grid, dim3(256), 0, st, x, in_scale, in_shift, in_act, w, y, H, W, C, rate,
-                         p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial);
+                         p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial, Pmax);
     else
       hipLaunchKernelGGL(dw_march_fwd, grid, dim3(256), 0, st, x, in_scale, in_shift, in_act, w, y, H, W, C, rate,
-                         p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial);
-    // the two-pixel forward writes fewer partial rows than the backward's decomposition: zero the rest
-    const int Pmax = dl3_dwconv3x3_partials(N, H, W, C, stride, rate, Ho, Wo, im);
-    if (stat_partial && Pmax > p.P)
-      (void)hipMemsetAsync(stat_partial + (size_t)p.P * C * 2, 0, (size_t)(Pmax - p.P) * C * 2 * sizeof(float), st);
+                         p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial, Pmax);
   } else {
-    DwGeom G{N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo};
+    DwGeom G{N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo, Pmax};
     dim3 grid(p.nslab, p.PB);
     hipLaunchKernelGGL(dw_gather_fwd, grid, dim3(256), 0, st, x, in_scale, in_shift, in_act, w, y, G,
                        stat_partial);
-    // gather fwd writes PB partial rows; pad the rest (caller sized the buffer with *_partials)
-    const int Pmax = dl3_dwconv3x3_partials(N, H, W, C, stride, rate, Ho, Wo, im);
-    if (stat_partial && Pmax > p.P)
-      (void)hipMemsetAsync(stat_partial + (size_t)p.P * C * 2, 0, (size_t)(Pmax - p.P) * C * 2 * sizeof(float), st);
   }
   DL3_LAUNCH_CHECK("dwconv3x3_fwd");
   return DL3_OK;
@@ -847,7 +861,9 @@ extern "C" int dl3_dwconv3x3_bwd(const float *g, const float *yraw, const float 
                        w, dx, dx_add, x_mean, x_invstd, dstat_partial, dw_partial, H, W, C, rate, p.nchunk, p.TK,
                        p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd());
   } else {
-    DwGeom G{N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo};
+    // (partial rows beyond this grid's: zeroed by the kernels, see pad_stat_partial)
+    const int Pmax = dl3_dwconv3x3_partials(N, H, W, C, stride, rate, Ho, Wo, im);
+    DwGeom G{N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo, Pmax};
     dim3 grid(p.nslab, p.PB);
     const char *e = getenv("DL3_DW_S2");  // 0 = generic gather for stride 2 as well (tuning / test aid)
     if (stride == 2 && rate == 1 && pad_t <= 1 && pad_l <= 1 && !(e && atoi(e) == 0))
@@ -856,12 +872,6 @@ extern "C" int dl3_dwconv3x3_bwd(const float *g, const float *yraw, const float 
     else
       hipLaunchKernelGGL(dw_gather_bwd, grid, dim3(256), 0, st, g, yraw, cA, cB, cC, x, in_scale, in_shift, in_act,
                          w, dx, dx_add, x_mean, x_invstd, dstat_partial, dw_partial, G);
-    const int Pmax = dl3_dwconv3x3_partials(N, H, W, C, stride, rate, Ho, Wo, im);
-    if (Pmax > p.P) {
-      (void)hipMemsetAsync(dw_partial + (size_t)p.P * 9 * C, 0, (size_t)(Pmax - p.P) * 9 * C * sizeof(float), st);
-      if (dstat_partial)
-        (void)hipMemsetAsync(dstat_partial + (size_t)p.P * C * 2, 0, (size_t)(Pmax - p.P) * C * 2 * sizeof(float), st);
-    }
   }
   DL3_LAUNCH_CHECK("dwconv3x3_bwd");
   return DL3_OK;

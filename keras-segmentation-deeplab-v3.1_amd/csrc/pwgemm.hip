@@ -37,6 +37,7 @@ struct GemmArgs {
   int stat_mode;  // 0 none, 1: sum c, sum c^2 ; 2: sum c, sum c*xhat
   const float *ep_mean, *ep_invstd;
   float *part;
+  int part_rows;  // rows the caller's partial buffer holds: the launch writes gridDim.y of them and zeroes the rest itself
   int mtiles;
   const void *bp; int nsub;  // split math: weights pre-split into 3 bf16 planes in MFMA fragment order (pack_b_kernel)
 #ifdef DL3_PHASE_TIMING
@@ -314,6 +315,12 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmArgs P) {
         }
         P.part[((size_t)by * P.N + col) * 2 + 0] = a1;
         P.part[((size_t)by * P.N + col) * 2 + 1] = a2;
+        // rows of the buffer no workgroup owns (it is sized for the largest grid any tile choice uses): zeroed here, by
+        // the row groups in turn, instead of by a memset node behind every launch
+        for (int r = by + (int)gridDim.y; r < P.part_rows; r += (int)gridDim.y) {
+          P.part[((size_t)r * P.N + col) * 2 + 0] = 0.f;
+          P.part[((size_t)r * P.N + col) * 2 + 1] = 0.f;
+        }
       }
     }
   }
@@ -836,6 +843,12 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
         }
         P.part[((size_t)by * P.N + col) * 2 + 0] = a1;
         P.part[((size_t)by * P.N + col) * 2 + 1] = a2;
+        // rows of the buffer no workgroup owns (it is sized for the largest grid any tile choice uses): zeroed here, by
+        // the row groups in turn, instead of by a memset node behind every launch
+        for (int r = by + (int)gridDim.y; r < P.part_rows; r += (int)gridDim.y) {
+          P.part[((size_t)r * P.N + col) * 2 + 0] = 0.f;
+          P.part[((size_t)r * P.N + col) * 2 + 1] = 0.f;
+        }
       }
     }
   }
@@ -1450,13 +1463,6 @@ static int gemm_common_check(const char *name, int M, int K, int N) {
   return DL3_OK;
 }
 
-// zero-fill partial rows the chosen grid did not write
-static void pad_partials(float *part, int M, int K, int N, int written, hipStream_t st) {
-  const int total = dl3_pwconv_partials(M, K, N);
-  if (part && total > written)
-    (void)hipMemsetAsync(part + (size_t)written * N * 2, 0, (size_t)(total - written) * N * 2 * sizeof(float), st);
-}
-
 extern "C" int dl3_pwconv_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
                               const float *w, const float *bias, float *y, int ldy, int M, int K, int N,
                               float *stat_partial, void *stream) {
@@ -1473,10 +1479,10 @@ extern "C" int dl3_pwconv_fwd(const float *x, int ldx, const float *in_scale, co
   A.add_div = 1; A.add_scale = 1.f;
   A.stat_mode = stat_partial ? 1 : 0;
   A.part = stat_partial;
+  A.part_rows = stat_partial ? dl3_pwconv_partials(M, K, N) : 0;
   hipStream_t st = (hipStream_t)stream;
   const int written = run_gemm(A, st);
   DL3_CHECK_ARG(written >= 0, "pwconv_fwd: split-math weight scratch unavailable (first launch inside a stream capture?)");
-  if (stat_partial) pad_partials(stat_partial, M, K, N, written, st);
   DL3_LAUNCH_CHECK("pwconv_fwd");
   return DL3_OK;
 }
@@ -1497,10 +1503,10 @@ extern "C" int dl3_pwconv_fwd_add(const float *x, int ldx, const float *in_scale
   A.ep_add = add; A.ld_add = ldadd; A.add_div = add_div; A.add_scale = 1.f;
   A.stat_mode = stat_partial ? 1 : 0;
   A.part = stat_partial;
+  A.part_rows = stat_partial ? dl3_pwconv_partials(M, K, N) : 0;
   hipStream_t st = (hipStream_t)stream;
   const int written = run_gemm(A, st);
   DL3_CHECK_ARG(written >= 0, "pwconv_fwd_add: split-math weight scratch unavailable (first launch inside a stream capture?)");
-  if (stat_partial) pad_partials(stat_partial, M, K, N, written, st);
   DL3_LAUNCH_CHECK("pwconv_fwd_add");
   return DL3_OK;
 }
@@ -1532,10 +1538,10 @@ extern "C" int dl3_pwconv_bwd_data(const float *g, int ldg, const float *yraw, i
   A.stat_mode = dstat_partial ? 2 : 0;
   A.ep_mean = x_mean; A.ep_invstd = x_invstd;
   A.part = dstat_partial;
+  A.part_rows = dstat_partial ? dl3_pwconv_partials(M, N, K) : 0;
   hipStream_t st = (hipStream_t)stream;
   const int written = run_gemm(A, st);
   DL3_CHECK_ARG(written >= 0, "pwconv_bwd_data: split-math weight scratch unavailable (first launch inside a stream capture?)");
-  if (dstat_partial) pad_partials(dstat_partial, M, N, K, written, st);
   DL3_LAUNCH_CHECK("pwconv_bwd_data");
   return DL3_OK;
 }
@@ -1549,13 +1555,19 @@ extern "C" size_t dl3_pwconv_bwd_weight_workspace(int M, int K, int N) {
   return ((size_t)S * K * N + (size_t)colsum_rows(M) * N) * sizeof(float);
 }
 
+extern "C" int dl3_pwconv_bwd_weight_splits(int M, int K, int N, int two_tensor_dy) {
+  if (M <= 0 || K <= 0 || N <= 0) return 0;
+  return wgrad_splits(M, K, N, pick_wgrad(M, K, N, two_tensor_dy != 0));
+}
+
 extern "C" int dl3_pwconv_bwd_weight(const float *x, int ldx, const float *in_scale, const float *in_shift,
                                      int in_act, const float *g, int ldg, const float *yraw, int ldyraw,
                                      const float *cA, const float *cB, const float *cC, float *dw, float *dbias,
                                      int M, int K, int N, void *workspace, size_t workspace_bytes, void *stream) {
   int rc = gemm_common_check("pwconv_bwd_weight", M, K, N);
   if (rc) return rc;
-  DL3_CHECK_ARG(x && g && dw && workspace, "pwconv_bwd_weight: null pointer");
+  DL3_CHECK_ARG(x && g && workspace, "pwconv_bwd_weight: null pointer");
+  DL3_CHECK_ARG(dw || !dbias, "pwconv_bwd_weight: dbias without dw (slabs left in the workspace) is not supported");
   DL3_CHECK_ARG(!cA || (yraw && cB && cC), "pwconv_bwd_weight: cA needs yraw, cB, cC");
   DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "pwconv_bwd_weight: scale/shift must come together");
   DL3_UNSUPPORTED(dbias && cA, "pwconv_bwd_weight: dbias with a BN-backward gradient operand is not needed by the path");
@@ -1592,6 +1604,7 @@ extern "C" int dl3_pwconv_bwd_weight(const float *x, int ldx, const float *in_sc
     default: launch_wgrad<1, 3, 4, 1>(A, grid, st, xvec && dvec); break;
   }
   DL3_LAUNCH_CHECK("pwconv_bwd_weight");
+  if (!dw) return DL3_OK;  // the caller folds the [S][K][N] slabs itself (dl3_reduce_partials / _batched)
   rc = dl3_reduce_partials(A.ws, S, K * N, dw, stream);
   if (rc) return rc;
   if (dbias) {

@@ -197,6 +197,11 @@ class Engine:
         # they leave the backward chain as a second captured stream (event fork behind the launch that completes their dY,
         # one join at the end).  Measured SLOWER at every batch size (two 256-VGPR workgroups fill a CU), so
         # the default is one stream; kept because it is tested bit-identical and documents the experiment.
+        self.poison = os.environ.get("DL3_POISON_SCRATCH", "0") == "1"
+        # every weight-gradient slab fold of the backward pass in ONE launch at its end (DL3_BATCH_FOLDS=0: one
+        # dl3_reduce_partials behind each weight-gradient launch, bit-identical — a test toggles it)
+        self.batch_folds = os.environ.get("DL3_BATCH_FOLDS", "1") == "1"
+        self._folds = []
         self.fork = os.environ.get("DL3_FORK", "0") in ("1", "2")
         # DL3_FORK=2 (experiment): only the weight gradient that can run next to an HBM-bound depthwise backward launch
         # leaves the chain, and the chain's next GEMM waits for it: matrix-bound and HBM-bound kernels overlap, two GEMMs never do
@@ -238,6 +243,8 @@ class Engine:
     # ------------------------------------------------------------------ memory
     def empty(self, n):
         t = torch.empty(int(n), dtype=torch.float32, device=self.device)
+        if self.poison:   # DL3_POISON_SCRATCH=1 (test aid): a launch that reads scratch nobody wrote turns the loss into NaN
+            t.fill_(float("nan"))
         self._keep.append(t)
         return t
 
@@ -351,6 +358,20 @@ class Engine:
         rec = (name, fn, list(args), None)
         lst.append(rec)
         return rec
+
+    def op_side(self, lst, name, *args):
+        """op for a launch that may leave the backward chain (see self.fork) and brings its own workspace"""
+        rec = self.op(lst, name, *args)
+        if self.fork:
+            self._side.add(id(rec))
+        return rec
+
+    def fold(self, src_ptr, P, n, dst_ptr):
+        """dst[n] = sum over the P partial rows at src: now, or with every other fold in one launch (self.batch_folds)"""
+        if self.batch_folds:
+            self._folds.append((int(src_ptr), int(dst_ptr), int(P), int(n)))
+        else:
+            self.op(self.ops_bwd, "dl3_reduce_partials", src_ptr, P, n, dst_ptr)
 
     _scratch_users = None
 
@@ -847,6 +868,17 @@ class Engine:
             rec = ("dl3_transpose_batched", getattr(self.lib, "dl3_transpose_batched"),
                    [self._tdesc.data_ptr(), len(rows), t0], None)
             self.ops_bwd.insert(first_bwd, rec)
+        if self._folds:
+            # (the slabs were written by launches on either stream: the fold sits behind the join at the end of the list)
+            rows, b0 = [], 0
+            for src, dst, P, n in self._folds:
+                rows.append([src, dst, P, n, b0])
+                b0 += self.lib.dl3_reduce_partials_blocks(P, n)
+            self._fdesc = torch.tensor(rows, dtype=torch.int64, device=self.device)
+            self._keep.append(self._fdesc)
+            rec = self.op(self.ops_bwd, "dl3_reduce_partials_batched", self._fdesc.data_ptr(), len(rows), b0)
+            if self.fork:
+                self._join_before.add(id(rec))
         if self.fork_pairs:
             self._pair_wgrads_with_depthwise()
         assert not self.prestat, "BatchNorm-backward sums reduced early but never folded"
@@ -1239,9 +1271,17 @@ class PwUnit(_ConvBase):
         wsrc = eng.wptr(self.wname()) + 4 * self.wrow0 * N
         if eng.trainable(self.wname()) or (self.bias and eng.trainable(self.bias)):
             ws = eng.lib.dl3_pwconv_bwd_weight_workspace(M, K, N)
-            eng.op_ws_side(eng.ops_bwd, "dl3_pwconv_bwd_weight", ws, 17, inv.p(), inv.ld, s, t, a, g, ldg, y, ldy, cA, cB, cC,
-                      eng.gptr(self.wname()) + (4 * self.wrow0 * N if eng.trainable(self.wname()) else 0),
-                      eng.gptr(self.bias) if self.bias else None, M, K, N, 0, ws)
+            if eng.batch_folds and not self.bias and eng.trainable(self.wname()):
+                # the launch leaves its [S][K][N] slabs in a workspace of its own; folded at the end of the pass
+                own = eng.empty(ws // 4 + 4)
+                eng.op_side(eng.ops_bwd, "dl3_pwconv_bwd_weight", inv.p(), inv.ld, s, t, a, g, ldg, y, ldy, cA, cB, cC,
+                            None, None, M, K, N, ptr(own), ws)
+                eng.fold(ptr(own), eng.lib.dl3_pwconv_bwd_weight_splits(M, K, N, 1 if cA else 0), K * N,
+                         eng.gptr(self.wname()) + 4 * self.wrow0 * N)
+            else:
+                eng.op_ws_side(eng.ops_bwd, "dl3_pwconv_bwd_weight", ws, 17, inv.p(), inv.ld, s, t, a, g, ldg, y, ldy, cA, cB,
+                               cC, eng.gptr(self.wname()) + (4 * self.wrow0 * N if eng.trainable(self.wname()) else 0),
+                               eng.gptr(self.bias) if self.bias else None, M, K, N, 0, ws)
         if self.img_add is not None:
             self._bwd_img_add(g, ldg, y, ldy, cA, cB, cC)
         ibuf = inv.buf
@@ -1313,7 +1353,7 @@ class DwUnit(_ConvBase):
         eng.op(eng.ops_bwd, "dl3_dwconv3x3_bwd", g, y, cA, cB, cC, inv.p(), s, t, a, eng.wptr(self.wname()),
                ptr(gout), ptr(add), ibuf.vptr(V_MEAN) if need_stat else None,
                ibuf.vptr(V_INVSTD) if need_stat else None, ptr(dpart), ptr(wpart), *self.geom, eng.dw_impl)
-        eng.op(eng.ops_bwd, "dl3_reduce_partials", ptr(wpart), self.P, 9 * C, eng.gptr(self.wname()))
+        eng.fold(ptr(wpart), self.P, 9 * C, eng.gptr(self.wname()))
         if need_stat:
             eng.finish_bn_bwd(ibuf, dpart, self.P, C)
 
@@ -1383,7 +1423,7 @@ class Conv3Unit(_ConvBase):
         if eng.trainable(self.wname()):
             wpart = eng.empty(self.P * 9 * Cin * Cout)
             eng.op(eng.ops_bwd, "dl3_conv3x3_bwd_weight", inv.p(), s, t, a, g, y, cA, cB, cC, ptr(wpart), *self.geom)
-            eng.op(eng.ops_bwd, "dl3_reduce_partials", ptr(wpart), self.P, 9 * Cin * Cout, eng.gptr(self.wname()))
+            eng.fold(ptr(wpart), self.P, 9 * Cin * Cout, eng.gptr(self.wname()))
         ibuf = inv.buf
         if not ibuf.requires_grad:
             return

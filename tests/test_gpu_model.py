@@ -710,7 +710,9 @@ def test_backward_fork_is_bit_identical(monkeypatch):
         for use_graph in (False, True):
             eng = model._engine(2, True, dropout=False, use_graph=use_graph, seed=100 + int(fork))  # distinct engine keys
             assert eng.fork == (fork != "0") and bool(eng._side) == (fork != "0")
-            assert bool(eng._join_before) == (fork == "2")
+            # the batched weight-gradient fold at the end of the pass waits for the side stream in every fork mode;
+            # mode 2 adds a join in front of the chain's next GEMM behind every pair
+            assert len(eng._join_before) == (0 if fork == "0" else 1) or (fork == "2" and len(eng._join_before) > 1)
             eng.set_input(x)
             eng.set_targets(y, sw)
             for _ in range(3 if use_graph else 1):   # the graph is captured on the second call
@@ -718,6 +720,68 @@ def test_backward_fork_is_bit_identical(monkeypatch):
             torch.cuda.synchronize()
             assert (eng.graph is not None) == use_graph
             got[(fork, use_graph)] = (eng.grads.cpu().numpy().copy(), float(eng.loss[0].item()))
+    ref = got[("0", False)]
+    for k, v in got.items():
+        assert v[1] == ref[1] and np.array_equal(v[0], ref[0]), k
+
+
+@pytest.mark.parametrize("backbone,shape", [("mobilenetv2", (96, 96, 3)), ("xception", (64, 64, 3))])
+def test_poisoned_scratch_changes_nothing(monkeypatch, backbone, shape):
+    """DL3_POISON_SCRATCH=1 fills every scratch allocation of the engine (statistic / weight-gradient partial buffers,
+    workspaces) with NaN before the plan is built: the kernels own every word they later read — in particular the rows of
+    a partial buffer beyond the launch's own grid, which the kernels zero themselves (round 3: no memset nodes) — so
+    loss and gradients do not change by a bit."""
+    model, params = _build(input_shape=shape, classes=3, backbone=backbone)
+    _load(model, params)
+    rng = np.random.default_rng(21)
+    B = 3   # odd: ragged row tiles and partial counts that differ between the forward and backward decompositions
+    x = rng.integers(0, 256, (B,) + shape).astype(np.float32)
+    y = rng.integers(0, 4, (B, shape[0] * shape[1])).astype(np.float32)
+    sw = (y < 3).astype(np.float32)
+    got = {}
+    for poison in ("0", "1"):
+        monkeypatch.setenv("DL3_POISON_SCRATCH", poison)
+        for use_graph in (False, True):
+            eng = model._engine(B, True, dropout=False, use_graph=use_graph, seed=300 + int(poison))
+            assert eng.poison == (poison == "1")
+            eng.set_input(x)
+            eng.set_targets(y, sw)
+            for _ in range(3 if use_graph else 1):
+                eng.fwd_bwd()
+            torch.cuda.synchronize()
+            got[(poison, use_graph)] = (eng.grads.cpu().numpy().copy(), float(eng.loss[0].item()))
+    ref = got[("0", False)]
+    assert np.isfinite(ref[1]) and np.isfinite(ref[0]).all()
+    for k, v in got.items():
+        assert v[1] == ref[1] and np.array_equal(v[0], ref[0]), k
+
+
+def test_batched_weight_gradient_folds_are_bit_identical(monkeypatch):
+    """DL3_BATCH_FOLDS=1 (default: every weight-gradient slab fold of the backward pass in ONE dl3_reduce_partials_batched
+    launch at its end, each 1x1 weight gradient keeping its slabs in a workspace of its own) against =0 (a
+    dl3_reduce_partials behind every weight-gradient launch): same gradients, bit for bit; ~55 kernel launches less per step."""
+    model, params = _build(input_shape=(64, 64, 3), classes=3)
+    _load(model, params)
+    rng = np.random.default_rng(22)
+    x = rng.integers(0, 256, (2, 64, 64, 3)).astype(np.float32)
+    y = rng.integers(0, 4, (2, 64 * 64)).astype(np.float32)
+    sw = (y < 3).astype(np.float32)
+    got, nops = {}, {}
+    for batch in ("0", "1"):
+        monkeypatch.setenv("DL3_BATCH_FOLDS", batch)
+        for use_graph in (False, True):
+            eng = model._engine(2, True, dropout=False, use_graph=use_graph, seed=400 + int(batch))
+            names = [o[0] for o in eng.ops_bwd]
+            assert names.count("dl3_reduce_partials_batched") == int(batch)
+            assert (names[-1] == "dl3_reduce_partials_batched") == (batch == "1")
+            nops[batch] = len(names)
+            eng.set_input(x)
+            eng.set_targets(y, sw)
+            for _ in range(3 if use_graph else 1):
+                eng.fwd_bwd()
+            torch.cuda.synchronize()
+            got[(batch, use_graph)] = (eng.grads.cpu().numpy().copy(), float(eng.loss[0].item()))
+    assert nops["0"] - nops["1"] >= 15   # depthwise / dense-3x3 folds leave the plan (the 1x1 folds were inside their launch's C call)
     ref = got[("0", False)]
     for k, v in got.items():
         assert v[1] == ref[1] and np.array_equal(v[0], ref[0]), k

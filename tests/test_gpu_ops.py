@@ -568,6 +568,61 @@ def test_reduce_partials(L, P, n):
     assert relerr(host(out), part.astype(np.float64).sum(0)) < 1e-5
 
 
+def test_reduce_partials_batched_is_bit_identical(L):
+    """dl3_reduce_partials_batched (every weight-gradient slab fold of a backward pass in one launch) == one
+    dl3_reduce_partials per fold, bit for bit, for every (rows, columns) class of block shape and ragged column counts"""
+    rng = np.random.default_rng(81)
+    folds = [(3, 700), (32, 64), (33, 1000), (256, 31), (257, 999), (1365, 9 * 40), (1, 5), (17, 153600)]
+    parts = [dev(rng.normal(0, 1, (P, n)).astype(np.float32)) for P, n in folds]
+    want = []
+    for (P, n), pt_ in zip(folds, parts):
+        o = empty(n)
+        call("dl3_reduce_partials", ptr(pt_), P, n, ptr(o))
+        want.append(host(o).copy())
+        assert relerr(want[-1], host(pt_).astype(np.float64).sum(0)) < 1e-5
+    outs = [torch.full((n,), float("nan"), device="cuda") for _, n in folds]
+    rows, b0 = [], 0
+    for (P, n), pt_, o in zip(folds, parts, outs):
+        rows.append([pt_.data_ptr(), o.data_ptr(), P, n, b0])
+        nb = L.dl3_reduce_partials_blocks(P, n)
+        assert nb == -(-n // (64 if P <= 32 else 32 if P <= 256 else 8))
+        b0 += nb
+    desc = torch.tensor(rows, dtype=torch.int64, device="cuda")
+    call("dl3_reduce_partials_batched", desc.data_ptr(), len(rows), b0)
+    for o, w in zip(outs, want):
+        assert np.array_equal(host(o), w)
+    assert L.dl3_reduce_partials_blocks(0, 5) == 0
+
+
+@pytest.mark.parametrize("case", [(4096, 160, 960, 2, True), (1040, 96, 24, 2, True), (600, 320, 256, 1, False)])
+def test_pwconv_bwd_weight_slabs_left_for_the_caller(L, case):
+    """dw == NULL: the launch leaves its S = dl3_pwconv_bwd_weight_splits slabs [S][K][N] at the head of the workspace;
+    folding them afterwards gives exactly what the folding call writes"""
+    M, K, N, act, two = case
+    rng = np.random.default_rng(82)
+    g, yraw, x = [dev(rng.normal(0, 1, sh).astype(np.float32)) for sh in ((M, N), (M, N), (M, K))]
+    cA, cB, cC = [dev(rng.normal(0, 1, N).astype(np.float32)) for _ in range(3)]
+    s, t = dev(rng.uniform(0.5, 1.5, K).astype(np.float32)), dev(rng.normal(0, 0.5, K).astype(np.float32))
+    nbytes = L.dl3_pwconv_bwd_weight_workspace(M, K, N)
+    S = L.dl3_pwconv_bwd_weight_splits(M, K, N, 1 if two else 0)
+    assert S >= 1 and S * K * N * 4 <= nbytes
+    out = []
+    for leave in (False, True):
+        ws = torch.full((nbytes // 4 + 4,), float("nan"), dtype=torch.float32, device="cuda")
+        dw = empty(K, N)
+        call("dl3_pwconv_bwd_weight", ptr(x), K, ptr(s), ptr(t), act, ptr(g), N, ptr(yraw) if two else None, N,
+             ptr(cA) if two else None, ptr(cB) if two else None, ptr(cC) if two else None, None if leave else ptr(dw),
+             None, M, K, N, ptr(ws), nbytes)
+        if leave:
+            call("dl3_reduce_partials", ptr(ws), S, K * N, ptr(dw))
+        out.append(host(dw).copy())
+    assert np.isfinite(out[0]).all() and np.array_equal(out[0], out[1])
+    from dl3_amd import capi
+    with pytest.raises(capi.DL3Error):   # a bias gradient needs the folding call
+        call("dl3_pwconv_bwd_weight", ptr(x), K, ptr(s), ptr(t), act, ptr(g), N, None, N, None, None, None, None,
+             ptr(empty(N)), M, K, N, ptr(ws), nbytes)
+
+
 def test_affine_add_and_dropout(L):
     rng = np.random.default_rng(9)
     M, C = 300, 40

@@ -3,7 +3,8 @@
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 out=$REPO/gpurun_out/r3ab; mkdir -p $out; rm -f $out/b*.json
 cd $REPO
-timeout 900 python -m pytest tests/test_gpu_ops.py -q -x -k "${AB_TESTS:-bn or reduce or partial}" > $out/t.log 2>&1; echo "test rc $?" >> $out/t.log
+timeout 900 python -m pytest tests/test_gpu_ops.py -q -x > $out/t.log 2>&1; echo "ops rc $?" >> $out/t.log
+timeout 900 python -m pytest tests/test_gpu_model.py -q -x -k "${AB_TESTS:-poison or fork}" >> $out/t.log 2>&1; echo "model rc $?" >> $out/t.log
 B="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-split-leg --no-roofline"
 for rep in 1 2; do
   for b in 128 16 2; do
@@ -20,4 +21,4 @@ for p in sorted(glob.glob(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/
     except Exception as e:
         print(os.path.basename(p), "failed", e)
 PY
-tail -3 $out/t.log; cat $out/summary.txt
+grep -E 'passed|failed|rc' $out/t.log; cat $out/summary.txt

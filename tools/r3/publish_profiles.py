@@ -55,7 +55,7 @@ for tag, plan, cmd in (("cfg2_b128", "plan_cfg2_b128.json", "python bench.py --n
     txt = ("# rocprofv3 --kernel-trace --stats of `%s` (tools/r3/collect.sh), final tree of round 3\n"
            "# %d steps in the trace: %d with adam_kernel (warm-ups + timed hipGraph replays) + 3 eager in-situ passes; per-step device time by\n"
            "# kernel-name family (TotalDurationNs / %d) next to bench.py's in-situ HIP-event figures of the SAME run:\n"
-           "#   1x1-conv GEMM kernels (pw_gemm_* + pw_wgrad_*): %.2f ms/step | in situ (op = kernel + its slab-reduce launch): %.2f ms/step\n"
+           "#   1x1-conv GEMM kernels (pw_gemm_* + pw_wgrad_*): %.2f ms/step | in situ (the family's ops + the pass's one slab-fold launch): %.2f ms/step\n"
            "#   depthwise march kernels (dw_march*):            %.2f ms/step | in situ (stride-1 depthwise ops): %.2f ms/step\n"
            "#   all kernels: %.2f ms/step | in situ all launches %.2f ms | timed region of this run: %s ms/step\n") % (
                cmd, n, steps, n, g / 1e6 / n, ig, d / 1e6 / n, idw, tot / 1e6 / n, it, timed)
