@@ -23,6 +23,20 @@ def test_library_exports_every_header_symbol():
     assert L.dl3_dwconv3x3_partials(16, 64, 64, 960, 1, 4, 64, 64, 0) > 0
 
 
+def test_sizing_queries_of_the_weight_gradient_folds():
+    """host-only entry points the engine sizes its fold plan with (no launch): slabs of a 1x1 weight gradient fit its
+    workspace; the workgroup count of a fold follows the (rows -> columns per workgroup) rule of dl3_reduce_partials"""
+    L = capi.lib()
+    for M, K, N in [(8192, 960, 160), (524288, 16, 96), (2, 320, 256), (131072, 256, 21), (65536, 1536, 2048)]:
+        for two in (0, 1):
+            S = L.dl3_pwconv_bwd_weight_splits(M, K, N, two)
+            assert S >= 1 and S * K * N * 4 <= L.dl3_pwconv_bwd_weight_workspace(M, K, N), (M, K, N, two, S)
+    assert L.dl3_pwconv_bwd_weight_splits(0, 8, 8, 0) == 0
+    for P, n, cols in [(1, 5, 64), (32, 6400, 64), (33, 100, 32), (256, 9 * 960, 32), (257, 9, 8), (1365, 153600, 8)]:
+        assert L.dl3_reduce_partials_blocks(P, n) == -(-n // cols)
+    assert L.dl3_reduce_partials_blocks(0, 10) == 0 and L.dl3_reduce_partials_blocks(4, 0) == 0
+
+
 def test_engine_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
