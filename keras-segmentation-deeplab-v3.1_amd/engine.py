@@ -201,6 +201,10 @@ class Engine:
         # every weight-gradient slab fold of the backward pass in ONE launch at its end (DL3_BATCH_FOLDS=0: one
         # dl3_reduce_partials behind each weight-gradient launch, bit-identical — a test toggles it)
         self.batch_folds = os.environ.get("DL3_BATCH_FOLDS", "1") == "1"
+        # ... of the folds whose partial rows are small: a deferred fold re-reads its slabs from HBM instead of the cache
+        # they were just written through, which costs more than the launch it saves from ~12 MB on (Xception B=16 with
+        # every fold deferred: 193.9 -> 196.4 ms)
+        self.fold_defer_bytes = int(os.environ.get("DL3_FOLD_DEFER_MB", "8")) << 20
         self._folds = []
         self.fork = os.environ.get("DL3_FORK", "0") in ("1", "2")
         # DL3_FORK=2 (experiment): only the weight gradient that can run next to an HBM-bound depthwise backward launch
@@ -366,9 +370,12 @@ class Engine:
             self._side.add(id(rec))
         return rec
 
+    def defer_fold(self, P, n):
+        return self.batch_folds and 4 * int(P) * int(n) <= self.fold_defer_bytes
+
     def fold(self, src_ptr, P, n, dst_ptr):
         """dst[n] = sum over the P partial rows at src: now, or with every other fold in one launch (self.batch_folds)"""
-        if self.batch_folds:
+        if self.defer_fold(P, n):
             self._folds.append((int(src_ptr), int(dst_ptr), int(P), int(n)))
         else:
             self.op(self.ops_bwd, "dl3_reduce_partials", src_ptr, P, n, dst_ptr)
@@ -1271,13 +1278,13 @@ class PwUnit(_ConvBase):
         wsrc = eng.wptr(self.wname()) + 4 * self.wrow0 * N
         if eng.trainable(self.wname()) or (self.bias and eng.trainable(self.bias)):
             ws = eng.lib.dl3_pwconv_bwd_weight_workspace(M, K, N)
-            if eng.batch_folds and not self.bias and eng.trainable(self.wname()):
+            S = eng.lib.dl3_pwconv_bwd_weight_splits(M, K, N, 1 if cA else 0)
+            if eng.defer_fold(S, K * N) and not self.bias and eng.trainable(self.wname()):
                 # the launch leaves its [S][K][N] slabs in a workspace of its own; folded at the end of the pass
                 own = eng.empty(ws // 4 + 4)
                 eng.op_side(eng.ops_bwd, "dl3_pwconv_bwd_weight", inv.p(), inv.ld, s, t, a, g, ldg, y, ldy, cA, cB, cC,
                             None, None, M, K, N, ptr(own), ws)
-                eng.fold(ptr(own), eng.lib.dl3_pwconv_bwd_weight_splits(M, K, N, 1 if cA else 0), K * N,
-                         eng.gptr(self.wname()) + 4 * self.wrow0 * N)
+                eng.fold(ptr(own), S, K * N, eng.gptr(self.wname()) + 4 * self.wrow0 * N)
             else:
                 eng.op_ws_side(eng.ops_bwd, "dl3_pwconv_bwd_weight", ws, 17, inv.p(), inv.ld, s, t, a, g, ldg, y, ldy, cA, cB,
                                cC, eng.gptr(self.wname()) + (4 * self.wrow0 * N if eng.trainable(self.wname()) else 0),
