@@ -117,9 +117,10 @@ def _work(name, a):
         M, K, N = a[22], a[23], a[24]
         by = M * N * (2 if nz(a[2]) else 1) + K * N + M * K * (1 + (1 if nz(a[10]) else 0) + (1 if nz(a[15]) else 0))
         return "gemm", "bwd-data M=%d K=%d N=%d" % (M, K, N), 2.0 * M * K * N, 4.0 * by
-    if name == "dl3_pwconv_bwd_weight":
+    if name in ("dl3_pwconv_bwd_weight", "dl3_pwconv_bwd_weight_dy"):
         M, K, N = a[14], a[15], a[16]
-        by = M * K + M * N * (2 if nz(a[7]) else 1) + K * N
+        # (_dy: the launch also writes dY once — the M*N the bwd-data launch of the layer no longer reads twice)
+        by = M * K + M * N * (2 if nz(a[7]) else 1) + K * N + (M * N if name.endswith("_dy") else 0)
         return "gemm", "bwd-weight M=%d K=%d N=%d" % (M, K, N), 2.0 * M * K * N, 4.0 * by
     if name == "dl3_dwconv3x3_fwd":
         N, H, W, C, stride, rate, Ho, Wo = a[6], a[7], a[8], a[9], a[10], a[11], a[14], a[15]

@@ -113,6 +113,15 @@ int dl3_pwconv_bwd_weight(const float *x, int ldx, const float *in_scale, const 
                           const float *g, int ldg, const float *yraw, int ldyraw, const float *cA,
                           const float *cB, const float *cC, float *dw, float *dbias, int M, int K, int N,
                           void *workspace, size_t workspace_bytes, void *stream);
+/* the same launch, which also writes the gradient operand it assembles anyway, dy_out[M][N](lddy) = cA*g + cB*yraw + cC
+ * (round 4): dl3_pwconv_bwd_data of the same layer can then be handed (g = dy_out, cA = NULL) — ONE operand tensor, no
+ * operand transform, and with it the room for a straight-line masked epilogue.  Costs one write of dY; the bwd-data GEMM
+ * reads one tensor less.  dy_out 16-byte aligned, lddy >= N and a multiple of 4.  Replaces the BatchNormalization
+ * backward TF runs as a separate op in front of both Conv2D gradients (deeplabv3p.py:175-201 expand / project convs). */
+int dl3_pwconv_bwd_weight_dy(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
+                             const float *g, int ldg, const float *yraw, int ldyraw, const float *cA,
+                             const float *cB, const float *cC, float *dw, float *dbias, int M, int K, int N,
+                             void *workspace, size_t workspace_bytes, float *dy_out, int lddy, void *stream);
 /* out[cols][rows] = in[rows][cols]^T  (W[K,N] -> WT[N,K] for bwd_data) */
 int dl3_transpose(const float *in, float *out, int rows, int cols, void *stream);
 /* n transposes in one launch (all W -> WT of a backward pass).  desc (device, int64 [n][6]): in pointer, out pointer,

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
     const float *__restrict__ sc, const float *__restrict__ sh, int act, const float *__restrict__ w,
     float *__restrict__ dx, const float *__restrict__ dx_add, const float *__restrict__ xmean,
     const float *__restrict__ xinvstd, float *__restrict__ dpart, float *__restrict__ wpart, int H, int W, int C,
-    int r, int nchunk, int TK, int nxseg, int nphase, int ppb, int nslab, int ny, int N, int xcd) {
+    int r, int nchunk, int TK, int nxseg, int nphase, int ppb, int nslab, int ny, int N, int xcd, int prows) {
   __shared__ float red[4 * 8 * 36];
   const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
   DwTile tile;
@@ -430,6 +430,10 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
         f32x4 o = {v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]};
         st4(wpart + ((size_t)p * 9 + i) * C + c, o);
       }
+      // the partial buffers hold max(forward plan, backward plan) rows and the folds read all of them: the two-pixel
+      // forward halves nxseg and may then halve TK once more, so its plan can be the LARGER one (8 x 64 x 64 x 960 at
+      // rate 16: 128 forward rows, 96 backward) — the rows this grid does not own are zeroed here as in the forward
+      pad_w_partial(wpart, p, N * ny * nxseg, prows, C, c);
     }
   }
   if (dpart) {
@@ -438,6 +442,7 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
     if (tid < 8 && c < C) {
       f32x4 r1 = {v[0], v[1], v[2], v[3]}, r2 = {v[4], v[5], v[6], v[7]};
       write_stat_partial(dpart, p, C, c, r1, r2);
+      pad_stat_partial(dpart, p, N * ny * nxseg, prows, C, c);
     }
   }
 }
@@ -819,7 +824,7 @@ extern "C" int dl3_dwconv3x3_fwd(const float *x, const float *in_scale, const fl
   DwPlan p = dw_plan(N, H, W, C, stride, rate, Ho, Wo, im, false);
   hipStream_t st = (hipStream_t)stream;
   // the caller sized the partial buffer with dl3_dwconv3x3_partials (the larger of the forward and the backward
-  // decomposition; the two-pixel forward writes half the backward's rows): the kernels zero the rows nobody owns
+  // decomposition — either can be the larger one): the kernels zero the rows nobody owns
   const int Pmax = dl3_dwconv3x3_partials(N, H, W, C, stride, rate, Ho, Wo, im);
   if (im == DL3_IMPL_MARCH) {
     dim3 grid(march_grid(p, N));
@@ -855,14 +860,14 @@ extern "C" int dl3_dwconv3x3_bwd(const float *g, const float *yraw, const float 
   DL3_UNSUPPORTED(im < 0, "dwconv3x3_bwd: march impl needs stride 1, pad == rate, Ho == H, Wo == W");
   DwPlan p = dw_plan(N, H, W, C, stride, rate, Ho, Wo, im, true);
   hipStream_t st = (hipStream_t)stream;
+  // (partial rows beyond this grid's: zeroed by the kernels, see pad_stat_partial)
+  const int Pmax = dl3_dwconv3x3_partials(N, H, W, C, stride, rate, Ho, Wo, im);
   if (im == DL3_IMPL_MARCH) {
     dim3 grid(march_grid(p, N));
     hipLaunchKernelGGL(dw_march_bwd, grid, dim3(256), 0, st, g, yraw, cA, cB, cC, x, in_scale, in_shift, in_act,
                        w, dx, dx_add, x_mean, x_invstd, dstat_partial, dw_partial, H, W, C, rate, p.nchunk, p.TK,
-                       p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd());
+                       p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), Pmax);
   } else {
-    // (partial rows beyond this grid's: zeroed by the kernels, see pad_stat_partial)
-    const int Pmax = dl3_dwconv3x3_partials(N, H, W, C, stride, rate, Ho, Wo, im);
     DwGeom G{N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo, Pmax};
     dim3 grid(p.nslab, p.PB);
     const char *e = getenv("DL3_DW_S2");  // 0 = generic gather for stride 2 as well (tuning / test aid)

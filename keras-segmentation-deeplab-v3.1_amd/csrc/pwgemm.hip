@@ -60,6 +60,9 @@ constexpr int BK = 16;
 #ifndef DL3_STREAM_KT_FWD
 #define DL3_STREAM_KT_FWD 16  // K-tile depth of the forward instantiation (32 measured in round 2: see DESIGN.md)
 #endif
+#ifndef DL3_STREAM_KT_MSK
+#define DL3_STREAM_KT_MSK 16  // K-tile depth of the single-tensor masked bwd-data instantiation (EPI 3)
+#endif
 #ifndef DL3_WGRAD_WGS_DEFAULT
 #define DL3_WGRAD_WGS_DEFAULT 1024
 #endif
@@ -468,6 +471,14 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
   // loop's own; 80 + 80 do not (nor 48 + 96 with a residual operand: measured, spills between the loads).
   constexpr bool PRE = (EPI == 2);
   static_assert(!PRE || (TM == 1 && WN == 1 && TN <= 3), "prefetched epilogue: narrow single-row-block tiles only");
+  // EPI 3 (round 4; single-tensor bwd-data: dY was materialised by the weight-gradient launch, dl3_pwconv_bwd_weight_dy):
+  // interior tiles take the straight-line MASKED epilogue (forward input for the activation mask and x_hat, optional
+  // residual gradient, BatchNorm-backward sums).  Without the second operand tensor and its coefficient registers the
+  // kernel has the room the two-tensor attempts of rounds 2 and 3 did not (912 B of scratch there).
+  // EPI 3: no residual operand; EPI 4: with one (two kernels instead of two code paths in one: each extra epilogue form
+  // costs registers across the whole kernel)
+  constexpr bool MSK = (EPI == 3 || EPI == 4);
+  static_assert(!MSK || !TWO, "straight-line masked epilogue: single-tensor operand only");
   // KT = depth of one K-tile: each half-wave walks KT/2 consecutive k (KT/8 float4 loads per lane and tensor)
   constexpr int WM = 4 / WN;
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, KH = KT / 2, NJ = KT / 8;
@@ -732,15 +743,34 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
 
     // ---------------- epilogue (same C/D layout as the LDS-staged kernel)
     DL3_T(tq2 = clock64(); tp0 += tq1 - tq0; tp1 += tq2 - tq1;)
+#ifndef DL3_EPI_NOFENCE
+    // The epilogue's addresses depend only on the tile coordinates: left alone, the scheduler computes them BEFORE the
+    // K loop and spills them across it (round 4, kernel-resource-usage: 75 scratch stores per row tile in front of the
+    // loop, ~100 reloads behind it in the 128x160 masked kernel).  Laundering the coordinates through an empty asm behind
+    // the last MFMA pins that arithmetic where it is used.
+    int m0e = __builtin_amdgcn_readfirstlane(m0), nw0e = __builtin_amdgcn_readfirstlane(nw0);  // (wave-uniform both)
+    asm volatile("" : "+s"(m0e), "+s"(nw0e));
+#else
+    const int m0e = m0, nw0e = nw0;
+#endif
     if (FWD && full) {
-      if (!P.ep_add) stream_epilogue_full<TM, TN, false, false, false>(P, acc, m0, nw0, wm, l31, lhi, st1, st2);
-      else stream_epilogue_full<TM, TN, false, true, false>(P, acc, m0, nw0, wm, l31, lhi, st1, st2);
+      if (!P.ep_add) stream_epilogue_full<TM, TN, false, false, false>(P, acc, m0e, nw0e, wm, l31, lhi, st1, st2);
+      else stream_epilogue_full<TM, TN, false, true, false>(P, acc, m0e, nw0e, wm, l31, lhi, st1, st2);
       DL3_T(tp2 += clock64() - tq2;)
       continue;
     }
+    if constexpr (MSK) {
+      // (run_gemm sends a launch here only with ep_x, stat_mode 2 and an addend that is a plain tensor or constant over
+      // whole 32-row blocks)
+      if (full) {
+        stream_epilogue_full<TM, TN, true, EPI == 4, true>(P, acc, m0e, nw0e, wm, l31, lhi, st1, st2);
+        DL3_T(tp2 += clock64() - tq2;)
+        continue;
+      }
+    }
     if constexpr (PRE) {
       if (full) {
-        float *pc = P.c + (size_t)(m0 + __builtin_amdgcn_readfirstlane(wm) * 32) * P.ldc + nw0;
+        float *pc = P.c + (size_t)(m0e + __builtin_amdgcn_readfirstlane(wm) * 32) * P.ldc + nw0e;
         const unsigned lo_c = (unsigned)(4 * lhi * P.ldc + l31);
         const bool mode2 = P.stat_mode == 2;
 #pragma unroll
@@ -763,7 +793,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
     // everything else: generic path, every element predicated
 #pragma unroll
     for (int j = 0; j < TN; j++) {
-      const int col = nw0 + j * 32 + l31;
+      const int col = nw0e + j * 32 + l31;
       const bool cok = col < P.N;
       const int colc = min(col, P.N - 1);
       float bias = 0.f, es = 1.f, et = 0.f, mu = 0.f, is = 0.f;
@@ -772,7 +802,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
       if (!FWD && P.stat_mode == 2) { mu = P.ep_mean[colc]; is = P.ep_invstd[colc]; }
 #pragma unroll
       for (int i = 0; i < TM; i++) {
-        const int rbase = m0 + (wm * TM + i) * 32 + 4 * lhi;
+        const int rbase = m0e + (wm * TM + i) * 32 + 4 * lhi;
         float xr_[16], ad[16];
         if (!FWD && P.ep_x) {
 #pragma unroll
@@ -865,6 +895,7 @@ struct WgradArgs {
   const float *cA, *cB, *cC;
   float *ws;  // [S][K][N]
   int M, K, N, Mper;
+  float *dyout; int lddy;  // nullable: dY = cA*g + cB*y + cC written out [M][N] by the workgroups of the first K-tile row
 #ifdef DL3_PHASE_TIMING
   long long *dbg;
 #endif
@@ -902,6 +933,10 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
   const int mend = min(P.M, mbeg + P.Mper);
   const bool xform = (P.xs != nullptr);
   const bool two = (P.cA != nullptr);
+  // the workgroups of the first K-tile row also write the gradient operand they assemble anyway, dY = cA*g + cB*y + cC,
+  // to HBM (every (row, column) is staged by exactly one (bx, by_ = 0, bz)): the bwd-data GEMM of the layer then reads ONE
+  // tensor instead of two and has no operand transform (round 4)
+  const bool dy_owner = (P.dyout != nullptr) && (by_ == 0);
 
   f32x16 acc[TA][TB];
 #pragma unroll
@@ -1001,6 +1036,16 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
         const bool rok = (m0 + mr) < mend;
         f32x4 v = kA4[i] * rg[i] + kC4[i];
         if (two) v += kB4[i] * ry[i];
+        if (dy_owner && rok) {
+          float *dp = P.dyout + (size_t)(m0 + mr) * P.lddy + nbase + nq * 4;
+          if (VEC) {
+            if (dok[i][0]) st4_nt(dp, v);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+              if (dok[i][j]) dp[j] = v[j];
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++)
           if (!(rok && dok[i][j])) v[j] = 0.f;
@@ -1332,10 +1377,15 @@ int run_gemm(GemmArgs A, hipStream_t st) {
 #undef DL3_SPLIT
       return (int)grid.y;
     }
+    // single-tensor masked bwd-data (dY materialised by dl3_pwconv_bwd_weight_dy): straight-line masked epilogue (EPI 3)
+    const bool msk = !two && !fwd && A.ep_x && A.stat_mode == 2 && !(A.ep_add && A.add_div > 1 && A.add_div % 32 != 0) &&
+                     env_int("DL3_GEMM_EPI3") != 0;
 #define DL3_STREAM(TM_, TN_, WN_)                                                                                    \
   do {                                                                                                               \
     if (two) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, true, 16, 0, WN_>), grid, blk, 0, st, A);           \
     else if (fwd) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, DL3_STREAM_KT_FWD, 1, WN_>), grid, blk, 0, st, A); \
+    else if (msk && !A.ep_add) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, DL3_STREAM_KT_MSK, 3, WN_>), grid, blk, 0, st, A); \
+    else if (msk) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, DL3_STREAM_KT_MSK, 4, WN_>), grid, blk, 0, st, A); \
     else hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, 16, 0, WN_>), grid, blk, 0, st, A);              \
   } while (0)
     if (c.id == 4 && pre_ok(A)) {
@@ -1560,12 +1610,15 @@ extern "C" int dl3_pwconv_bwd_weight_splits(int M, int K, int N, int two_tensor_
   return wgrad_splits(M, K, N, pick_wgrad(M, K, N, two_tensor_dy != 0));
 }
 
-extern "C" int dl3_pwconv_bwd_weight(const float *x, int ldx, const float *in_scale, const float *in_shift,
+static int pwconv_bwd_weight_impl(const float *x, int ldx, const float *in_scale, const float *in_shift,
                                      int in_act, const float *g, int ldg, const float *yraw, int ldyraw,
                                      const float *cA, const float *cB, const float *cC, float *dw, float *dbias,
-                                     int M, int K, int N, void *workspace, size_t workspace_bytes, void *stream) {
+                                     int M, int K, int N, void *workspace, size_t workspace_bytes, float *dy_out, int lddy,
+                                     void *stream) {
   int rc = gemm_common_check("pwconv_bwd_weight", M, K, N);
   if (rc) return rc;
+  DL3_CHECK_ARG(!dy_out || (lddy >= N && lddy % 4 == 0 && al16(dy_out)),
+                "pwconv_bwd_weight_dy: dy_out must be 16-byte aligned with a leading dimension >= N that is a multiple of 4");
   DL3_CHECK_ARG(x && g && workspace, "pwconv_bwd_weight: null pointer");
   DL3_CHECK_ARG(dw || !dbias, "pwconv_bwd_weight: dbias without dw (slabs left in the workspace) is not supported");
   DL3_CHECK_ARG(!cA || (yraw && cB && cC), "pwconv_bwd_weight: cA needs yraw, cB, cC");
@@ -1585,6 +1638,7 @@ extern "C" int dl3_pwconv_bwd_weight(const float *x, int ldx, const float *in_sc
   A.cA = cA; A.cB = cB; A.cC = cC;
   A.ws = (float *)workspace;
   A.M = M; A.K = K; A.N = N;
+  A.dyout = dy_out; A.lddy = lddy;
   A.Mper = dl3_cdiv(dl3_cdiv(M, S), DL3_WGRAD_MS) * DL3_WGRAD_MS;
   DL3_T(A.dbg = g_phase_dbg;)
   hipStream_t st = (hipStream_t)stream;
@@ -1616,6 +1670,24 @@ extern "C" int dl3_pwconv_bwd_weight(const float *x, int ldx, const float *in_sc
     if (rc) return rc;
   }
   return DL3_OK;
+}
+
+extern "C" int dl3_pwconv_bwd_weight(const float *x, int ldx, const float *in_scale, const float *in_shift,
+                                     int in_act, const float *g, int ldg, const float *yraw, int ldyraw,
+                                     const float *cA, const float *cB, const float *cC, float *dw, float *dbias,
+                                     int M, int K, int N, void *workspace, size_t workspace_bytes, void *stream) {
+  return pwconv_bwd_weight_impl(x, ldx, in_scale, in_shift, in_act, g, ldg, yraw, ldyraw, cA, cB, cC, dw, dbias, M, K, N,
+                                workspace, workspace_bytes, nullptr, 0, stream);
+}
+
+extern "C" int dl3_pwconv_bwd_weight_dy(const float *x, int ldx, const float *in_scale, const float *in_shift,
+                                        int in_act, const float *g, int ldg, const float *yraw, int ldyraw,
+                                        const float *cA, const float *cB, const float *cC, float *dw, float *dbias,
+                                        int M, int K, int N, void *workspace, size_t workspace_bytes, float *dy_out,
+                                        int lddy, void *stream) {
+  DL3_CHECK_ARG(dy_out, "pwconv_bwd_weight_dy: dy_out is NULL (use dl3_pwconv_bwd_weight)");
+  return pwconv_bwd_weight_impl(x, ldx, in_scale, in_shift, in_act, g, ldg, yraw, ldyraw, cA, cB, cC, dw, dbias, M, K, N,
+                                workspace, workspace_bytes, dy_out, lddy, stream);
 }
 
 extern "C" int dl3_transpose(const float *in, float *out, int rows, int cols, void *stream) {

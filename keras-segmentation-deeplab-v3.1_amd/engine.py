@@ -206,6 +206,11 @@ class Engine:
         # every fold deferred: 193.9 -> 196.4 ms)
         self.fold_defer_bytes = int(os.environ.get("DL3_FOLD_DEFER_MB", "8")) << 20
         self._folds = []
+        # round 4: the weight-gradient launch of a BatchNorm'ed 1x1 convolution also writes dY = cA*g + cB*y + cC (it
+        # assembles it anyway), and the bwd-data GEMM of the layer reads that ONE tensor (dl3_pwconv_bwd_weight_dy) — for
+        # outputs of at most DL3_DY_MAT channels (0 disables; wide outputs pay a 2 GB write to save a 2 GB read)
+        self.dy_mat_maxn = int(os.environ.get("DL3_DY_MAT", "100000"))
+        self.dy_buf = None
         self.fork = os.environ.get("DL3_FORK", "0") in ("1", "2")
         # DL3_FORK=2 (experiment): only the weight gradient that can run next to an HBM-bound depthwise backward launch
         # leaves the chain, and the chain's next GEMM waits for it: matrix-bound and HBM-bound kernels overlap, two GEMMs never do
@@ -861,6 +866,11 @@ class Engine:
         # weight transposes for bwd-data, then the units in reverse
         self._transposes = []
         first_bwd = len(self.ops_bwd)
+        # one buffer holds the materialised dY of whichever 1x1 convolution is being differentiated (written by its
+        # weight-gradient launch, read by its bwd-data launch right behind it on the same stream)
+        n = max([u.M * u.N for u in self.units if isinstance(u, PwUnit) and u.dy_mat_ok()] or [0])
+        if n:
+            self.dy_buf = self.empty(n)
         for u in reversed(self.units):
             u.bwd()
         if self._transposes:
@@ -1270,25 +1280,39 @@ class PwUnit(_ConvBase):
         eng.op(eng.ops_bwd, "dl3_affine_add", ptr(sg), N, None, None, ACT_NONE, ptr(sy), N, None, None, ACT_NONE,
                ptr(gout), N, B, N, 0.0, 0, None)
 
+    def dy_mat_ok(self):
+        """does the weight-gradient launch of this convolution also write dY for its bwd-data launch?  (its output is
+        BatchNorm'ed — otherwise dY is g itself —, it has a weight gradient to compute and data gradient to hand on, the
+        backward fork is off — the two launches must stay ordered on one stream — and N is within DL3_DY_MAT)"""
+        eng, outv = self.eng, self.outv
+        has_bn = any(off == outv.off for _, off, _ in outv.buf.bns)
+        return (has_bn and self.N <= eng.dy_mat_maxn and self.N % 4 == 0 and not eng.fork and not self.bias
+                and eng.trainable(self.wname()) and self.inv.buf.requires_grad)
+
     def bwd(self):
         eng, inv, outv = self.eng, self.inv, self.outv
         M, K, N = self.M, self.K, self.N
         g, ldg, y, ldy, cA, cB, cC = eng.grad_operand(outv)
         s, t, a = inv.xform()
         wsrc = eng.wptr(self.wname()) + 4 * self.wrow0 * N
+        dy = ptr(eng.dy_buf) if (cA is not None and self.dy_mat_ok()) else None
         if eng.trainable(self.wname()) or (self.bias and eng.trainable(self.bias)):
             ws = eng.lib.dl3_pwconv_bwd_weight_workspace(M, K, N)
             S = eng.lib.dl3_pwconv_bwd_weight_splits(M, K, N, 1 if cA else 0)
+            fn, tail = ("dl3_pwconv_bwd_weight_dy", (dy, N)) if dy else ("dl3_pwconv_bwd_weight", ())
             if eng.defer_fold(S, K * N) and not self.bias and eng.trainable(self.wname()):
                 # the launch leaves its [S][K][N] slabs in a workspace of its own; folded at the end of the pass
                 own = eng.empty(ws // 4 + 4)
-                eng.op_side(eng.ops_bwd, "dl3_pwconv_bwd_weight", inv.p(), inv.ld, s, t, a, g, ldg, y, ldy, cA, cB, cC,
-                            None, None, M, K, N, ptr(own), ws)
+                eng.op_side(eng.ops_bwd, fn, inv.p(), inv.ld, s, t, a, g, ldg, y, ldy, cA, cB, cC,
+                            None, None, M, K, N, ptr(own), ws, *tail)
                 eng.fold(ptr(own), S, K * N, eng.gptr(self.wname()) + 4 * self.wrow0 * N)
             else:
-                eng.op_ws_side(eng.ops_bwd, "dl3_pwconv_bwd_weight", ws, 17, inv.p(), inv.ld, s, t, a, g, ldg, y, ldy, cA, cB,
+                eng.op_ws_side(eng.ops_bwd, fn, ws, 17, inv.p(), inv.ld, s, t, a, g, ldg, y, ldy, cA, cB,
                                cC, eng.gptr(self.wname()) + (4 * self.wrow0 * N if eng.trainable(self.wname()) else 0),
-                               eng.gptr(self.bias) if self.bias else None, M, K, N, 0, ws)
+                               eng.gptr(self.bias) if self.bias else None, M, K, N, 0, ws, *tail)
+        if dy:
+            # from here on the layer's gradient operand is the one tensor the weight-gradient launch just wrote
+            g, ldg, y, ldy, cA, cB, cC = dy, N, None, 0, None, None, None
         if self.img_add is not None:
             self._bwd_img_add(g, ldg, y, ldy, cA, cB, cC)
         ibuf = inv.buf

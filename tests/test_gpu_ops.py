@@ -53,6 +53,10 @@ DW_CASES = [
     (1, 64, 64, 2048, 1, 36, None, 0, 1),
     (1, 64, 64, 728, 1, 2, None, 0, 1),    # middle flow at OS=8: 728 channels (22.75 slabs of 32), rate 2
     (1, 33, 33, 1536, 1, 4, None, 0, 1),   # exit flow rate 4, odd map
+    # the two-pixel FORWARD plan has more partial rows than the backward plan (96 / 48 against 72 / 36): the backward
+    # launch must zero the rows of the NaN-filled partial buffers it does not own
+    (3, 33, 65, 960, 1, 16, None, 0, 2),
+    (3, 33, 65, 960, 1, 2, None, 0, 2),
 ]
 
 
@@ -359,6 +363,50 @@ def test_pwconv_bwd_data(L, case):
         assert relerr(s2, (ref * (x - mean) * invstd).sum(0)) < 1e-3
 
 
+MSK_CASES = [
+    # single-tensor masked bwd-data (dY materialised by dl3_pwconv_bwd_weight_dy): straight-line masked epilogue, EPI 3
+    # (no residual) / EPI 4 (residual tensor or per-image addend); ragged shapes take the generic epilogue on their
+    # edge tiles.  M, K, N, act, add mode
+    (65536, 960, 160, 2, 0),          # project conv, 128x160 tiles (128x96 prefetching tiles unless DL3_GEMM_PRE=0)
+    (65536 + 200, 160, 960, None, 1),  # expand conv + residual gradient, ragged last row tile
+    (65536, 576, 96, 2, 0),
+    (8192, 384, 64, None, 1),         # few row tiles: 32-row configurations
+    (4096, 320, 256, None, 2),        # per-image addend (64 rows per image)
+    (1000, 144, 24, 2, 0),            # ragged in both directions
+    (32768, 728, 728, 1, 1),          # Xception middle flow
+]
+
+
+@pytest.mark.parametrize("pre", ["1", "0"])
+@pytest.mark.parametrize("case", MSK_CASES)
+def test_pwconv_bwd_data_single_tensor_masked(L, case, pre, monkeypatch):
+    monkeypatch.setenv("DL3_GEMM_PRE", pre)
+    M, K, N, act, addmode = case
+    test_pwconv_bwd_data(L, (M, K, N, act, False, addmode, True))
+
+
+def test_pwconv_bwd_data_masked_epilogue_toggle_is_bit_identical(L, monkeypatch):
+    """DL3_GEMM_EPI3=0 sends the same launch through the generic epilogue: same sums in the same order"""
+    M, K, N = 16384, 160, 960
+    rng = np.random.default_rng(14)
+    g = dev(rng.normal(0, 1, (M, N)))
+    w = rng.normal(0, 0.2, (K, N)).astype(np.float32)
+    x, add = dev(rng.normal(0, 1, (M, K))), dev(rng.normal(0, 1, (M, K)))
+    mean, invstd = dev(rng.normal(0, 1, K)), dev(rng.uniform(0.5, 2, K))
+    wT = empty(N, K)
+    call("dl3_transpose", ptr(dev(w)), ptr(wT), K, N)
+    P = L.dl3_pwconv_partials(M, N, K)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DL3_GEMM_EPI3", flag)
+        dx, dpart = empty(M, K), empty(P, K, 2)
+        call("dl3_pwconv_bwd_data", ptr(g), N, None, N, None, None, None, ptr(wT), ptr(dx), K, ptr(x), K, None, None, 0,
+             ptr(add), K, 1, 1.0, ptr(mean), ptr(invstd), ptr(dpart), M, K, N)
+        outs.append((host(dx).copy(), host(dpart).copy()))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
 BW_CASES = [
     # M, K, N, act, two-tensor, dbias
     (1024, 16, 96, 2, True, False),
@@ -400,6 +448,33 @@ def test_pwconv_bwd_weight(L, case):
     assert relerr(host(dw), ref) < TOL
     if dbias:
         assert relerr(host(db), dY.sum(0)) < TOL
+
+
+@pytest.mark.parametrize("case", [c for c in BW_CASES if c[4] and not c[5]] + [(130, 24, 144, 2, True, False)])
+def test_pwconv_bwd_weight_writes_dy(L, case):
+    """dl3_pwconv_bwd_weight_dy: the same weight gradient bit for bit, plus dY = cA*g + cB*y + cC written once"""
+    M, K, N, act, two, dbias = case
+    rng = np.random.default_rng(15)
+    g = rng.normal(0, 1, (M, N)).astype(np.float32)
+    yraw = rng.normal(0, 1, (M, N)).astype(np.float32)
+    cA, cB, cC = [rng.normal(0, 1, N).astype(np.float32) for _ in range(3)]
+    x = rng.normal(0, 1, (M, K)).astype(np.float32)
+    s, t, a = _xform(rng, K, act)
+    nbytes = L.dl3_pwconv_bwd_weight_workspace(M, K, N)
+    ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device="cuda")
+    args = (ptr(dev(x)), K, ptr(dev(s)) if s is not None else None, ptr(dev(t)) if t is not None else None, a,
+            ptr(dev(g)), N, ptr(dev(yraw)), N, ptr(dev(cA)), ptr(dev(cB)), ptr(dev(cC)))
+    dw0, dw1 = empty(K, N), empty(K, N)
+    ldd = N + 8
+    dy = empty(M, ldd)
+    call("dl3_pwconv_bwd_weight", *args, ptr(dw0), None, M, K, N, ptr(ws), nbytes)
+    call("dl3_pwconv_bwd_weight_dy", *args, ptr(dw1), None, M, K, N, ptr(ws), nbytes, ptr(dy), ldd)
+    assert np.array_equal(host(dw0), host(dw1))
+    got = host(dy)
+    # fp32 fma of the kernel against the same expression in float64
+    ref = cA.astype(np.float64) * g + cB.astype(np.float64) * yraw + cC
+    assert relerr(got[:, :N], ref) < 1e-6
+    assert np.isnan(got[:, N:]).all()   # nothing written beyond the N columns
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 32, 3, 32, 2), (1, 17, 19, 3, 32, 2), (1, 16, 16, 32, 64, 1)])
