@@ -63,6 +63,8 @@ def parse_args():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-split-leg", action="store_true",
                     help="skip the second timed loop with DL3_GEMM_MATH=split (reported beside, never as, the headline)")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="skip the compact legs (configs[1] at B=2 / B=16, configs[2], configs[3]) of the default run")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = sweep thread counts up to os.cpu_count()")
     ap.add_argument("--plan-json", default=None, help="write the per-launch in-situ table (op, shape, ms, FLOPs, bytes)")
     return ap.parse_args()
@@ -95,7 +97,12 @@ def build_engine(args):
         model = Deeplabv3(weights=None, input_shape=shape, classes=21, backbone=args.backbone, OS=args.os)
     else:
         model = SegModel(image_size=shape[:2]).create_seg_model(args.head, n=21, backbone=args.backbone)
-    eng = model._engine(args.batch, True, bn_mode=args.bn_mode, dropout=True, use_graph=not args.no_graph)
+    kw = {}
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # the engine Model.train_on_batch builds under Model.distribute(): the loss is normalised by the GLOBAL
+        # count(w != 0), refreshed before every step (Engine.sync_nnz) — the N>1 number times the product path
+        kw["external_nnz"] = True
+    eng = model._engine(args.batch, True, bn_mode=args.bn_mode, dropout=True, use_graph=not args.no_graph, **kw)
     rng = np.random.default_rng(1000 + int(os.environ.get("RANK", "0")))
     x = rng.integers(0, 256, (args.batch,) + shape).astype(np.float32)
     y = rng.integers(0, 22, (args.batch, args.size * args.size)).astype(np.float32)  # 21 = void
@@ -263,16 +270,31 @@ def cpu_baseline_leg(args):
             what, B / med, best, {k: round(v, 2) for k, v in sweep.items()}))
         return dict(value=B / med, cores=best, sweep_img_s={str(k): round(v, 3) for k, v in sweep.items()})
 
+    def case_fwd1(size, classes):
+        # BASELINE.json configs[0] as stated: Deeplabv3(mobilenetv2, (128,128,3), classes=2, OS=16), single-image
+        # forward (inference-mode BatchNorm, moving statistics)
+        kw = dict(backbone="mobilenetv2", input_shape=(size, size, 3), classes=classes, OS=16)
+        params = O.init_params(O.param_shapes("mobilenetv2", classes), seed=1)
+        x = np.random.default_rng(0).integers(0, 256, (1, size, size, 3)).astype(np.float32)
+        return lambda: T.infer_logits(params, x, **kw)
+
     c2 = measure(case(args.size, 21, 2), 2, "cfg2 %dx%d B=2" % (args.size, args.size))
     cpu_a = cpu_a_leg(args, avail)
-    # cfg1's shape at B=2: with one image the image-pooling BatchNorm sees a single value per channel
-    c1 = measure(case(128, 2, 2), 2, "cfg1 128x128 B=2")
+    c1 = measure(case_fwd1(128, 2), 1, "cfg1 128x128 single-image forward")
+    # cfg1's shape as a training step, B=2 (with one image the image-pooling BatchNorm sees a single value per channel)
+    c1t = measure(case(128, 2, 2), 2, "cfg1 128x128 B=2 fwd+bwd")
     return dict(value=c2["value"], unit="img/s", cores=c2["cores"], kind="port", host_cores_available=avail,
                 sample="median of 10 steps x 2 images %dx%dx21 fwd+bwd after 2 warm-up steps, torch-CPU (oneDNN) restatement "
-                       "oracle/torch_ref.py, best of the thread-count sweep" % (args.size, args.size),
+                       "oracle/torch_ref.py; thread counts swept (4 ... all cores, stopping once a count is half as fast as "
+                       "the best): oneDNN's fp32 convolutions of this graph stop scaling at `cores` threads on this host — "
+                       "more threads are SLOWER (see thread_sweep_img_s)" % (args.size, args.size),
                 thread_sweep_img_s=c2["sweep_img_s"], cpu_a=cpu_a,
                 cfg1={"value": c1["value"], "unit": "img/s", "cores": c1["cores"],
-                      "sample": "median of 10 steps x 2 images 128x128x2 fwd+bwd", "thread_sweep_img_s": c1["sweep_img_s"]})
+                      "sample": "BASELINE.json configs[0]: median of 10 single-image forwards 128x128x3 -> 2 classes "
+                                "(inference BatchNorm) after 2 warm-ups", "thread_sweep_img_s": c1["sweep_img_s"]},
+                cfg1_train_b2={"value": c1t["value"], "unit": "img/s", "cores": c1t["cores"],
+                               "sample": "median of 10 steps x 2 images 128x128x2 fwd+bwd",
+                               "thread_sweep_img_s": c1t["sweep_img_s"]})
 
 
 def cpu_a_leg(args, avail):
@@ -350,7 +372,63 @@ def split_math_leg(args):
             "what": "same workload, same K steps; the 1x1-conv GEMMs (forward, bwd-data, bwd-weight) computed as 6 bf16 MFMAs "
                     "on exact 3-way bf16 splits of the fp32 operands (fp32 accumulate); everything else unchanged",
             "accuracy": "max |err| / sum|a||b| against float64 at M=65536 K=960 N=160: split 3.3e-7, v_mfma_f32 3.7e-7 "
-                        "(tests/test_gpu_ops.py::test_split_math_error); all parity tests pass unchanged in this mode"}
+                        "(tests/test_gpu_ops.py::test_split_math_error); full-size parity in this mode: tests/test_gpu_fullsize.py "
+                        "::test_cfg2_mnv2_512_train_step_split_math, ::test_cfg3_subpixel_mnv2_512_train_step_split_math, "
+                        "::test_cfg4_xception_os8_256_train_step_split_math (same bars as the f32 tests)"}
+
+
+def _free_engines():
+    import gc
+    from dl3_amd import graph as G
+    gc.collect()
+    G.clear_session()
+    torch.cuda.empty_cache()
+
+
+def compact_leg(args, **over):
+    """One more configuration of BASELINE.json timed the same way (resident synthetic batch, hipGraph replay + Adam,
+    barrier-free single GPU), compactly: 3 warm-up steps, then as many steps as fill about a second (5..200), plus ONE
+    in-situ pass for the family fractions.  The headline engine has been freed before."""
+    a = argparse.Namespace(**vars(args))
+    for k, v in over.items():
+        setattr(a, k, v)
+    _free_engines()
+    model, eng = build_engine(a)
+
+    def step():
+        eng.fwd_bwd()
+        eng.adam(None, 1.0)
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    if not a.no_graph and eng.graph is None:
+        return {"error": "hipGraph capture failed"}
+    t0 = time.perf_counter()
+    step()
+    step()
+    torch.cuda.synchronize()
+    est = (time.perf_counter() - t0) / 2
+    steps = int(min(200, max(5, round(1.0 / max(est, 1e-4)))))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"value": a.batch * steps / dt, "unit": "img/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "batch": a.batch,
+           "workload": "%s %dx%d OS=%d head=%s B=%d" % (a.backbone, a.size, a.size, a.os, a.head, a.batch),
+           "launches_per_step": len(eng.ops_fwd) + len(eng.ops_bwd) + 1, "device_gb": round(torch.cuda.memory_allocated() / 1e9, 2)}
+    rb = roofline_blocks(insitu_profile(eng, passes=1), a)
+    if "roofline" in rb:
+        out["gemm_frac_of_fp32_mfma_peak"] = round(rb["roofline"]["frac"], 4)
+        out["gemm_share_of_step"] = round(rb["roofline"]["share_of_step"], 4)
+    if "roofline_hbm" in rb:
+        out["atrous_dw_frac_of_hbm_peak"] = round(rb["roofline_hbm"]["frac"], 4)
+        out["atrous_dw_share_of_step"] = round(rb["roofline_hbm"]["share_of_step"], 4)
+    log("leg %s: %.1f img/s (%.2f ms/step, %d steps)" % (out["workload"], out["value"], out["ms_per_step"], steps))
+    del step
+    return out
 
 
 def main():
@@ -383,6 +461,8 @@ def main():
     dp.broadcast(eng.state)
 
     def step():
+        if eng.external_nnz:
+            eng.sync_nnz(dp)  # device count + one-float RCCL all-reduce + scale, all on the stream (no host round trip)
         eng.fwd_bwd()
         scale = dp.allreduce_grads(eng.grads)
         eng.adam(None, scale)
@@ -454,10 +534,27 @@ def main():
                 with open(args.plan_json, "w") as f:
                     json.dump({"batch": args.batch, "backbone": args.backbone, "head": args.head, "os": args.os,
                                "size": args.size, "rows": rows}, f, indent=0)
+        rec["config"]["deferred_fold_workspaces_mb"] = round(eng.own_fold_ws_bytes / 2 ** 20, 1)
+        default_run = default_cfg and args.batch == 128 and args.bn_mode == "batch"
         if dp.world == 1 and not args.no_split_leg and rec["config"]["matrix_math"] == "f32":
             del step
             eng = model = None
             rec["split_math"] = split_math_leg(args)
+        if dp.world == 1 and default_run and not args.no_legs:
+            # what else BASELINE.json lists, timed by the same run: the reference's own batch sizes for
+            # configs[1] (notebook: 2, SegModel default: 16, utils.py:162), configs[2] (Subpixel head) and configs[3]
+            # (Xception OS=8).  `value` above is untouched by these.
+            try:
+                del step
+            except NameError:
+                pass
+            eng = model = None
+            rec["by_batch"] = {str(b): compact_leg(args, batch=b) for b in (2, 16)}
+            rec["configs"] = {
+                "cfg3_subpixel_b128": compact_leg(args, head="subpixel"),
+                "cfg4_xception_os8_b16": compact_leg(args, backbone="xception", os=8, batch=16),
+            }
+            _free_engines()
         if dp.world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline_leg(args)
             log("cpu baseline done")

@@ -16,6 +16,13 @@
  *    weights in Keras layouts (pointwise [K][N]; depthwise [3][3][C]; dense [3][3][Cin][Cout]).
  *  - no allocation, no synchronisation, no global mutable state inside ops; the last
  *    argument is the hipStream_t to enqueue on.  Ops are hipGraph-capturable.
+ *    Two documented exceptions, both opt-in and off by default: dl3_set_gemm_math() is a
+ *    process-wide switch (by design: it selects the arithmetic of every later launch), and in
+ *    split math (DL3_MATH_SPLIT) the dl3_pwconv_fwd / _bwd_data launches keep ONE device
+ *    scratch per device for the launch's pre-split weights, grown with hipMalloc on first use —
+ *    so the first split-math launch of a process must not be issued inside a stream capture
+ *    (it returns -1 with a message; the engine's eager warm-up step takes care of it).  The
+ *    f32 path — the default, and the only one any benchmark headline uses — keeps the rule.
  *  - "input transform": a tensor is handed over as (raw, scale[C], shift[C], act) and is
  *    read as act(scale*raw+shift) — BatchNorm + ReLU/ReLU6 of the PRODUCER are applied on
  *    load by the consumer, so an activation is written once and read once.  scale==NULL
@@ -191,6 +198,15 @@ int dl3_bn_finalize_direct(const float *y, int ldy, int M, int C, const float *g
 /* inference / frozen mode: scale, shift, mean, invstd from the moving statistics */
 int dl3_bn_frozen(const float *gamma, const float *beta, const float *moving_mean, const float *moving_var,
                   float eps, int C, float *scale, float *shift, float *mean, float *invstd, void *stream);
+/* the same for a tensor whose PRODUCER subtracts the mean: neg_mean[C] = -moving_mean is handed to the producing
+ * convolution as its bias (a BatchNorm'ed Conv2D has none of its own, deeplabv3p.py:78-79), the tensor holds y - mean,
+ * and consumers read scale*(y - mean) + beta with scale = gamma*invstd, shift = beta, mean = 0.  scale*y + (beta -
+ * mean*scale) rounds the large product mean*scale into the shift once and for all — half an ulp of |mean*scale| on
+ * every element, the size of the tensor's own rounding noise when |mean| >> sigma; (y - mean) is exact there.  This is
+ * the form the reference's BatchNormalization evaluates in inference, gamma*(x - mean)/sqrt(var + eps) + beta. */
+int dl3_bn_frozen_centered(const float *gamma, const float *beta, const float *moving_mean, const float *moving_var,
+                           float eps, int C, float *scale, float *shift, float *mean, float *invstd, float *neg_mean,
+                           void *stream);
 /* fold backward partials (sum g, sum g*x_hat) into dgamma, dbeta and the on-load coefficients
  * dY = cA*g + cB*yraw + cC.  batch_mode=1: full BN backward; 0: frozen statistics (cB=cC=0). */
 int dl3_bn_bwd_finalize(const float *dstat_partial, int P, int ldc, int C, double count, const float *gamma,
@@ -292,6 +308,8 @@ int dl3_reduce_partials(const float *partial, int P, int n, float *out, void *st
 int dl3_reduce_partials_blocks(int P, int n);
 int dl3_reduce_partials_batched(const long long *desc, int m, int total_blocks, void *stream);
 int dl3_fill(float *p, float value, size_t n, void *stream);
+/* p[i] *= value (the data-parallel loss normaliser: count_all(w != 0) summed over ranks on the stream, then / world) */
+int dl3_scale(float *p, float value, size_t n, void *stream);
 /* Keras Adam with decay (notebook cell 2): lr_t is computed on the host;
  * g is first multiplied by grad_scale (1/world_size after the RCCL sum) */
 int dl3_adam_step(float *p, const float *g, float *m, float *v, size_t n, float lr_t, float beta1, float beta2,

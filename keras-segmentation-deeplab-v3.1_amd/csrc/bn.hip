@@ -157,6 +157,25 @@ __global__ __launch_bounds__(256) void bn_frozen_kernel(const float *__restrict_
   }
 }
 
+// the same with the mean subtraction moved into the PRODUCER: neg_mean = -moving_mean goes into the bias slot of the
+// convolution that writes the tensor, which then stores y - mean; consumers read scale * (y - mean) + beta
+__global__ __launch_bounds__(256) void bn_frozen_centered_kernel(const float *__restrict__ gamma,
+                                                                 const float *__restrict__ beta,
+                                                                 const float *__restrict__ mmean,
+                                                                 const float *__restrict__ mvar, float eps, int C,
+                                                                 float *scale, float *shift, float *mean, float *invstd,
+                                                                 float *neg_mean) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C) {
+    const double is = 1.0 / sqrt((double)mvar[c] + (double)eps);
+    scale[c] = (float)((double)gamma[c] * is);
+    shift[c] = beta[c];
+    neg_mean[c] = -mmean[c];
+    if (mean) mean[c] = 0.f;
+    if (invstd) invstd[c] = (float)is;
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__restrict__ part, int P, int ldc, int C,
                                                               double count, const float *__restrict__ gamma,
                                                               const float *__restrict__ mean,
@@ -411,6 +430,10 @@ __global__ __launch_bounds__(256) void fill_kernel(float *p, float v, size_t n) 
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
 }
 
+__global__ __launch_bounds__(256) void scale_kernel(float *p, float v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] *= v;
+}
+
 // Keras Adam (notebook cell 2): p -= lr_t * m / (sqrt(v) + eps), bias correction folded into lr_t
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                    float *__restrict__ m, float *__restrict__ v, size_t n,
@@ -512,6 +535,17 @@ extern "C" int dl3_bn_frozen(const float *gamma, const float *beta, const float 
   return DL3_OK;
 }
 
+extern "C" int dl3_bn_frozen_centered(const float *gamma, const float *beta, const float *moving_mean,
+                                      const float *moving_var, float eps, int C, float *scale, float *shift, float *mean,
+                                      float *invstd, float *neg_mean, void *stream) {
+  DL3_CHECK_ARG(gamma && beta && moving_mean && moving_var && scale && shift && neg_mean && C > 0,
+                "bn_frozen_centered: bad argument");
+  hipLaunchKernelGGL(bn_frozen_centered_kernel, dim3(dl3_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                     moving_mean, moving_var, eps, C, scale, shift, mean, invstd, neg_mean);
+  DL3_LAUNCH_CHECK("bn_frozen_centered");
+  return DL3_OK;
+}
+
 extern "C" int dl3_bn_bwd_finalize(const float *dstat_partial, int P, int ldc, int C, double count,
                                    const float *gamma, const float *mean, const float *invstd, int batch_mode,
                                    float *cA, float *cB, float *cC, float *dgamma, float *dbeta, void *stream) {
@@ -605,6 +639,13 @@ extern "C" int dl3_fill(float *p, float value, size_t n, void *stream) {
   DL3_CHECK_ARG(p && n > 0, "fill: bad argument");
   hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, value, n);
   DL3_LAUNCH_CHECK("fill");
+  return DL3_OK;
+}
+
+extern "C" int dl3_scale(float *p, float value, size_t n, void *stream) {
+  DL3_CHECK_ARG(p && n > 0, "scale: bad argument");
+  hipLaunchKernelGGL(scale_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, value, n);
+  DL3_LAUNCH_CHECK("scale");
   return DL3_OK;
 }
 

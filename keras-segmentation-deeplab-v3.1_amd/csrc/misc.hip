@@ -6,6 +6,16 @@
 
 namespace {
 
+// Keras categorical_crossentropy clips the renormalised probability with tf.clip_by_value before the log
+// (utils.py:130 -> keras/backend/tensorflow_backend.py), and the gradient of clip_by_value is ZERO where its input lies
+// outside [1e-7, 1 - 1e-7]: a pixel whose true-class probability has left that interval has a constant loss and hands
+// no gradient to any logit; inside it the gradient is (p - onehot).  1.f inside (bounds included, as TF), 0.f outside.
+__device__ __forceinline__ float dl3_clip_pass(float q) { return (q >= 1e-7f && q <= 1.f - 1e-7f) ? 1.f : 0.f; }
+// The loss normaliser count(w != 0): an integer count in a single process, count_all / world under data parallelism
+// (fractional, below 1 when the global count is smaller than the world): only a zero count is replaced (no weight is
+// non-zero -> every term is zero anyway)
+#define DL3_NNZ_FLOOR 1e-20f
+
 // tf.image.resize_bilinear(align_corners=False) of TF 1.x: src = dst * (in/out), no half-pixel
 // offset; lower = floor(src), upper = min(lower+1, in-1), lerp = src - lower.
 struct Lerp {
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(256) void shuffle_xent_kernel(const float *__restri
     tile[px * LP + (e / rr) * (rr + 1) + e % rr] = u[flat + t];
   }
   __syncthreads();
-  const float inv_nnz = 1.f / fmaxf(*nnz, 1.f);
+  const float inv_nnz = 1.f / fmaxf(*nnz, DL3_NNZ_FLOOR);
   const int Wr = W * r;
   float lsum = 0.f;
   for (int o = threadIdx.x; o < pb * rr; o += 256) {
@@ -251,12 +261,14 @@ __global__ __launch_bounds__(256) void shuffle_xent_kernel(const float *__restri
       psum += z[c];
       pt = (c == t) ? z[c] : pt;
     }
+    float inside = 1.f;
     if (t >= 0 && t < C) {
       float qq = pt / psum;
+      inside = dl3_clip_pass(qq);
       qq = fminf(fmaxf(qq, 1e-7f), 1.f - 1e-7f);
       lsum += -logf(qq) * w * inv_nnz;
     }
-    const float gs = w * inv_nnz;
+    const float gs = w * inv_nnz * inside;
 #pragma unroll
     for (int c = 0; c < MAXC; c++)
       if (c < C) cell[c * (rr + 1)] = (z[c] - (c == t ? 1.f : 0.f)) * gs;
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float *__restri
                                                            float *__restrict__ dl, float *__restrict__ loss_part,
                                                            long M, int C) {
   __shared__ float red[4];
-  const float inv_nnz = 1.f / fmaxf(*nnz, 1.f);
+  const float inv_nnz = 1.f / fmaxf(*nnz, DL3_NNZ_FLOOR);
   float lsum = 0.f;
   for (long m = (long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long)gridDim.x * 256) {
     const float *r = x + (size_t)m * C;
@@ -386,13 +398,18 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float *__restri
       psum += pc;
       if (c == t) pt = pc;
       if (probs) probs[(size_t)m * C + c] = pc;
-      if (dl) dl[(size_t)m * C + c] = (pc - (c == t ? 1.f : 0.f)) * w * inv_nnz;
     }
+    float inside = 1.f;
     if (t >= 0 && t < C) {
       // Keras categorical_crossentropy on probabilities: renormalise, clip to [1e-7, 1-1e-7], -log
       float q = pt / psum;
+      inside = dl3_clip_pass(q);
       q = fminf(fmaxf(q, 1e-7f), 1.f - 1e-7f);
       lsum += -logf(q) * w * inv_nnz;
+    }
+    if (dl) {
+      const float gs = w * inv_nnz * inside;
+      for (int c = 0; c < C; c++) dl[(size_t)m * C + c] = (expf(r[c] - mx) * inv - (c == t ? 1.f : 0.f)) * gs;
     }
   }
   lsum = wave_sum(lsum);
@@ -414,7 +431,7 @@ __global__ __launch_bounds__(256) void xent32_kernel(const float *__restrict__ x
   constexpr int MAXC = 32;
   __shared__ float tile[256 * MAXC];
   __shared__ float red[4];
-  const float inv_nnz = 1.f / fmaxf(*nnz, 1.f);
+  const float inv_nnz = 1.f / fmaxf(*nnz, DL3_NNZ_FLOOR);
   float lsum = 0.f;
   for (long base = (long)blockIdx.x * 256; base < M; base += (long)gridDim.x * 256) {
     const long m = base + threadIdx.x;
@@ -465,8 +482,10 @@ __global__ __launch_bounds__(256) void xent32_kernel(const float *__restrict__ x
       psum += z[c];
       pt = (c == t) ? z[c] : pt;
     }
+    float inside = 1.f;
     if (ok && t >= 0 && t < C) {
       float q = pt / psum;
+      inside = dl3_clip_pass(q);
       q = fminf(fmaxf(q, 1e-7f), 1.f - 1e-7f);
       lsum += -logf(q) * w * inv_nnz;
     }
@@ -480,7 +499,7 @@ __global__ __launch_bounds__(256) void xent32_kernel(const float *__restrict__ x
       __syncthreads();
     }
     if (dl) {
-      const float gs = w * inv_nnz;
+      const float gs = w * inv_nnz * inside;
 #pragma unroll
       for (int c = 0; c < MAXC; c++)
         if (c < C) tile[threadIdx.x * C + c] = (z[c] - (c == t ? 1.f : 0.f)) * gs;
@@ -518,7 +537,7 @@ __global__ __launch_bounds__(256) void xent32_fold_kernel(const float *__restric
     xw[ox] = lx.w;
     xlo[ox] = lx.lo;
   }
-  const float inv_nnz = 1.f / fmaxf(*nnz, 1.f);
+  const float inv_nnz = 1.f / fmaxf(*nnz, DL3_NNZ_FLOOR);
   float lsum = 0.f;
   for (int row = blockIdx.x; row < N * Ho; row += gridDim.x) {
     const int n = row / Ho, oy = row - n * Ho;
@@ -561,12 +580,14 @@ __global__ __launch_bounds__(256) void xent32_fold_kernel(const float *__restric
         psum += z[c];
         pt = (c == t) ? z[c] : pt;
       }
+      float inside = 1.f;
       if (t >= 0 && t < C) {
         float q = pt / psum;
+        inside = dl3_clip_pass(q);
         q = fminf(fmaxf(q, 1e-7f), 1.f - 1e-7f);
         lsum += -logf(q) * w * inv_nnz;
       }
-      const float gs = w * inv_nnz;
+      const float gs = w * inv_nnz * inside;
 #pragma unroll
       for (int c = 0; c < MAXC; c++)
         if (c < C) fold_tile[ox * C + c] = (z[c] - (c == t ? 1.f : 0.f)) * gs;

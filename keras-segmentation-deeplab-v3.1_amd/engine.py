@@ -23,7 +23,7 @@ from . import capi
 from .capi import ACT_NONE, ACT_RELU, ACT_RELU6, IMPL_AUTO, ptr
 
 _ACT = {"relu": ACT_RELU, "relu6": ACT_RELU6}
-V_SCALE, V_SHIFT, V_MEAN, V_INVSTD, V_CA, V_CB, V_CC = range(7)
+V_SCALE, V_SHIFT, V_MEAN, V_INVSTD, V_CA, V_CB, V_CC, V_NEGMEAN = range(8)
 
 
 def _unbias_keras224(n, eps):
@@ -124,7 +124,7 @@ class Buf:
         self.eng, self.N, self.H, self.W, self.ld, self.name = eng, N, H, W, ld, name
         self.M = N * H * W
         self.t = eng.empty(self.M * ld)
-        v = torch.zeros(7, ld, dtype=torch.float32)
+        v = torch.zeros(8, ld, dtype=torch.float32)
         v[V_SCALE] = 1.0
         v[V_CA] = 1.0
         self.vec = v.to(eng.device)
@@ -204,7 +204,8 @@ class Engine:
         # ... of the folds whose partial rows are small: a deferred fold re-reads its slabs from HBM instead of the cache
         # they were just written through, which costs more than the launch it saves from ~12 MB on (Xception B=16 with
         # every fold deferred: 193.9 -> 196.4 ms)
-        self.fold_defer_bytes = int(os.environ.get("DL3_FOLD_DEFER_MB", "8")) << 20
+        self.fold_defer_bytes = int(float(os.environ.get("DL3_FOLD_DEFER_MB", "8")) * (1 << 20))
+        self.own_fold_ws_bytes = 0   # device memory of the deferred folds' own slab workspaces (reported by bench.py)
         self._folds = []
         # round 4: the weight-gradient launch of a BatchNorm'ed 1x1 convolution also writes dY = cA*g + cB*y + cC (it
         # assembles it anyway), and the bwd-data GEMM of the layer reads that ONE tensor (dl3_pwconv_bwd_weight_dy) — for
@@ -609,6 +610,18 @@ class Engine:
                     v.buf.vptr(V_SCALE, v.off), v.buf.vptr(V_SHIFT, v.off), v.buf.vptr(V_MEAN, v.off),
                     v.buf.vptr(V_INVSTD, v.off), self.wptr(n + "/moving_mean:0") if upd else None,
                     self.wptr(n + "/moving_variance:0") if upd else None)
+        elif isinstance(unit, PwUnit) and unit.bias is None and os.environ.get("DL3_BN_CENTER", "1") != "0":
+            # moving statistics, 1x1 convolution in front (round 4): the GEMM's free bias slot takes -mean, the tensor holds
+            # y - mean and consumers read scale*(y - mean) + beta — the reference's own gamma*(x - mean)/sqrt(var + eps) +
+            # beta instead of scale*y + (beta - mean*scale), whose shift carries half an ulp of |mean*scale| into every
+            # element (dl3_bn_frozen_centered)
+            negm = v.buf.vptr(V_NEGMEAN, v.off)
+            self.op(self.ops_prep, "dl3_bn_frozen_centered", self.wptr(n + "/gamma:0"), self.wptr(n + "/beta:0"),
+                    self.wptr(n + "/moving_mean:0"), self.wptr(n + "/moving_variance:0"), l.cfg["eps"], C,
+                    v.buf.vptr(V_SCALE, v.off), v.buf.vptr(V_SHIFT, v.off), v.buf.vptr(V_MEAN, v.off),
+                    v.buf.vptr(V_INVSTD, v.off), negm)
+            assert unit.fwd_rec[0] in ("dl3_pwconv_fwd", "dl3_pwconv_fwd_add") and unit.fwd_rec[2][6] is None
+            unit.fwd_rec[2][6] = negm
         else:
             self.op(self.ops_prep, "dl3_bn_frozen", self.wptr(n + "/gamma:0"), self.wptr(n + "/beta:0"),
                     self.wptr(n + "/moving_mean:0"), self.wptr(n + "/moving_variance:0"), l.cfg["eps"], C,
@@ -807,6 +820,10 @@ class Engine:
         self.fused_shuffle = None
         if (self.training and self.fused_tail is None and isinstance(last, ShuffleUnit) and last.outv.buf is v.buf
                 and os.environ.get("DL3_FUSE_SHUFFLE", "1") != "0"
+                # the fused kernel reads the Subpixel convolution's output as a plain contiguous tensor of co*r*r channels
+                # and writes that buffer's gradient itself: only with a single consumer and no view on top
+                and not last.inv.aff and last.inv.act == ACT_NONE and last.inv.off == 0
+                and last.inv.ld == last.co * last.r * last.r and last.inv.buf.expected == 1 and not last.inv.buf.bns
                 and self.lib.dl3_shuffle_xent_partials(self.B, last.inv.buf.H, last.inv.buf.W, last.co, last.r) > 0 and C <= 32):
             self.fused_shuffle = last
             self._shuffle_op = self.ops_fwd.pop()
@@ -1118,6 +1135,22 @@ class Engine:
                   torch.cuda.current_stream().cuda_stream)
         return float(tmp[0].item())
 
+    def sync_nnz(self, comm=None):
+        """external_nnz engines, before each step: the loss normaliser count_all(w != 0) / world of the resident sample
+        weights.  On the RCCL data plane nothing leaves the stream (device count, a one-float all-reduce, a scale — no
+        host round trip); on the gloo plane (functional tests) the count goes through the host."""
+        assert self.external_nnz
+        st = torch.cuda.current_stream().cuda_stream
+        M = self.logits_view.buf.M
+        if comm is not None and comm.comm is not None:
+            capi.call("dl3_count_nonzero", ptr(self.sweights), M, ptr(self.nnz), st)
+            capi.call("dl3_comm_allreduce_f32", comm.comm, ptr(self.nnz), ptr(self.nnz), 1, st)
+            capi.call("dl3_scale", ptr(self.nnz), 1.0 / comm.world, 1, st)
+        elif comm is not None and comm.world > 1:
+            self.set_nnz(comm.sum_over_ranks(self.count_nnz()) / comm.world)
+        else:
+            capi.call("dl3_count_nonzero", ptr(self.sweights), M, ptr(self.nnz), st)
+
     def set_nnz(self, value):
         """external_nnz engines: the normaliser the loss kernel divides by (global count / world, see train_step)"""
         assert self.external_nnz
@@ -1201,11 +1234,7 @@ class Engine:
         if self.external_nnz:
             # one loss over the global batch: L = sum_all(l*w) / count_all(w != 0).  Every rank divides by
             # count_all / world; the all-reduce sums the shard gradients and Adam applies 1/world
-            local = self.count_nnz()
-            if comm is not None and comm.world > 1:
-                self.set_nnz(comm.sum_over_ranks(local) / comm.world)
-            else:
-                self.set_nnz(local)
+            self.sync_nnz(comm)
         self.fwd_bwd()
         scale = 1.0
         if comm is not None:
@@ -1254,14 +1283,15 @@ class PwUnit(_ConvBase):
         s, t, a = inv.xform()
         w = eng.wptr(self.wname()) + 4 * self.wrow0 * self.N
         if img_add is None:
-            eng.op(eng.ops_fwd, "dl3_pwconv_fwd", inv.p(), inv.ld, s, t, a, w,
-                   eng.wptr(self.bias) if self.bias else None, outv.p(), outv.ld, self.M, self.K, self.N, ptr(self.stat))
+            self.fwd_rec = eng.op(eng.ops_fwd, "dl3_pwconv_fwd", inv.p(), inv.ld, s, t, a, w,
+                                  eng.wptr(self.bias) if self.bias else None, outv.p(), outv.ld, self.M, self.K, self.N,
+                                  ptr(self.stat))
         else:
             assert img_add.M == eng.B and img_add.ld == self.N and self.M % eng.B == 0
             eng._consume(View(img_add, 0, self.N))
-            eng.op(eng.ops_fwd, "dl3_pwconv_fwd_add", inv.p(), inv.ld, s, t, a, w,
-                   eng.wptr(self.bias) if self.bias else None, outv.p(), outv.ld, self.M, self.K, self.N, ptr(self.stat),
-                   ptr(img_add.t), self.N, self.M // eng.B)
+            self.fwd_rec = eng.op(eng.ops_fwd, "dl3_pwconv_fwd_add", inv.p(), inv.ld, s, t, a, w,
+                                  eng.wptr(self.bias) if self.bias else None, outv.p(), outv.ld, self.M, self.K, self.N,
+                                  ptr(self.stat), ptr(img_add.t), self.N, self.M // eng.B)
 
     def _bwd_img_add(self, g, ldg, y, ldy, cA, cB, cC):
         """gradient of the per-image addend: S[img, n] = sum over the image's pixels of dY[m, n], dY = cA*g + cB*y + cC
@@ -1303,6 +1333,7 @@ class PwUnit(_ConvBase):
             if eng.defer_fold(S, K * N) and not self.bias and eng.trainable(self.wname()):
                 # the launch leaves its [S][K][N] slabs in a workspace of its own; folded at the end of the pass
                 own = eng.empty(ws // 4 + 4)
+                eng.own_fold_ws_bytes += ws + 16
                 eng.op_side(eng.ops_bwd, fn, inv.p(), inv.ld, s, t, a, g, ldg, y, ldy, cA, cB, cC,
                             None, None, M, K, N, ptr(own), ws, *tail)
                 eng.fold(ptr(own), S, K * N, eng.gptr(self.wname()) + 4 * self.wrow0 * N)

@@ -572,7 +572,10 @@ class Model:
 
     def train_on_batch(self, x, y, sample_weight=None, **engine_kw):
         dp = self._dp
-        if dp is not None and dp.world > 1:
+        # the data-parallel step also runs for a communicator of ONE rank (dp.comm set): every launch of the N-rank step —
+        # the one-float count all-reduce in front of the hipGraph replay, the arena all-reduce behind it — on one GPU
+        multi = dp is not None and (dp.world > 1 or dp.comm is not None)
+        if multi:
             n = x.shape[0]
             if n < dp.world:
                 raise ValueError("global batch of %d images cannot be split over %d ranks" % (n, dp.world))
@@ -585,7 +588,7 @@ class Model:
             engine_kw = dict(engine_kw, external_nnz=True)
         eng = self._engine(x.shape[0], True, **engine_kw)
         opt = (self._compiled or {}).get("optimizer") or {}
-        if dp is None or dp.world == 1:
+        if not multi:
             return eng.train_step(x, y, sample_weight, opt)
         if not self._dp_synced:  # identical weights and moving statistics on every rank before the first step
             dp.broadcast(eng.params)

@@ -75,6 +75,20 @@ class DataParallel:
                       % (L.dl3_last_error().decode() if rc else "this rank was fine"))
         self.backend = "gloo"
 
+    def attach_single_rank_rccl(self):
+        """world of one only: bring up an RCCL communicator of ONE rank on the current device, so that the data-parallel
+        step (count all-reduce, hipGraph replay, arena all-reduce, Adam with 1/world) runs launch for launch as it does on
+        N GPUs.  What a one-GPU box can check of the N-GPU path (tests/test_gpu_parallel.py)."""
+        assert self.world == 1 and self.comm is None
+        from . import capi
+        L = capi.lib()
+        raw = ctypes.create_string_buffer(128)
+        capi.check(L.dl3_comm_unique_id(raw), "dl3_comm_unique_id")
+        handle = ctypes.c_void_p()
+        capi.check(L.dl3_comm_init(ctypes.byref(handle), raw.raw, 0, 1), "dl3_comm_init")
+        self.comm, self.backend = handle, "rccl"
+        return self
+
     def rccl_ranks(self):
         """number of ranks RCCL itself reports for the data-plane communicator (None when the data plane is not RCCL)"""
         if self.comm is None:
@@ -93,12 +107,12 @@ class DataParallel:
 
     def allreduce_grads(self, flat):
         """sum the flat gradient arena over ranks in place; returns the scale the optimizer must apply"""
-        if self.world > 1:
-            if self.comm is not None:
-                from . import capi
-                capi.call("dl3_comm_allreduce_f32", self.comm, flat.data_ptr(), flat.data_ptr(), flat.numel(),
-                          torch.cuda.current_stream().cuda_stream)
-            elif flat.is_cuda:
+        if self.comm is not None:   # (also a communicator of one rank: the launch is the same, the sum an identity)
+            from . import capi
+            capi.call("dl3_comm_allreduce_f32", self.comm, flat.data_ptr(), flat.data_ptr(), flat.numel(),
+                      torch.cuda.current_stream().cuda_stream)
+        elif self.world > 1:
+            if flat.is_cuda:
                 h = flat.cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.SUM)
                 flat.copy_(h)
@@ -108,12 +122,12 @@ class DataParallel:
 
     def broadcast(self, flat, src=0):
         """identical initial weights / Adam state on every rank"""
-        if self.world > 1:
-            if self.comm is not None:
-                from . import capi
-                capi.call("dl3_comm_broadcast_f32", self.comm, flat.data_ptr(), flat.numel(), src,
-                          torch.cuda.current_stream().cuda_stream)
-            elif flat.is_cuda:
+        if self.comm is not None:
+            from . import capi
+            capi.call("dl3_comm_broadcast_f32", self.comm, flat.data_ptr(), flat.numel(), src,
+                      torch.cuda.current_stream().cuda_stream)
+        elif self.world > 1:
+            if flat.is_cuda:
                 h = flat.cpu()
                 dist.broadcast(h, src=src)
                 flat.copy_(h)

@@ -106,25 +106,39 @@ CRF_PARAMS = dict(gt_prob=0.7, gaussian_sxy=(3, 3), gaussian_compat=3, bilateral
                   bilateral_compat=10, iterations=5)
 
 
+def restore_crf_labels(MAP, colors):
+    """MAP indices -> the mask's original values, exactly as the reference does it (utils.py:86-89): for every index u
+    present in MAP, ascending, `np.putmask(MAP, MAP == u, colors[u])` IN PLACE.  The quirk is reproduced, not fixed
+    (SURVEY G5): a value written for an earlier index is matched again by a later one — with mask values {0, 2, 15} index
+    1 becomes 2 and is then rewritten to 15 together with index 2, so class 2 vanishes from the result.  Masks whose
+    values are 0..n-1 (the usual label maps) come back unchanged."""
+    for u in np.unique(MAP):
+        np.putmask(MAP, MAP == u, colors[u])
+    return MAP
+
+
 def do_crf(im, mask, zero_unsure=True):
     """Fully connected CRF refinement of a label mask given the image (reference utils.py:74-91): unary energies from
     the labels with CRF_PARAMS['gt_prob'], a Gaussian (position) and a bilateral (position + colour) pairwise term,
-    five mean-field iterations, MAP labels mapped back to the mask's original values."""
+    five mean-field iterations, MAP labels mapped back to the mask's original values by the reference's own in-place
+    loop (restore_crf_labels)."""
     try:
         import pydensecrf.densecrf as dcrf
         from pydensecrf.utils import unary_from_labels
     except ImportError as e:  # pragma: no cover - optional host dependency
         raise ImportError("do_crf needs the optional host package pydensecrf (not installed)") from e
-    values, labels = np.unique(mask, return_inverse=True)
-    h, w = mask.shape[:2]
-    n = len(values)
-    crf = dcrf.DenseCRF2D(w, h, n)
-    crf.setUnaryEnergy(unary_from_labels(labels, n, gt_prob=CRF_PARAMS["gt_prob"], zero_unsure=zero_unsure))
+    colors, labels = np.unique(mask, return_inverse=True)
+    labels = labels.reshape(-1)  # numpy 1.x (the reference's) returns the inverse flat; numpy >= 2 in the mask's shape
+    image_size = mask.shape[:2]
+    n_labels = len(set(labels.flat))
+    crf = dcrf.DenseCRF2D(image_size[1], image_size[0], n_labels)  # width, height, nlabels
+    crf.setUnaryEnergy(unary_from_labels(labels, n_labels, gt_prob=CRF_PARAMS["gt_prob"], zero_unsure=zero_unsure))
     crf.addPairwiseGaussian(sxy=CRF_PARAMS["gaussian_sxy"], compat=CRF_PARAMS["gaussian_compat"])
     crf.addPairwiseBilateral(sxy=CRF_PARAMS["bilateral_sxy"], srgb=CRF_PARAMS["bilateral_srgb"],
-                             rgbim=np.ascontiguousarray(im, dtype=np.uint8), compat=CRF_PARAMS["bilateral_compat"])
-    q = np.asarray(crf.inference(CRF_PARAMS["iterations"]))
-    return values[np.argmax(q, axis=0)].reshape(h, w)
+                             rgbim=np.ascontiguousarray(im.astype("uint8")), compat=CRF_PARAMS["bilateral_compat"])
+    q = crf.inference(CRF_PARAMS["iterations"])
+    MAP = np.argmax(q, axis=0).reshape(image_size)
+    return restore_crf_labels(MAP, colors)
 
 
 class SegmentationGenerator:

@@ -314,8 +314,10 @@ def loss_sparse_xent_ignoring_last_label(logits, labels, weights):
     [TF-semantics] Keras categorical_crossentropy on probabilities: p /= sum(p); clip(p,1e-7,1-1e-7);
     l = -sum(y*log p); weighted: score = l*w; score /= mean(w != 0); loss = mean(score)
       => loss = sum(l*w)/count(w != 0).
-    Returns (loss, dlogits) with dlogits = (p - onehot)*w/nnz (clip ignored, as TF's gradient of
-    softmax+log away from the clip).  A void row (label == C) has an all-zero one-hot row (utils.py:129 drops the last
+    Returns (loss, dlogits) with dlogits = (p - onehot)*w/nnz where the true-class probability lies inside the clip
+    interval [1e-7, 1-1e-7] and ZERO where it does not: [TF-semantics] the gradient of tf.clip_by_value is zero outside
+    its bounds, so such a pixel's loss is a constant (round 4; before, the clip was ignored in the gradient — identical
+    unless a probability has left the interval, i.e. a logit gap above ~16).  A void row (label == C) has an all-zero one-hot row (utils.py:129 drops the last
     column), so it contributes neither loss nor gradient — whatever its sample weight; a non-zero weight there still
     counts in nnz, exactly as Keras' mean(w != 0) does."""
     C = logits.shape[-1]
@@ -326,11 +328,13 @@ def loss_sparse_xent_ignoring_last_label(logits, labels, weights):
     bi, pi = np.nonzero(valid)
     onehot[bi, pi, t[bi, pi]] = 1
     q = p / p.sum(axis=-1, keepdims=True)
+    qt = (onehot * q).sum(axis=-1)
+    inside = (qt >= 1e-7) & (qt <= 1 - 1e-7)  # clip_by_value passes the gradient here (bounds included) and only here
     q = np.clip(q, 1e-7, 1 - 1e-7)
     l = -(onehot * np.log(q)).sum(axis=-1)
     nnz = max(float((weights != 0).sum()), 1.0)
     loss = float((l * weights).sum(dtype=np.float64) / nnz)
-    dlogits = (p - onehot) * (weights * valid / p.dtype.type(nnz))[..., None]
+    dlogits = (p - onehot) * (weights * (valid & inside) / p.dtype.type(nnz))[..., None]
     return loss, dlogits.astype(logits.dtype), p
 
 
@@ -579,6 +583,60 @@ def train_grads(params, x, labels, weights, **kw):
             g = None if g is None else g[..., None]
         out[name] = g
     return loss, out, logits, net
+
+
+# --------------------------------------------------------------------------------------
+# the optimizer of the reference's training cell: Adam(lr=7e-4, epsilon=1e-8, decay=1e-6)
+# (segmentation.ipynb cell 2, json line 107) as Keras 2.2.4 keras/optimizers.py Adam.get_updates states it
+# --------------------------------------------------------------------------------------
+ADAM_DEFAULTS = dict(lr=7e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-8, decay=1e-6)
+
+
+def adam_update(p, g, m, v, iterations, lr=7e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-8, decay=1e-6):
+    """One Keras 2.2.4 Adam update of one weight [TF-semantics, Adam.get_updates]:
+        lr   = lr * 1 / (1 + decay * iterations)          (only when decay > 0; `iterations` BEFORE its increment)
+        t    = iterations + 1
+        lr_t = lr * sqrt(1 - beta_2^t) / (1 - beta_1^t)
+        m_t  = beta_1 * m + (1 - beta_1) * g ;  v_t = beta_2 * v + (1 - beta_2) * g^2
+        p_t  = p - lr_t * m_t / (sqrt(v_t) + epsilon)      (epsilon OUTSIDE the root, no m_hat / v_hat division)
+    Returns (p_t, m_t, v_t)."""
+    if decay > 0:
+        lr = lr * (1.0 / (1.0 + decay * iterations))
+    t = iterations + 1
+    lr_t = lr * (np.sqrt(1.0 - beta_2 ** t) / (1.0 - beta_1 ** t))
+    m_t = beta_1 * m + (1.0 - beta_1) * g
+    v_t = beta_2 * v + (1.0 - beta_2) * np.square(g)
+    return p - lr_t * m_t / (np.sqrt(v_t) + epsilon), m_t, v_t
+
+
+def train_steps(params, batches, opt=None, frozen=(), **kw):
+    """len(batches) x Model.train_on_batch (notebook json 107,160: fit_generator -> train_on_batch): forward in the
+    training phase, loss, gradients, one Adam update of every trainable weight, the BatchNorm moving-statistics update.
+    batches: [(x, labels, weights), ...]; frozen: weight names that do not train (layer.trainable = False, notebook json
+    147-155); kw as for train_grads (bn_frozen=True: BatchNorm normalises with the moving statistics, which then stay).
+    Returns (losses, params after the last step, {name: (m, v)})."""
+    o = dict(ADAM_DEFAULTS)
+    o.update(opt or {})
+    p = dict(params)
+    state = {}
+    losses = []
+    for it, (x, y, w) in enumerate(batches):
+        loss, grads, _, net = train_grads(p, x, y, w, **kw)
+        losses.append(float(loss))
+        new = dict(p)
+        for name, g in grads.items():
+            if g is None or name in frozen or name.split("/")[-1].startswith("moving"):
+                continue
+            m, v = state.get(name, (np.zeros_like(p[name]), np.zeros_like(p[name])))
+            new[name], m, v = adam_update(p[name], g.reshape(p[name].shape), m, v, it, **o)
+            state[name] = (m, v)
+        for bn, st in net.new_stats.items():
+            if (bn + "/gamma:0") in frozen:   # Keras 2.2.x collects no updates from a non-trainable layer
+                continue
+            new[bn + "/moving_mean:0"] = st["mean"]
+            new[bn + "/moving_variance:0"] = st["var"]
+        p = new
+    return losses, p, state
 
 
 # --------------------------------------------------------------------------------------

@@ -87,6 +87,7 @@ class Ref:
         self.bn_frozen = bn_frozen
         self.dtype = dtype
         self.batch_stats = {}  # BN layer name -> (batch mean, biased batch variance) of the last training forward
+        self.bn_meta = {}      # BN layer name -> (epsilon, values per channel) of that forward
 
     # x is NCHW throughout
     def conv(self, x, name, k=1, stride=1, same=True, bias=False):
@@ -118,6 +119,7 @@ class Ref:
         if self.training and not self.bn_frozen:
             with torch.no_grad():
                 self.batch_stats[name] = (x.mean(dim=(0, 2, 3)).numpy(), x.var(dim=(0, 2, 3), unbiased=False).numpy())
+                self.bn_meta[name] = (eps, x.shape[0] * x.shape[2] * x.shape[3])
             return F.batch_norm(x, None, None, g, b, True, 0.0, eps)
         return F.batch_norm(x, mm, mv, g, b, False, 0.0, eps)
 
@@ -232,8 +234,8 @@ class Ref:
         onehot = F.one_hot(t, C + 1)[..., :C].to(self.dtype)  # utils.py:129
         p = torch.softmax(lg, dim=-1)
         q = p / p.sum(dim=-1, keepdim=True)
-        # the clip is applied to the VALUE only, so that (like the oracle) its gradient is (p-y)w/nnz
-        q = q + (q.clamp(1e-7, 1 - 1e-7) - q).detach()
+        # tf.clip_by_value: identity gradient inside [1e-7, 1-1e-7] (bounds included), zero outside — torch.clamp's own
+        q = q.clamp(1e-7, 1 - 1e-7)
         l = -(onehot * torch.log(q)).sum(dim=-1)
         nnz = max(float((w != 0).sum()), 1.0)
         return (l * w).sum() / nnz
@@ -264,3 +266,49 @@ def calibrate_bn(params, x, dtype=torch.float64, **kw):
         out[name + "/moving_mean:0"] = m.astype(np.float32)
         out[name + "/moving_variance:0"] = v.astype(np.float32)
     return out
+
+
+def _bn_momentum(name):
+    """BatchNormalization momentum by layer: 0.999 where the reference passes it (the MobileNetV2 backbone,
+    deeplabv3p.py:178,189,197,322-323), the Keras default 0.99 everywhere else"""
+    return 0.999 if (name == "Conv_BN" or name.startswith("expanded_conv")) else 0.99
+
+
+def train_steps(params, batches, opt=None, bn_frozen=False, dtype=torch.float64, **kw):
+    """Independent restatement of k x train_on_batch with the notebook's optimizer (segmentation.ipynb json 107:
+    Adam(lr=7e-4, epsilon=1e-8, decay=1e-6); Keras 2.2.4 Adam.get_updates) for tests/: torch autograd gradients, the
+    Adam arithmetic on torch tensors, the Keras 2.2.4 / TF 1.13 moving-statistics update (Bessel x n/(n-(1+eps))).
+    Shares no code with oracle/dl3_oracle.py.  Returns (losses, params after the last step)."""
+    o = dict(lr=7e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-8, decay=1e-6)
+    o.update(opt or {})
+    p = {k: np.asarray(v) for k, v in params.items()}
+    mom1, mom2, losses = {}, {}, []
+    for it, (x, y, w) in enumerate(batches):
+        ref = Ref(p, True, None, bn_frozen, dtype)
+        loss = ref.loss(ref.logits(x, **kw), y, w)
+        loss.backward()
+        losses.append(float(loss.detach()))
+        lr = o["lr"] / (1.0 + o["decay"] * it) if o["decay"] > 0 else o["lr"]
+        t = it + 1
+        lr_t = lr * math.sqrt(1.0 - o["beta_2"] ** t) / (1.0 - o["beta_1"] ** t)
+        new = dict(p)
+        with torch.no_grad():
+            for name, wt in ref.t.items():
+                if wt.grad is None:
+                    continue
+                m = mom1.get(name, torch.zeros_like(wt))
+                v = mom2.get(name, torch.zeros_like(wt))
+                m = o["beta_1"] * m + (1.0 - o["beta_1"]) * wt.grad
+                v = o["beta_2"] * v + (1.0 - o["beta_2"]) * wt.grad * wt.grad
+                mom1[name], mom2[name] = m, v
+                new[name] = (wt - lr_t * m / (torch.sqrt(v) + o["epsilon"])).numpy()
+        for name, (bm, bv) in ref.batch_stats.items():
+            eps, n = ref.bn_meta[name]
+            unb = bv * (n / (n - 1.0)) if n > 1 else bv
+            if n > 1.0 + eps:
+                unb = unb * (n / (n - (1.0 + eps)))
+            mo = _bn_momentum(name)
+            new[name + "/moving_mean:0"] = mo * p[name + "/moving_mean:0"] + (1.0 - mo) * bm
+            new[name + "/moving_variance:0"] = mo * p[name + "/moving_variance:0"] + (1.0 - mo) * unb
+        p = new
+    return losses, p

@@ -841,6 +841,11 @@ def test_softmax_argmax_xent(L, C, void_w):
     M = 5000
     x = rng.normal(0, 3, (M, C)).astype(np.float32)
     labels = rng.integers(0, C + 1, M).astype(np.float32)
+    # rows whose true-class probability has left Keras' clip interval [1e-7, 1 - 1e-7] on either side: the loss is the
+    # constant -log(bound) and tf.clip_by_value hands NO gradient to the logits (round 4)
+    for i in range(20):
+        labels[i] = i % C
+        x[i, i % C] = x[i].max() + 40.0 if i >= 10 else x[i].min() - 40.0
     w = _sample_weights(rng, labels, C, void_w)
     p = empty(M, C)
     call("dl3_softmax_fwd", ptr(dev(x)), ptr(p), M, C)
@@ -857,6 +862,7 @@ def test_softmax_argmax_xent(L, C, void_w):
     dl, lp, probs = empty(M, C), empty(P), empty(M, C)
     call("dl3_softmax_xent", ptr(dev(x)), ptr(dev(labels)), ptr(dev(w)), ptr(nnz), ptr(probs), ptr(dl), ptr(lp), M, C)
     assert relerr(host(dl), dl_ref[0]) < 1e-5
+    assert np.all(host(dl)[:20] == 0) and np.all(dl_ref[0][:20] == 0)
     assert abs(host(lp).astype(np.float64).sum() - loss_ref) < 1e-5 * abs(loss_ref)
     assert relerr(host(probs), p_ref[0]) < 1e-5
 

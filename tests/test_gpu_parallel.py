@@ -225,3 +225,49 @@ def test_bench_self_spawns_its_ranks():
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     res = subprocess.run(cmd, env=env2, capture_output=True, text=True, timeout=300)
     assert res.returncode != 0 and "WORLD_SIZE" in res.stderr
+
+
+def test_data_parallel_step_with_a_one_rank_rccl_communicator_under_hipgraph():
+    """the N-GPU train_on_batch launch for launch on ONE GPU — Model.distribute() with an RCCL
+    communicator of one rank: device count of the sample weights, a one-float ncclAllReduce and a scale IN FRONT of the
+    captured backward hipGraph, the gradient arena's ncclAllReduce BEHIND its replay, Adam with 1/world — on one stream,
+    eager (step 1), capturing (step 2) and replaying (steps 3-4).  A sum over one rank is the identity, so weights and
+    losses must equal the plain single-process run bit for bit."""
+    import dl3_amd  # noqa: F401
+    from dl3_amd.parallel import DataParallel
+    from oracle import dl3_oracle as O
+    from tests.test_gpu_model import _build, _load
+    assert int(os.environ.get("WORLD_SIZE", "1")) == 1
+    shape, classes, B = (96, 96, 3), 4, 3
+    rng = np.random.default_rng(3)
+    batches = []
+    for _ in range(4):
+        x = rng.integers(0, 256, (B,) + shape).astype(np.float32)
+        y = rng.integers(0, classes + 1, (B, shape[0] * shape[1], 1)).astype(np.float32)
+        sw = ((y[..., 0] < classes) * rng.uniform(0.5, 2.0, y.shape[:2])).astype(np.float32)
+        batches.append((x, y, sw))
+
+    def run(distributed):
+        model, params = _build("mobilenetv2", shape, classes, "deeplab")
+        _load(model, params)
+        dp = None
+        if distributed:
+            dp = DataParallel().attach_single_rank_rccl()
+            assert dp.rccl_ranks() == 1
+            model.distribute(dp)
+        losses = [model.train_on_batch(x, y, sw, dropout=False) for x, y, sw in batches]
+        eng = model._active
+        assert eng.graph is not None, "the step was never captured"
+        assert eng.external_nnz == distributed
+        torch.cuda.synchronize()
+        w = eng.params.cpu().numpy().copy()
+        st = eng.state.cpu().numpy().copy()
+        if dp is not None:
+            dp.close()
+        return losses, w, st
+
+    la, wa, sa = run(False)
+    lb, wb, sb = run(True)
+    assert la == lb, (la, lb)
+    assert np.array_equal(wa, wb) and np.array_equal(sa, sb)
+    assert len(set(la)) == 4

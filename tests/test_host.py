@@ -244,6 +244,78 @@ def test_crf_hook_parameters():
             U.do_crf(np.zeros((8, 8, 3), np.uint8), np.zeros((8, 8), np.int32))
 
 
+def test_crf_label_restore_reproduces_the_reference_loop():
+    """utils.py:86-89 maps MAP indices back with an in-place np.putmask loop over ascending indices; a value written for
+    an earlier index is matched again by a later one.  SURVEY G5: reproduce, do not fix (VERDICT r3 weak #5)."""
+    from dl3_amd import utils as U
+    colors = np.array([0, 2, 15])
+    MAP = np.array([[0, 1, 2], [1, 1, 0], [2, 0, 1]])
+    got = U.restore_crf_labels(MAP.copy(), colors)
+    # index 1 -> 2, then every 2 (old index 2 AND the freshly written ones) -> 15: class 2 vanishes
+    assert np.array_equal(got, np.array([[0, 15, 15], [15, 15, 0], [15, 0, 15]]))
+    # contiguous label values 0..n-1 come back unchanged, and so do values that never collide with a later index
+    assert np.array_equal(U.restore_crf_labels(MAP.copy(), np.array([0, 1, 2])), MAP)
+    assert np.array_equal(U.restore_crf_labels(MAP.copy(), np.array([7, 9, 30])), np.array([7, 9, 30])[MAP])
+    # an index absent from MAP is never touched: colors {0, 2, 15} with no pixel of index 1 keep class 2's pixels ... gone too
+    assert np.array_equal(U.restore_crf_labels(np.array([0, 2, 2]), colors), np.array([0, 15, 15]))
+
+
+def test_crf_hook_runs_against_a_recording_pydensecrf(monkeypatch):
+    """N4 executed: do_crf driven end to end against a stand-in `pydensecrf` that records every call (the real package
+    is not installable offline).  Checks the call sequence, argument values and shapes the reference issues
+    (utils.py:74-91: DenseCRF2D(width, height, n), unary_from_labels(labels, n, gt_prob=.7, zero_unsure), Gaussian sxy
+    (3,3) compat 3, bilateral sxy 80 srgb 13 compat 10 on the uint8 image, 5 iterations) and the label restore."""
+    import sys
+    import types
+    from dl3_amd import utils as U
+    calls = []
+
+    class DenseCRF2D:
+        def __init__(self, w, h, n):
+            calls.append(("init", w, h, n))
+            self.n, self.hw = n, h * w
+
+        def setUnaryEnergy(self, u):
+            calls.append(("unary", u.shape, u.dtype))
+            self.u = u
+
+        def addPairwiseGaussian(self, sxy, compat):
+            calls.append(("gaussian", sxy, compat))
+
+        def addPairwiseBilateral(self, sxy, srgb, rgbim, compat):
+            calls.append(("bilateral", sxy, srgb, rgbim.dtype, rgbim.shape, rgbim.flags["C_CONTIGUOUS"], compat))
+
+        def inference(self, it):
+            calls.append(("inference", it))
+            return np.exp(-self.u)  # the unary alone: MAP = the input labels
+
+    def unary_from_labels(labels, n, gt_prob, zero_unsure):
+        calls.append(("unary_from_labels", labels.shape, n, gt_prob, zero_unsure))
+        u = np.full((n, labels.size), -np.log((1.0 - gt_prob) / (n - 1)), np.float32)
+        u[labels.reshape(-1), np.arange(labels.size)] = -np.log(gt_prob)
+        return u
+
+    pkg, dm, um = types.ModuleType("pydensecrf"), types.ModuleType("pydensecrf.densecrf"), types.ModuleType("pydensecrf.utils")
+    dm.DenseCRF2D, um.unary_from_labels = DenseCRF2D, unary_from_labels
+    pkg.densecrf, pkg.utils = dm, um
+    for k, v in (("pydensecrf", pkg), ("pydensecrf.densecrf", dm), ("pydensecrf.utils", um)):
+        monkeypatch.setitem(sys.modules, k, v)
+    rng = np.random.default_rng(0)
+    im = rng.integers(0, 256, (6, 9, 3)).astype(np.float32)
+    mask = rng.integers(0, 3, (6, 9)).astype(np.int32)
+    out = U.do_crf(im, mask, zero_unsure=False)
+    assert calls[0] == ("init", 9, 6, 3)
+    assert calls[1] == ("unary_from_labels", (54,), 3, 0.7, False)
+    assert calls[2][0] == "unary" and calls[2][1] == (3, 54)
+    assert calls[3] == ("gaussian", (3, 3), 3)
+    assert calls[4] == ("bilateral", 80, 13, np.dtype("uint8"), (6, 9, 3), True, 10)
+    assert calls[5] == ("inference", 5)
+    assert out.shape == (6, 9) and np.array_equal(out, mask)
+    # non-contiguous original values go through the reference's in-place restore (class 2 -> 15 together with index 2)
+    out2 = U.do_crf(im, np.array([0, 2, 15])[mask], zero_unsure=True)
+    assert np.array_equal(out2, np.array([0, 15, 15])[mask])
+
+
 def test_stored_channel_plan():
     """engine.plan_channels: Xception's 728-channel tensors are stored 736 wide (whole 128-byte lines per pixel row),
     nothing else changes; device weight shapes follow; the slices of a Concatenate keep their logical widths"""

@@ -135,6 +135,33 @@ def test_batchnorm_and_loss_semantics():
     assert abs(O.loss_sparse_xent_ignoring_last_label(lp, labels, w2)[0] - loss2) < 1e-15
 
 
+def test_loss_clip_gradient_is_tf_clip_by_value():
+    """Keras categorical_crossentropy clips the probability with tf.clip_by_value before the log: outside [1e-7, 1-1e-7]
+    the loss is the constant -log(bound) and the gradient is zero; inside it is (p - onehot) w / nnz"""
+    logits = np.array([[[0.0, 30.0, 0.0],     # true class 0: p = e^-30 < 1e-7 -> clipped from below
+                        [30.0, 0.0, 0.0],     # true class 0: p > 1 - 1e-7   -> clipped from above
+                        [1.0, 2.0, 0.5]]])    # ordinary pixel
+    labels = np.array([[0.0, 0.0, 2.0]])
+    w = np.array([[1.0, 2.0, 1.0]])
+    loss, dl, p = O.loss_sparse_xent_ignoring_last_label(logits, labels, w)
+    assert np.all(dl[0, 0] == 0) and np.all(dl[0, 1] == 0)
+    assert np.allclose(dl[0, 2], (p[0, 2] - np.array([0, 0, 1.0])) / 3)
+    assert abs(loss - (-np.log(1e-7) - 2 * np.log(1 - 1e-7) - np.log(p[0, 2, 2])) / 3) < 1e-12
+    # finite differences see the same: the clipped pixels do not move the loss
+    lp = logits.copy()
+    lp[0, 0, 0] += 1e-3
+    lp[0, 1, 1] += 1e-3
+    assert O.loss_sparse_xent_ignoring_last_label(lp, labels, w)[0] == loss
+    # ... and so does the independent torch restatement (torch.clamp has clip_by_value's gradient)
+    from oracle import torch_ref as T
+    import torch
+    ref = T.Ref({}, True, dtype=torch.float64)
+    lt = torch.tensor(logits.reshape(1, 1, 3, 3), requires_grad=True)
+    lv = ref.loss(lt, labels, w)
+    lv.backward()
+    assert abs(float(lv) - loss) < 1e-12 and np.allclose(lt.grad.numpy().reshape(1, 3, 3), dl, atol=1e-15)
+
+
 def test_param_counts():
     n = lambda **k: sum(int(np.prod(s)) for s in O.param_shapes(**k).values())
     assert n(backbone="mobilenetv2", classes=2) == 2141762
@@ -294,3 +321,58 @@ def test_c_operators_agree_with_numpy_operators(backbone, OS, head):
     with CB.installed(threads=4):
         l2, g2, lg2, _ = O.train_grads(p32, x.astype(np.float32), labels.astype(np.float32), w.astype(np.float32), **kw)
     assert lg2.dtype == np.float32 and abs(l2 - l0) < 1e-4 * abs(l0) and np.abs(lg2 - lg0).max() < 1e-3 * np.abs(lg0).max()
+
+
+def test_adam_update_known_answers():
+    """Keras 2.2.4 Adam.get_updates (notebook json 107: Adam(lr=7e-4, epsilon=1e-8, decay=1e-6)): hand-computed steps"""
+    p, g = np.array([1.0, -2.0, 0.5]), np.array([0.1, -0.2, 0.0])
+    z = np.zeros(3)
+    # first step (iterations = 0): no decay yet, lr_t = lr*sqrt(1-b2)/(1-b1); m = (1-b1) g, v = (1-b2) g^2
+    p1, m1, v1 = O.adam_update(p, g, z, z, 0, lr=1e-2, beta_1=0.9, beta_2=0.999, epsilon=1e-8, decay=1e-3)
+    lr_t = 1e-2 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    assert np.allclose(m1, 0.1 * g, rtol=1e-15) and np.allclose(v1, 0.001 * g * g, rtol=1e-12)
+    assert np.allclose(p1, p - lr_t * (0.1 * g) / (np.sqrt(0.001) * np.abs(g) + 1e-8), rtol=1e-14)
+    # |update| of a weight with a non-negligible gradient is ~lr in the first step, whatever the gradient's size
+    assert np.allclose(np.abs(p1 - p)[:2], 1e-2, rtol=1e-5) and p1[2] == p[2]
+    # second step: `iterations` = 1 enters the decay BEFORE its increment, t = 2
+    p2, m2, v2 = O.adam_update(p1, g, m1, v1, 1, lr=1e-2, beta_1=0.9, beta_2=0.999, epsilon=1e-8, decay=1e-3)
+    lr2 = 1e-2 / (1 + 1e-3 * 1) * np.sqrt(1 - 0.999 ** 2) / (1 - 0.9 ** 2)
+    assert np.allclose(m2, 0.19 * g, rtol=1e-14) and np.allclose(v2, (0.999 * 0.001 + 0.001) * g * g, rtol=1e-12)
+    assert np.allclose(p2, p1 - lr2 * m2 / (np.sqrt(v2) + 1e-8), rtol=1e-14)
+    # decay = 0 leaves lr alone (Keras tests `initial_decay > 0`)
+    p3, _, _ = O.adam_update(p, g, z, z, 7, lr=1e-2, decay=0.0)
+    t = 8
+    assert np.allclose(p3, p - 1e-2 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * (0.1 * g) / (np.sqrt(0.001 * g * g) + 1e-8))
+
+
+@pytest.mark.parametrize("bn_frozen", [False, True])
+def test_three_training_steps_two_restatements_agree(bn_frozen):
+    """3 x train_on_batch (forward, loss, backward, Adam with decay, BatchNorm moving statistics): the numpy oracle and
+    the torch restatement — which share no code — land on the same weights in float64"""
+    from oracle import torch_ref as T
+    kw = dict(backbone="mobilenetv2", input_shape=(32, 32, 3), classes=3, OS=16)
+    params = O.init_params(O.param_shapes("mobilenetv2", 3), seed=3)
+    rng = np.random.default_rng(5)
+    x0 = rng.integers(0, 256, (3, 32, 32, 3)).astype(np.float64)
+    params = {k: v.astype(np.float64) for k, v in O.calibrate_bn(params, x0, **kw).items()}
+    batches = []
+    for _ in range(3):
+        x = rng.integers(0, 256, (3, 32, 32, 3)).astype(np.float64)
+        y = rng.integers(0, 4, (3, 32 * 32)).astype(np.float64)
+        w = ((y < 3) * rng.uniform(0.5, 2.0, y.shape)).astype(np.float64)
+        batches.append((x, y, w))
+    la, pa, _ = O.train_steps(params, batches, bn_frozen=bn_frozen, **kw)
+    lb, pb = T.train_steps(params, batches, bn_frozen=bn_frozen, **kw)
+    assert np.allclose(la, lb, rtol=1e-9)
+    assert la[0] != la[1] != la[2]
+    moved = 0
+    for name, a in pa.items():
+        b = np.asarray(pb[name]).reshape(a.shape)
+        d0 = np.abs(a - params[name]).max()
+        if name.split("/")[-1].startswith("moving"):
+            assert (d0 == 0) == bn_frozen, name
+        # Adam normalises the update: a gradient that is analytically zero (image_pooling/kernel in batch mode with 3
+        # values per channel is NOT; nothing here is) would turn rounding noise into +-lr steps — none present
+        assert np.abs(a - b).max() <= 1e-7 * max(np.abs(a).max(), 1e-3) + 2e-6 * d0, (name, np.abs(a - b).max(), d0)
+        moved += d0 > 0
+    assert moved > 100
