@@ -60,9 +60,6 @@ constexpr int BK = 16;
 #ifndef DL3_STREAM_KT_FWD
 #define DL3_STREAM_KT_FWD 16  // K-tile depth of the forward instantiation (32 measured in round 2: see DESIGN.md)
 #endif
-#ifndef DL3_STREAM_KT_MSK
-#define DL3_STREAM_KT_MSK 16  // K-tile depth of the single-tensor masked bwd-data instantiation (EPI 3)
-#endif
 #ifndef DL3_WGRAD_WGS_DEFAULT
 #define DL3_WGRAD_WGS_DEFAULT 1024
 #endif
@@ -471,14 +468,10 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
   // loop's own; 80 + 80 do not (nor 48 + 96 with a residual operand: measured, spills between the loads).
   constexpr bool PRE = (EPI == 2);
   static_assert(!PRE || (TM == 1 && WN == 1 && TN <= 3), "prefetched epilogue: narrow single-row-block tiles only");
-  // EPI 3 (round 4; single-tensor bwd-data: dY was materialised by the weight-gradient launch, dl3_pwconv_bwd_weight_dy):
-  // interior tiles take the straight-line MASKED epilogue (forward input for the activation mask and x_hat, optional
-  // residual gradient, BatchNorm-backward sums).  Without the second operand tensor and its coefficient registers the
-  // kernel has the room the two-tensor attempts of rounds 2 and 3 did not (912 B of scratch there).
-  // EPI 3: no residual operand; EPI 4: with one (two kernels instead of two code paths in one: each extra epilogue form
-  // costs registers across the whole kernel)
-  constexpr bool MSK = (EPI == 3 || EPI == 4);
-  static_assert(!MSK || !TWO, "straight-line masked epilogue: single-tensor operand only");
+  // (EPI 3 / 4, round 4: a straight-line MASKED epilogue for the single-tensor bwd-data launches — forward input for the
+  // mask and x_hat, optional residual, BatchNorm-backward sums; 0-260 B of scratch once the epilogue addresses were
+  // fenced — measured no faster than the generic epilogue below: bwd-data GEMMs 25.95 ms per step with it, 25.81 without
+  // (B=128, same call, profiles/r04_ab_dy_epilogue.txt); removed again)
   // KT = depth of one K-tile: each half-wave walks KT/2 consecutive k (KT/8 float4 loads per lane and tensor)
   constexpr int WM = 4 / WN;
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, KH = KT / 2, NJ = KT / 8;
@@ -759,15 +752,6 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
       DL3_T(tp2 += clock64() - tq2;)
       continue;
     }
-    if constexpr (MSK) {
-      // (run_gemm sends a launch here only with ep_x, stat_mode 2 and an addend that is a plain tensor or constant over
-      // whole 32-row blocks)
-      if (full) {
-        stream_epilogue_full<TM, TN, true, EPI == 4, true>(P, acc, m0e, nw0e, wm, l31, lhi, st1, st2);
-        DL3_T(tp2 += clock64() - tq2;)
-        continue;
-      }
-    }
     if constexpr (PRE) {
       if (full) {
         float *pc = P.c + (size_t)(m0e + __builtin_amdgcn_readfirstlane(wm) * 32) * P.ldc + nw0e;
@@ -936,7 +920,10 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
   // the workgroups of the first K-tile row also write the gradient operand they assemble anyway, dY = cA*g + cB*y + cC,
   // to HBM (every (row, column) is staged by exactly one (bx, by_ = 0, bz)): the bwd-data GEMM of the layer then reads ONE
   // tensor instead of two and has no operand transform (round 4)
-  const bool dy_owner = (P.dyout != nullptr) && (by_ == 0);
+  // ... and they take turns: the gridDim.y workgroups that share a row slab (same bx, bz: they all assemble the same dY
+  // stages) each write every gridDim.y-th stage, so that no workgroup carries the whole store stream (first version, all
+  // stores on by_ == 0: the launch waited for those workgroups, +4.5 ms per step for 25 GB of stores)
+  const bool dy_on = (P.dyout != nullptr);
 
   f32x16 acc[TA][TB];
 #pragma unroll
@@ -1015,6 +1002,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
   };
 
   auto store_tiles = [&](int m0, float *Xs, float *Ds) {
+    const bool dy_owner = dy_on && (((m0 - mbeg) / MS) % (int)gridDim.y == by_);
 #pragma unroll
     for (int i = 0; i < NX; i++) {
       const int idx = tid + 256 * i;
@@ -1216,14 +1204,16 @@ int env_int(const char *name) {
 }
 
 // small: the 32-row configurations may be chosen (they exist for the stream kernel only)
-GemmCfg pick_gemm(int M, int K, int N, bool two, bool small) {
+GemmCfg pick_gemm(int M, int K, int N, bool two, bool small, bool fwd = true) {
   const int fb = env_int("DL3_GEMM_BWD_CFG");  // tuning aid: tile configuration of the two-tensor (bwd-data) launches only
   if (two && fb >= 0 && fb < kNumGemmCfgs && (small || kGemmCfgs[fb].BM != 32)) return kGemmCfgs[fb];
   const int forced = env_int("DL3_GEMM_CFG");  // tuning aid (tools/gemm_tune.py)
   if (forced >= 0 && forced < kNumGemmCfgs && (small || kGemmCfgs[forced].BM != 32)) return kGemmCfgs[forced];
   // measured exception (tools/gemm_tune.py): a forward GEMM with a very short reduction and a wide output
   // (24 -> 144 at 128x128) is a pure streaming kernel and wants the tall 256x64 tile
-  if (!two && K < 32 && N > 128 && M >= 65536) return kGemmCfgs[1];
+  // (forward launches only: the single-tensor bwd-data launches of round 4 are `!two` as well — 144 <- 24 at 128x128 ran
+  // 0.71 -> 0.83 ms through this exception)
+  if (fwd && !two && K < 32 && N > 128 && M >= 65536) return kGemmCfgs[1];
   double best = 1e30;
   GemmCfg bc = kGemmCfgs[0];
   for (const GemmCfg &c : kGemmCfgs) {
@@ -1333,7 +1323,10 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   const bool bvec = (A.N % 4 == 0) && (A.ldb % 4 == 0) && al16(A.b);
   const bool vec = avec && bvec;
   const bool stream = vec && env_int("DL3_GEMM_IMPL") != 0 && A.K <= DL3_STREAM_KMAX;
-  GemmCfg c = pick_gemm(A.M, A.K, A.N, two, stream);
+  // (a per-image addend stays on the forward instantiation when its straight-line epilogue can take it: 32-row blocks
+  // inside one image)
+  const bool fwd = !two && !A.ep_x && A.stat_mode != 2 && !(A.ep_add && A.add_div > 1 && A.add_div % 32 != 0);
+  GemmCfg c = pick_gemm(A.M, A.K, A.N, two, stream, fwd);
   if (stream && pre_ok(A) && pre_wanted(A)) c = kGemmCfgs[4];
   A.mtiles = dl3_cdiv(A.M, c.BM);
   DL3_T(A.dbg = g_phase_dbg;)
@@ -1343,9 +1336,6 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   // spill.  DL3_GEMM_IMPL=0 forces the staged kernel (which also serves unaligned operands).
   if (stream) {
     dim3 blk(256);
-    // (a per-image addend stays on the forward instantiation when its straight-line epilogue can take it: 32-row blocks
-    // inside one image)
-    const bool fwd = !two && !A.ep_x && A.stat_mode != 2 && !(A.ep_add && A.add_div > 1 && A.add_div % 32 != 0);
     if (split_math() && c.id != 5 && c.id != 6) {  // (the 32-row small-M tiles keep the f32 MFMA: their split weight tiles exceed the LDS)
       const unsigned dyn = 4u * (two ? 3 : 2) * (unsigned)dl3_cdiv(A.K, 32) * 32;
       const int ktiles = dl3_cdiv(A.K, 32);
@@ -1377,15 +1367,10 @@ int run_gemm(GemmArgs A, hipStream_t st) {
 #undef DL3_SPLIT
       return (int)grid.y;
     }
-    // single-tensor masked bwd-data (dY materialised by dl3_pwconv_bwd_weight_dy): straight-line masked epilogue (EPI 3)
-    const bool msk = !two && !fwd && A.ep_x && A.stat_mode == 2 && !(A.ep_add && A.add_div > 1 && A.add_div % 32 != 0) &&
-                     env_int("DL3_GEMM_EPI3") != 0;
 #define DL3_STREAM(TM_, TN_, WN_)                                                                                    \
   do {                                                                                                               \
     if (two) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, true, 16, 0, WN_>), grid, blk, 0, st, A);           \
     else if (fwd) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, DL3_STREAM_KT_FWD, 1, WN_>), grid, blk, 0, st, A); \
-    else if (msk && !A.ep_add) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, DL3_STREAM_KT_MSK, 3, WN_>), grid, blk, 0, st, A); \
-    else if (msk) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, DL3_STREAM_KT_MSK, 4, WN_>), grid, blk, 0, st, A); \
     else hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, 16, 0, WN_>), grid, blk, 0, st, A);              \
   } while (0)
     if (c.id == 4 && pre_ok(A)) {
@@ -1497,10 +1482,11 @@ extern "C" int dl3_pwconv_partials(int M, int K, int N) {
   // the stat partial row count must not depend on which operand form is used: take the max
   int p = 0;
   for (int two = 0; two < 2; two++)
-    for (int small = 0; small < 2; small++) {
-      const int q = gemm_grid_y(M, N, pick_gemm(M, K, N, two != 0, small != 0));
-      p = q > p ? q : p;
-    }
+    for (int small = 0; small < 2; small++)
+      for (int fwd = 0; fwd < 2; fwd++) {
+        const int q = gemm_grid_y(M, N, pick_gemm(M, K, N, two != 0, small != 0, fwd != 0));
+        p = q > p ? q : p;
+      }
   if (N % 96 == 0) {  // the prefetching bwd-data variant overrides the choice with the 128x96 tile (run_gemm)
     const int q = gemm_grid_y(M, N, kGemmCfgs[4]);
     p = q > p ? q : p;

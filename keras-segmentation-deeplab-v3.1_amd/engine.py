@@ -208,9 +208,13 @@ class Engine:
         self.own_fold_ws_bytes = 0   # device memory of the deferred folds' own slab workspaces (reported by bench.py)
         self._folds = []
         # round 4: the weight-gradient launch of a BatchNorm'ed 1x1 convolution also writes dY = cA*g + cB*y + cC (it
-        # assembles it anyway), and the bwd-data GEMM of the layer reads that ONE tensor (dl3_pwconv_bwd_weight_dy) — for
-        # outputs of at most DL3_DY_MAT channels (0 disables; wide outputs pay a 2 GB write to save a 2 GB read)
-        self.dy_mat_maxn = int(os.environ.get("DL3_DY_MAT", "100000"))
+        # assembles it anyway), and the bwd-data GEMM of the layer reads that ONE tensor (dl3_pwconv_bwd_weight_dy).  The
+        # write is paid by the weight-gradient launch: cheap next to a wide X (project convolutions, +0.02-0.06 ms against
+        # -0.3-0.7 ms of bwd-data at B=128) but not for an HBM-bound launch with a narrow X and a wide dY (16 -> 96 at
+        # 256x256: +0.88 ms against -0.65): only where N <= DL3_DY_MAT_N or K >= DL3_DY_MAT_K (DL3_DY_MAT=0 disables)
+        self.dy_mat = os.environ.get("DL3_DY_MAT", "1") != "0"
+        self.dy_mat_maxn = int(os.environ.get("DL3_DY_MAT_N", "320"))
+        self.dy_mat_mink = int(os.environ.get("DL3_DY_MAT_K", "96"))
         self.dy_buf = None
         self.fork = os.environ.get("DL3_FORK", "0") in ("1", "2")
         # DL3_FORK=2 (experiment): only the weight gradient that can run next to an HBM-bound depthwise backward launch
@@ -1313,11 +1317,11 @@ class PwUnit(_ConvBase):
     def dy_mat_ok(self):
         """does the weight-gradient launch of this convolution also write dY for its bwd-data launch?  (its output is
         BatchNorm'ed — otherwise dY is g itself —, it has a weight gradient to compute and data gradient to hand on, the
-        backward fork is off — the two launches must stay ordered on one stream — and N is within DL3_DY_MAT)"""
+        backward fork is off — the two launches must stay ordered on one stream — and the shape rule of Engine.dy_mat holds)"""
         eng, outv = self.eng, self.outv
         has_bn = any(off == outv.off for _, off, _ in outv.buf.bns)
-        return (has_bn and self.N <= eng.dy_mat_maxn and self.N % 4 == 0 and not eng.fork and not self.bias
-                and eng.trainable(self.wname()) and self.inv.buf.requires_grad)
+        return (has_bn and eng.dy_mat and (self.N <= eng.dy_mat_maxn or self.K >= eng.dy_mat_mink) and self.N % 4 == 0
+                and not eng.fork and not self.bias and eng.trainable(self.wname()) and self.inv.buf.requires_grad)
 
     def bwd(self):
         eng, inv, outv = self.eng, self.inv, self.outv

@@ -364,9 +364,8 @@ def test_pwconv_bwd_data(L, case):
 
 
 MSK_CASES = [
-    # single-tensor masked bwd-data (dY materialised by dl3_pwconv_bwd_weight_dy): straight-line masked epilogue, EPI 3
-    # (no residual) / EPI 4 (residual tensor or per-image addend); ragged shapes take the generic epilogue on their
-    # edge tiles.  M, K, N, act, add mode
+    # single-tensor masked bwd-data (dY materialised by dl3_pwconv_bwd_weight_dy: g is the only operand tensor, cA = NULL)
+    # with activation mask, BatchNorm-backward sums and every kind of addend.  M, K, N, act, add mode
     (65536, 960, 160, 2, 0),          # project conv, 128x160 tiles (128x96 prefetching tiles unless DL3_GEMM_PRE=0)
     (65536 + 200, 160, 960, None, 1),  # expand conv + residual gradient, ragged last row tile
     (65536, 576, 96, 2, 0),
@@ -383,28 +382,6 @@ def test_pwconv_bwd_data_single_tensor_masked(L, case, pre, monkeypatch):
     monkeypatch.setenv("DL3_GEMM_PRE", pre)
     M, K, N, act, addmode = case
     test_pwconv_bwd_data(L, (M, K, N, act, False, addmode, True))
-
-
-def test_pwconv_bwd_data_masked_epilogue_toggle_is_bit_identical(L, monkeypatch):
-    """DL3_GEMM_EPI3=0 sends the same launch through the generic epilogue: same sums in the same order"""
-    M, K, N = 16384, 160, 960
-    rng = np.random.default_rng(14)
-    g = dev(rng.normal(0, 1, (M, N)))
-    w = rng.normal(0, 0.2, (K, N)).astype(np.float32)
-    x, add = dev(rng.normal(0, 1, (M, K))), dev(rng.normal(0, 1, (M, K)))
-    mean, invstd = dev(rng.normal(0, 1, K)), dev(rng.uniform(0.5, 2, K))
-    wT = empty(N, K)
-    call("dl3_transpose", ptr(dev(w)), ptr(wT), K, N)
-    P = L.dl3_pwconv_partials(M, N, K)
-    outs = []
-    for flag in ("1", "0"):
-        monkeypatch.setenv("DL3_GEMM_EPI3", flag)
-        dx, dpart = empty(M, K), empty(P, K, 2)
-        call("dl3_pwconv_bwd_data", ptr(g), N, None, N, None, None, None, ptr(wT), ptr(dx), K, ptr(x), K, None, None, 0,
-             ptr(add), K, 1, 1.0, ptr(mean), ptr(invstd), ptr(dpart), M, K, N)
-        outs.append((host(dx).copy(), host(dpart).copy()))
-    assert np.array_equal(outs[0][0], outs[1][0])
-    assert np.array_equal(outs[0][1], outs[1][1])
 
 
 BW_CASES = [
