@@ -920,17 +920,65 @@ def test_three_train_on_batch_steps_follow_the_adam_oracle(bn_mode, opt):
         u = float(np.sum(upd ** 2))
         num, den, n32 = num + d, den + u, n32 + d32
         r = np.sqrt(d / u)
-        if r > worst[0]:
+        # per tensor: only tensors large enough for a relative L2 to mean something (a handful of flipped signs decide a
+        # 32-element beta) and that MOVE in float64 — the beta of a project BatchNorm whose every path leads through a
+        # convolution + batch-statistics BatchNorm has an analytically zero gradient (the next BatchNorm removes any
+        # per-channel constant): float64 leaves it alone, any fp32 evaluation turns its rounding noise into +-lr steps
+        if ref.size >= 1024 and np.sqrt(u / ref.size) >= 0.1 * o["lr"] / (1.0 + 2 * o["decay"]) and r > worst[0]:
             worst = (r, name, np.sqrt(d32 / u))
     tot, tot32 = np.sqrt(num / den), np.sqrt(n32 / den)
     print("update distance to float64, whole model: gpu %.3e, the noisier fp32 yardstick %.3e; worst tensor %s" % (tot, tot32, worst))
     assert tot <= max(2e-2, 2.0 * tot32), (tot, tot32)
-    assert worst[0] <= max(0.2, 3.0 * worst[2]), worst
-    # the moments themselves (linear / quadratic in the gradients, no sign amplification)
+    assert worst[1] is not None and worst[0] <= max(0.25, 3.0 * worst[2]), worst
+    # the moments themselves, against the same yardstick (they follow the trajectories apart: the weights the second and
+    # third gradients are taken at already differ by the sign noise above; the arithmetic of the update itself is pinned
+    # to 1e-6 on GIVEN gradients by test_engine_adam_follows_the_oracle_on_given_gradients)
+    _, _, st32n = O.train_steps(params, batches, opt=o, bn_frozen=frozen, **kw)
     for name in ("Conv/kernel:0", "expanded_conv_7_depthwise/depthwise_kernel:0", "expanded_conv_16_project_BN/gamma:0",
                  "aspp0/kernel:0", "custom_logits_semantic/bias:0"):
         kind, off, n, shp, _ = eng.slots[name]
         m = eng.adam_m[off:off + n].cpu().numpy().reshape(shp)
         v = eng.adam_v[off:off + n].cpu().numpy().reshape(shp)
-        assert _l2(m, st64[name][0].reshape(shp)) < 3e-2, name
-        assert _l2(v, st64[name][1].reshape(shp)) < 3e-2, name
+        ym, yv = _l2(st32n[name][0], st64[name][0]), _l2(st32n[name][1], st64[name][1])
+        em, ev = _l2(m, st64[name][0].reshape(shp)), _l2(v, st64[name][1].reshape(shp))
+        print("   moments %-48s m: gpu %.2e numpy-fp32 %.2e   v: gpu %.2e numpy-fp32 %.2e" % (name, em, ym, ev, yv))
+        assert em < max(3e-2, 3.0 * ym) and ev < max(3e-2, 3.0 * yv), name
+
+
+@pytest.mark.parametrize("opt", [None, dict(lr=1e-3, decay=0.5, epsilon=1e-4, beta_1=0.8, beta_2=0.99)])
+def test_engine_adam_follows_the_oracle_on_given_gradients(opt):
+    """a20: Engine.adam — the host half of Keras 2.2.4 Adam.get_updates (decay on `iterations` BEFORE the increment, t =
+    iterations + 1, bias correction folded into lr_t) + dl3_adam_step — over FOUR steps on gradients handed in, against
+    oracle/dl3_oracle.adam_update in float64 on the same numbers: weights, m and v to fp32 rounding.  With the
+    gradients given there is no trajectory noise: a wrong schedule, epsilon placement or moment update shows at 1e-1,
+    the bar is 1e-5 of the update.  (Gradient magnitudes span 1e-9 .. 1e+1: both sides of epsilon.)"""
+    model, params = _build("mobilenetv2", (64, 64, 3), 3, "deeplab")
+    _load(model, params)
+    eng = model._engine(2, True, dropout=False, use_graph=False)
+    o = dict(O.ADAM_DEFAULTS)
+    o.update(opt or {})
+    n = eng.n_param
+    rng = np.random.default_rng(31)
+    p = eng.params[:n].cpu().numpy().astype(np.float64)
+    p0 = p.copy()
+    m, v = np.zeros(n), np.zeros(n)
+    scale = 10.0 ** rng.uniform(-9, 1, n)
+    for it in range(4):
+        g = (rng.normal(0, 1, n) * scale).astype(np.float32)
+        eng.grads[:n].copy_(torch.from_numpy(g).cuda())
+        eng.adam(o, 1.0)
+        p, m, v = O.adam_update(p, g.astype(np.float64), m, v, it, **o)
+    torch.cuda.synchronize()
+    assert eng.iteration == 4
+    gp = eng.params[:n].cpu().numpy().astype(np.float64)
+    gm, gv = eng.adam_m[:n].cpu().numpy().astype(np.float64), eng.adam_v[:n].cpu().numpy().astype(np.float64)
+    assert np.abs(gm - m).max() <= 1e-6 * np.abs(m).max() and _l2(gm, m) < 1e-6
+    assert _l2(gv, v) < 1e-6 and np.all(np.abs(gv - v) <= 2e-6 * v + 1e-37)
+    upd = p - p0
+    # every weight: fp32 representation of the weight itself (4 roundings) + 1e-5 of its update
+    assert np.all(np.abs(gp - p) <= 4 * 6e-8 * np.maximum(np.abs(p), np.abs(p0)) + 1e-5 * np.abs(upd) + 1e-12)
+    assert _l2(gp - p0, upd) < 2e-5, _l2(gp - p0, upd)
+    # the schedule is visible: the four steps are not four equal steps (decay) and elements below epsilon move less
+    big = scale > 1e-2
+    small = scale < 1e-8 * max(1.0, o["epsilon"] / 1e-8)
+    assert np.abs(upd[big]).mean() > o["lr"] / (1 + 3 * o["decay"]) and np.abs(upd[small]).mean() < 0.5 * np.abs(upd[big]).mean()
