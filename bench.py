@@ -129,6 +129,12 @@ def _work(name, a):
         # (_dy: the launch also writes dY once — the M*N the bwd-data launch of the layer no longer reads twice)
         by = M * K + M * N * (2 if nz(a[7]) else 1) + K * N + (M * N if name.endswith("_dy") else 0)
         return "gemm", "bwd-weight M=%d K=%d N=%d" % (M, K, N), 2.0 * M * K * N, 4.0 * by
+    if name == "dl3_pwconv_bwd_fused":
+        # both gradients in one pass: x, g (+ yraw), wT in; dx out (+ the addend and, if it is another tensor, stat_x in)
+        M, K, N = a[23], a[24], a[25]
+        by = M * K + M * N * (2 if nz(a[7]) else 1) + K * N + M * K * (1 + (1 if nz(a[16]) else 0) +
+                                                                      (1 if (nz(a[18]) and a[18] != a[0]) else 0))
+        return "gemm", "bwd-fused M=%d K=%d N=%d" % (M, K, N), 4.0 * M * K * N, 4.0 * by
     if name == "dl3_dwconv3x3_fwd":
         N, H, W, C, stride, rate, Ho, Wo = a[6], a[7], a[8], a[9], a[10], a[11], a[14], a[15]
         fam = "dw_dilated" if (rate > 1 and stride == 1) else "dw"
@@ -203,7 +209,8 @@ def roofline_blocks(rows, args):
         tf = g["flops"] / g["ms"] / 1e9
         out["roofline"] = {
             "bound": "mfma", "kernel": "Conv2D 1x1 GEMM family on v_mfma_f32_32x32x2_f32: pw_gemm_stream_kernel (forward, "
-            "bwd-data) + pw_wgrad_kernel (bwd-weight), %d launches/step" % g["launches"],
+            "bwd-data) + pw_wgrad_kernel (bwd-weight) + pw_bwd_fused_kernel (both gradients of the HBM-bound early "
+            "layers in one pass), %d launches/step" % g["launches"],
             "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS,
             "traffic": _pmc_traffic("gemm", args)[0], "traffic_source": _pmc_traffic("gemm", args)[1],
             "avg_ms": g["ms"] / g["launches"], "family_ms_per_step": g["ms"], "algorithmic_flops_per_step": g["flops"],

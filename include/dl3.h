@@ -129,6 +129,25 @@ int dl3_pwconv_bwd_weight_dy(const float *x, int ldx, const float *in_scale, con
                              const float *g, int ldg, const float *yraw, int ldyraw, const float *cA,
                              const float *cB, const float *cC, float *dw, float *dbias, int M, int K, int N,
                              void *workspace, size_t workspace_bytes, float *dy_out, int lddy, void *stream);
+/* Both gradients of a 1x1 convolution in ONE pass over (g, yraw, x) — for the HBM-bound layers with a small weight matrix
+ * (round 4: the expand / project convolutions of the first inverted-residual blocks, deeplabv3p.py:175-201, 16..144
+ * channels on 256x256 / 128x128 maps, where _bwd_weight and _bwd_data each read the wide gradient operand once):
+ *   dw[K,N] = T(x)^T . dY                                  (dw == NULL: the [S][K][N] slabs stay in the workspace)
+ *   dx[M,K](lddx) = mask_{in_act}(dY . wT[N,K]) + dx_add   dY = cA*g + cB*yraw + cC
+ *   dstat_partial (nullable) [S][K][2] = sum(dx), sum(dx * (stat_x - x_mean) * x_invstd) — stat_x is the forward input
+ *   itself or, when the gradient reaches another BatchNorm'ed tensor unchanged through a residual Add, that tensor.
+ * S = dl3_pwconv_bwd_fused_splits(M, K, N) workgroups / slabs / partial rows; workspace >= _workspace(M, K, N) bytes.
+ * _supported: K, N multiples of 4 with ceil(K/32) * ceil(N/32) <= 5.  All operands 16-byte aligned, leading dimensions
+ * multiples of 4. */
+int dl3_pwconv_bwd_fused_supported(int M, int K, int N);
+int dl3_pwconv_bwd_fused_splits(int M, int K, int N);
+size_t dl3_pwconv_bwd_fused_workspace(int M, int K, int N);
+int dl3_pwconv_bwd_fused(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
+                         const float *g, int ldg, const float *yraw, int ldyraw, const float *cA, const float *cB,
+                         const float *cC, const float *wT, float *dw, float *dx, int lddx, const float *dx_add,
+                         int ldadd, const float *stat_x, int ldstatx, const float *x_mean, const float *x_invstd,
+                         float *dstat_partial, int M, int K, int N, void *workspace, size_t workspace_bytes,
+                         void *stream);
 /* out[cols][rows] = in[rows][cols]^T  (W[K,N] -> WT[N,K] for bwd_data) */
 int dl3_transpose(const float *in, float *out, int rows, int cols, void *stream);
 /* n transposes in one launch (all W -> WT of a backward pass).  desc (device, int64 [n][6]): in pointer, out pointer,

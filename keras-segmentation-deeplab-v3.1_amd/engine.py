@@ -211,10 +211,14 @@ class Engine:
         # assembles it anyway), and the bwd-data GEMM of the layer reads that ONE tensor (dl3_pwconv_bwd_weight_dy).  The
         # write is paid by the weight-gradient launch: cheap next to a wide X (project convolutions, +0.02-0.06 ms against
         # -0.3-0.7 ms of bwd-data at B=128) but not for an HBM-bound launch with a narrow X and a wide dY (16 -> 96 at
-        # 256x256: +0.88 ms against -0.65): only where N <= DL3_DY_MAT_N or K >= DL3_DY_MAT_K (DL3_DY_MAT=0 disables)
+        # 256x256: +0.88 ms against -0.65): only where N <= K or K >= DL3_DY_MAT_K (DL3_DY_MAT=0 disables)
+        # (second look, same call: the criterion is the width of X against dY, not the width of dY: N <= K or K >= 96)
         self.dy_mat = os.environ.get("DL3_DY_MAT", "1") != "0"
-        self.dy_mat_maxn = int(os.environ.get("DL3_DY_MAT_N", "320"))
         self.dy_mat_mink = int(os.environ.get("DL3_DY_MAT_K", "96"))
+        # both gradients of an HBM-bound 1x1 convolution with a small weight matrix in one pass (dl3_pwconv_bwd_fused):
+        # layers with at least DL3_FUSED_ROWS pixel rows (DL3_FUSED_BWD=0 disables)
+        self.fused_bwd = os.environ.get("DL3_FUSED_BWD", "1") != "0"
+        self.fused_min_rows = int(os.environ.get("DL3_FUSED_ROWS", "131072"))
         self.dy_buf = None
         self.fork = os.environ.get("DL3_FORK", "0") in ("1", "2")
         # DL3_FORK=2 (experiment): only the weight gradient that can run next to an HBM-bound depthwise backward launch
@@ -1320,10 +1324,58 @@ class PwUnit(_ConvBase):
         backward fork is off — the two launches must stay ordered on one stream — and the shape rule of Engine.dy_mat holds)"""
         eng, outv = self.eng, self.outv
         has_bn = any(off == outv.off for _, off, _ in outv.buf.bns)
-        return (has_bn and eng.dy_mat and (self.N <= eng.dy_mat_maxn or self.K >= eng.dy_mat_mink) and self.N % 4 == 0
+        return (has_bn and eng.dy_mat and (self.N <= self.K or self.K >= eng.dy_mat_mink) and self.N % 4 == 0
+                and not self.fused_ok()
                 and not eng.fork and not self.bias and eng.trainable(self.wname()) and self.inv.buf.requires_grad)
 
+    def fused_ok(self):
+        """both gradients in one pass (dl3_pwconv_bwd_fused): a small weight matrix, many pixel rows, a trainable kernel
+        without bias, a data gradient to hand on, whole aligned tensors on both sides"""
+        eng, inv, outv = self.eng, self.inv, self.outv
+        return bool(eng.fused_bwd and not eng.fork and self.img_add is None and not self.bias and self.wrow0 == 0
+                    and self.M >= eng.fused_min_rows and eng.trainable(self.wname()) and inv.buf.requires_grad
+                    and inv.ld % 4 == 0 and inv.off % 4 == 0 and outv.ld % 4 == 0 and outv.off % 4 == 0
+                    and eng.lib.dl3_pwconv_bwd_fused_supported(self.M, self.K, self.N))
+
+    def _bwd_fused(self):
+        eng, inv, outv = self.eng, self.inv, self.outv
+        M, K, N = self.M, self.K, self.N
+        g, ldg, y, ldy, cA, cB, cC = eng.grad_operand(outv)
+        s, t, a = inv.xform()
+        ibuf = inv.buf
+        wT = eng.empty(K * N)
+        eng.transpose(eng.wptr(self.wname()), wT, K, N)
+        gout, add, last = eng.contrib_kernel(ibuf)
+        need_stat = last and bool(ibuf.bns)
+        if need_stat and (inv.off != 0 or inv.C != ibuf.ld):
+            raise NotImplementedError("BN-backward statistics through a channel slice")
+        S = eng.lib.dl3_pwconv_bwd_fused_splits(M, K, N)
+        ws = eng.lib.dl3_pwconv_bwd_fused_workspace(M, K, N)
+        tgt = None
+        if last and not need_stat and a == ACT_NONE and inv.off == 0 and inv.C == ibuf.ld:
+            tgt = eng.alias_stats_target(ibuf)   # see bwd(): the sums of the BatchNorm the gradient reaches through the Add
+        sbuf = tgt if tgt is not None else (ibuf if need_stat else None)
+        dpart = eng.empty(S * sbuf.ld * 2) if sbuf is not None else None
+        own = eng.empty(ws // 4 + 4)
+        eng.own_fold_ws_bytes += ws + 16
+        eng.op(eng.ops_bwd, "dl3_pwconv_bwd_fused", inv.p(), inv.ld, s, t, a, g, ldg, y, ldy, cA, cB, cC, ptr(wT), None,
+               gout.data_ptr() + 4 * inv.off, ibuf.ld, (add.data_ptr() + 4 * inv.off) if add is not None else None, ibuf.ld,
+               (sbuf.t.data_ptr() + (4 * inv.off if sbuf is ibuf else 0)) if sbuf is not None else None,
+               sbuf.ld if sbuf is not None else 0, sbuf.vptr(V_MEAN, inv.off if sbuf is ibuf else 0) if sbuf is not None else None,
+               sbuf.vptr(V_INVSTD, inv.off if sbuf is ibuf else 0) if sbuf is not None else None, ptr(dpart), M, K, N,
+               ptr(own), ws)
+        if eng.defer_fold(S, K * N):
+            eng.fold(ptr(own), S, K * N, eng.gptr(self.wname()))
+        else:
+            eng.op(eng.ops_bwd, "dl3_reduce_partials", ptr(own), S, K * N, eng.gptr(self.wname()))
+        if tgt is not None:
+            eng.prestat[id(tgt)] = (dpart, S, tgt.ld)
+        elif need_stat:
+            eng.finish_bn_bwd(ibuf, dpart, S, ibuf.ld)
+
     def bwd(self):
+        if self.fused_ok():
+            return self._bwd_fused()
         eng, inv, outv = self.eng, self.inv, self.outv
         M, K, N = self.M, self.K, self.N
         g, ldg, y, ldy, cA, cB, cC = eng.grad_operand(outv)

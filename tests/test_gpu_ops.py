@@ -454,6 +454,73 @@ def test_pwconv_bwd_weight_writes_dy(L, case):
     assert np.isnan(got[:, N:]).all()   # nothing written beyond the N columns
 
 
+FUSED_CASES = [
+    # M, K, N, act, two-tensor dY, residual addend, stats (0 none, 1 on the forward input, 2 on another tensor)
+    (4096 + 17, 16, 96, None, True, True, 1),    # block 1 expand: K below one 32-block, 3 column blocks, ragged rows
+    (3000, 32, 16, 2, True, False, 1),           # block 0 project: ReLU6 mask from the depthwise output
+    (2500, 24, 144, None, True, True, 2),        # 24 -> 144: 5 column blocks, sums against the Add's other input
+    (2048, 144, 24, 2, True, False, 1),          # 144 -> 24: 5 row blocks of the weight matrix, two dX blocks on one wave
+    (1000, 96, 24, 1, False, False, 0),          # plain dY, ReLU mask, no sums
+    (777, 144, 32, 2, True, True, 1),
+    (640, 64, 64, None, True, False, 1),         # 2 x 2 blocks
+    (20, 16, 96, None, True, True, 1),           # fewer rows than one stage
+    (40000, 128, 32, 2, True, False, 1),         # 4 x 1, more stages than workgroups
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_pwconv_bwd_fused(L, case):
+    """dl3_pwconv_bwd_fused == dl3_pwconv_bwd_weight + dl3_pwconv_bwd_data of the same layer (float64 reference): weight
+    gradient (slabs folded by the op or left for the caller), masked data gradient + addend, BatchNorm-backward sums"""
+    M, K, N, act, two, has_add, stats = case
+    assert L.dl3_pwconv_bwd_fused_supported(M, K, N) == 1
+    rng = np.random.default_rng(16)
+    g = rng.normal(0, 1, (M, N)).astype(np.float32)
+    yraw = rng.normal(0, 1, (M, N)).astype(np.float32)
+    cA, cB, cC = [rng.normal(0, 1, N).astype(np.float32) for _ in range(3)]
+    w = rng.normal(0, 0.2, (K, N)).astype(np.float32)
+    x = rng.normal(0, 1, (M, K)).astype(np.float32)
+    other = rng.normal(0, 1, (M, K)).astype(np.float32)
+    s, t, a = _xform(rng, K, act)
+    mean = rng.normal(0, 1, K).astype(np.float32)
+    invstd = rng.uniform(0.5, 2, K).astype(np.float32)
+    add = rng.normal(0, 1, (M, K)).astype(np.float32) if has_add else None
+    z = x.astype(np.float64) if s is None else (s * x.astype(np.float64) + t)
+    dY = (cA * g.astype(np.float64) + cB * yraw + cC) if two else g.astype(np.float64)
+    dw_ref = np_act(z, a).T @ dY
+    dx_ref = dY @ w.astype(np.float64).T * np_mask(z, a)
+    if has_add:
+        dx_ref = dx_ref + add
+    sx = x if stats == 1 else other
+    wT = empty(N, K)
+    call("dl3_transpose", ptr(dev(w)), ptr(wT), K, N)
+    S = L.dl3_pwconv_bwd_fused_splits(M, K, N)
+    nbytes = L.dl3_pwconv_bwd_fused_workspace(M, K, N)
+    assert nbytes == S * K * N * 4
+    args = lambda dwp, dxp, partp, wsp: (
+        ptr(dev(x)), K, ptr(dev(s)) if s is not None else None, ptr(dev(t)) if t is not None else None, a, ptr(dev(g)), N,
+        ptr(dev(yraw)) if two else None, N, ptr(dev(cA)) if two else None, ptr(dev(cB)) if two else None,
+        ptr(dev(cC)) if two else None, ptr(wT), dwp, dxp, K, ptr(dev(add)) if has_add else None, K,
+        ptr(dev(sx)) if stats else None, K, ptr(dev(mean)) if stats else None, ptr(dev(invstd)) if stats else None, partp,
+        M, K, N, wsp, nbytes)
+    ws = empty(S, K, N)
+    dw, dx, part = empty(K, N), empty(M, K), empty(S, K, 2)
+    call("dl3_pwconv_bwd_fused", *args(ptr(dw), ptr(dx), ptr(part) if stats else None, ptr(ws)))
+    assert relerr(host(dx), dx_ref) < TOL
+    assert relerr(host(dw), dw_ref) < TOL
+    if stats:
+        s1, s2 = fold_partials(part, S, K)
+        assert relerr(s1, dx_ref.sum(0)) < 1e-3
+        assert relerr(s2, (dx_ref * (sx - mean) * invstd).sum(0)) < 1e-3
+    # dw == NULL: the slabs stay in the workspace; folded by the caller they are the same gradient bit for bit
+    ws2, dx2 = empty(S, K, N), empty(M, K)
+    call("dl3_pwconv_bwd_fused", *args(None, ptr(dx2), None if not stats else ptr(empty(S, K, 2)), ptr(ws2)))
+    dw2 = empty(K, N)
+    call("dl3_reduce_partials", ptr(ws2), S, K * N, ptr(dw2))
+    assert np.array_equal(host(dw2), host(dw)) and np.array_equal(host(dx2), host(dx))
+    assert L.dl3_pwconv_bwd_fused_supported(M, 192, 32) == 0 and L.dl3_pwconv_bwd_fused_supported(M, 30, 32) == 0
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 32, 3, 32, 2), (1, 17, 19, 3, 32, 2), (1, 16, 16, 32, 64, 1)])
 def test_conv3x3(L, shape):
     N, H, W, Cin, Cout, stride = shape

@@ -16,7 +16,7 @@ done
 python - "$out" <<'PY'
 import glob, json, os, sys
 out = sys.argv[1]
-print("%-28s %9s %9s | %8s %8s %8s %8s %8s" % ("variant", "img/s", "ms/step", "gemm fwd", "bwd-data", "bwd-wgt", "dw", "other"))
+print("%-28s %9s %9s | %8s %8s %8s %8s %8s %8s" % ("variant", "img/s", "ms/step", "gemm fwd", "bwd-data", "bwd-wgt", "bwd-fusd", "dw", "other"))
 for p in sorted(glob.glob(os.path.join(out, "*.json"))):
     if p.endswith(".plan.json"):
         continue
@@ -26,7 +26,7 @@ for p in sorted(glob.glob(os.path.join(out, "*.json"))):
     except Exception as e:
         print("%-28s failed: %s" % (name, e))
         continue
-    fam = {"fwd": 0.0, "bwd-data": 0.0, "bwd-weight": 0.0, "dw": 0.0, "other": 0.0}
+    fam = {"fwd": 0.0, "bwd-data": 0.0, "bwd-weight": 0.0, "bwd-fused": 0.0, "dw": 0.0, "other": 0.0}
     try:
         for r in json.load(open(os.path.join(out, name + ".plan.json")))["rows"]:
             if r["family"] == "gemm":
@@ -38,6 +38,6 @@ for p in sorted(glob.glob(os.path.join(out, "*.json"))):
                 fam["other"] += r["ms"]
     except Exception:
         pass
-    print("%-28s %9.1f %9.3f | %8.2f %8.2f %8.2f %8.2f %8.2f" % (name, d["value"], d["ms_per_step"], fam["fwd"], fam["bwd-data"],
-                                                             fam["bwd-weight"], fam["dw"], fam["other"]))
+    print("%-28s %9.1f %9.3f | %8.2f %8.2f %8.2f %8.2f %8.2f %8.2f" % (name, d["value"], d["ms_per_step"], fam["fwd"], fam["bwd-data"],
+                                                                   fam["bwd-weight"], fam["bwd-fused"], fam["dw"], fam["other"]))
 PY
