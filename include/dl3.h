@@ -137,8 +137,8 @@ int dl3_pwconv_bwd_weight_dy(const float *x, int ldx, const float *in_scale, con
  *   dstat_partial (nullable) [S][K][2] = sum(dx), sum(dx * (stat_x - x_mean) * x_invstd) — stat_x is the forward input
  *   itself or, when the gradient reaches another BatchNorm'ed tensor unchanged through a residual Add, that tensor.
  * S = dl3_pwconv_bwd_fused_splits(M, K, N) workgroups / slabs / partial rows; workspace >= _workspace(M, K, N) bytes.
- * _supported: K, N multiples of 4 with ceil(K/32) * ceil(N/32) <= 5.  All operands 16-byte aligned, leading dimensions
- * multiples of 4. */
+ * _supported: 0 unless K, N are multiples of 4 with ceil(K/32) * ceil(N/32) <= 5; 2: any epilogue; 1 (K > 64): without
+ * dx_add and with stat_x == x only (-4 otherwise).  All operands 16-byte aligned, leading dimensions multiples of 4. */
 int dl3_pwconv_bwd_fused_supported(int M, int K, int N);
 int dl3_pwconv_bwd_fused_splits(int M, int K, int N);
 size_t dl3_pwconv_bwd_fused_workspace(int M, int K, int N);

@@ -32,24 +32,34 @@ struct FusedArgs {
 
 constexpr int FMS = 32;  // rows per stage
 
-template <int KB, int NB>
-__global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(FusedArgs P) {
+// AUX: the epilogue has operands of its own — a residual addend and / or BatchNorm-backward sums against ANOTHER tensor
+// than the forward input (the Add's other input, Engine.alias_stats_target) — staged through LDS next to x (expand
+// convolutions: K <= 64, the tiles are small).  Without AUX the sums, if any, are taken against the forward input itself,
+// which is staged RAW (the input transform is applied where the fragments are read: it is two VALU operations per
+// element, and the epilogue needs the raw value for the activation mask and x_hat anyway).
+// (three workgroups per CU where the registers allow it without spilling: these launches wait for memory, not for the
+// matrix pipe; the five-block and AUX shapes keep 2 — at 3 they spill 20-150 B per lane)
+template <int KB, int NB, bool AUX>
+__global__ __launch_bounds__(256, (KB * NB == 5 || AUX) ? 2 : 3) void pw_bwd_fused_kernel(FusedArgs P) {
   constexpr int KP = KB * 32, NP = NB * 32;
   constexpr int LDX = KP + 4, LDD = NP + 4, LDW = KP;
   constexpr int NBLK = KB * NB;
   constexpr int WB = (NBLK + 3) / 4;  // dW blocks per wave (at most)
   constexpr int XB = (KB + 3) / 4;    // dX blocks per wave (at most)
-  __shared__ float Xs[FMS * LDX];     // T(x) of the stage, row-major
-  __shared__ float Ds[FMS * LDD];     // dY of the stage, row-major
-  __shared__ float Wl[NP * LDW];      // W^T [n][k], zero beyond K / N
-  __shared__ float cfx[2 * KP];       // input transform scale | shift
-  __shared__ float cfd[3 * NP];       // cA | cB | cC
+  __shared__ float Xr[FMS * LDX];                 // x of the stage, raw, row-major
+  __shared__ float Ds[FMS * LDD];                 // dY of the stage, row-major
+  __shared__ float Sx[AUX ? FMS * LDX : 1];       // the other stat tensor
+  __shared__ float Ad[AUX ? FMS * LDX : 1];       // the addend
+  __shared__ float Wl[NP * LDW];                  // W^T [n][k], zero beyond K / N
+  __shared__ float cfx[2 * KP];                   // input transform scale | shift
+  __shared__ float cfd[3 * NP];                   // cA | cB | cC
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int bz = blockIdx.x;
   const int mbeg = bz * P.Mper, mend = min(P.M, mbeg + P.Mper);
   const bool two = (P.cA != nullptr);
+  const bool sep = AUX && P.sx != nullptr && P.sx != P.x;
   const float hi = (P.x_act == DL3_ACT_RELU6) ? 6.f : __builtin_inff();
 
   for (int i = tid; i < KP; i += 256) {
@@ -77,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(FusedArgs P) {
 #pragma unroll
   for (int b = 0; b < XB; b++) st1[b] = st2[b] = 0.f;
 
-  f32x4 rx[KB], rg[NB], ry[NB];
+  f32x4 rx[KB], rg[NB], ry[NB], rs[AUX ? KB : 1], ra[AUX ? KB : 1];
   auto load_regs = [&](int m0) {
 #pragma unroll
     for (int i = 0; i < KB; i++) {
@@ -85,6 +95,10 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(FusedArgs P) {
       const int mr = idx / (KP / 4), kq = idx % (KP / 4);
       const int row = min(m0 + mr, P.M - 1), k = min(kq * 4, P.K - 4);
       rx[i] = ld4(P.x + (size_t)row * P.ldx + k);
+      if constexpr (AUX) {
+        if (sep) rs[i] = ld4(P.sx + (size_t)row * P.ldsx + k);
+        if (P.add) ra[i] = ld4(P.add + (size_t)row * P.ldadd + k);
+      }
     }
 #pragma unroll
     for (int i = 0; i < NB; i++) {
@@ -96,14 +110,17 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(FusedArgs P) {
     }
   };
   auto store_lds = [&](int m0) {
+    // x stays raw and needs no zeroing: rows beyond the range meet an all-zero dY row, columns beyond K only feed
+    // accumulator rows / output columns that are never written (the addresses were clamped: every value is finite)
 #pragma unroll
     for (int i = 0; i < KB; i++) {
       const int idx = tid + 256 * i;
       const int mr = idx / (KP / 4), kq = idx % (KP / 4);
-      const bool ok = (m0 + mr) < mend && kq * 4 < P.K;
-      f32x4 v = dl3_act4(ld4(cfx + kq * 4) * rx[i] + ld4(cfx + KP + kq * 4), P.x_act);
-      if (!ok) v = splat4(0.f);
-      st4(&Xs[mr * LDX + kq * 4], v);
+      st4(&Xr[mr * LDX + kq * 4], rx[i]);
+      if constexpr (AUX) {
+        if (sep) st4(&Sx[mr * LDX + kq * 4], rs[i]);
+        if (P.add) st4(&Ad[mr * LDX + kq * 4], ra[i]);
+      }
     }
 #pragma unroll
     for (int i = 0; i < NB; i++) {
@@ -124,37 +141,23 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(FusedArgs P) {
     __syncthreads();
     if (m0 + FMS < mend) load_regs(m0 + FMS);  // in flight under this stage's MFMAs
 
-    // ---- dX blocks of this wave: epilogue operands requested before the MFMAs
-    // block kx of the wave covers columns (4 * kx + (3 - wave)) * 32 ..: the waves with the fewest dW blocks take them
-    float sxv[XB][16], adv[XB][16];
-#pragma unroll
-    for (int kx = 0; kx < XB; kx++) {
-      const int kbx = 4 * kx + (3 - wave);
-      if (kbx < KB) {
-        const int col = min(kbx * 32 + l31, P.K - 1);
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int row = min(m0 + (r & 3) + 8 * (r >> 2) + 4 * lhi, P.M - 1);
-          sxv[kx][r] = P.sx ? P.sx[(size_t)row * P.ldsx + col] : 0.f;
-          adv[kx][r] = P.add ? P.add[(size_t)row * P.ldadd + col] : 0.f;
-        }
-      }
-    }
     // ---- dW += T(X)^T . dY: block b of the wave = (kb, nb) = ((wave + 4 b) / NB, (wave + 4 b) % NB)
 #pragma unroll
     for (int b = 0; b < WB; b++) {
       const int blk = wave + 4 * b;
       if (blk < NBLK) {
         const int kb = blk / NB, nb = blk % NB;
+        const float sk = cfx[kb * 32 + l31], tk = cfx[KP + kb * 32 + l31];
 #pragma unroll
         for (int s = 0; s < FMS / 2; s++) {
-          const float a = Xs[(2 * s + lhi) * LDX + kb * 32 + l31];
+          const float a = dl3_act(sk * Xr[(2 * s + lhi) * LDX + kb * 32 + l31] + tk, P.x_act);
           const float bb = Ds[(2 * s + lhi) * LDD + nb * 32 + l31];
           accw[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, accw[b], 0, 0, 0);
         }
       }
     }
-    // ---- dX = dY . W^T, finished per stage
+    // ---- dX = dY . W^T, finished per stage.  Block kx of the wave covers columns (4 kx + 3 - wave) * 32 ..: the waves
+    // with the fewest dW blocks take them
 #pragma unroll
     for (int kx = 0; kx < XB; kx++) {
       const int kbx = 4 * kx + (3 - wave);
@@ -162,6 +165,7 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(FusedArgs P) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll 8
         for (int s = 0; s < NP / 2; s++) {
           const float a = Ds[l31 * LDD + 2 * s + lhi];
           const float bb = Wl[(2 * s + lhi) * LDW + kbx * 32 + l31];
@@ -169,22 +173,27 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(FusedArgs P) {
         }
         const int col = kbx * 32 + l31;
         const bool cok = col < P.K;
+        const float sc = cfx[col], tc = cfx[KP + col];
         const float mu = (P.part && cok) ? P.mean[col] : 0.f, is = (P.part && cok) ? P.invstd[col] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int rl = (r & 3) + 8 * (r >> 2) + 4 * lhi;
           const int row = m0 + rl;
+          const float raw = Xr[rl * LDX + col];
           float v = acc[r];
           if (P.x_act != DL3_ACT_NONE) {
-            // mask of ReLU / ReLU6 from the clamped value itself: T in (0, hi) <=> pre-activation in (0, hi)
-            const float t = Xs[rl * LDX + col];
-            v = (t > 0.f && t < hi) ? v : 0.f;
+            const float z = sc * raw + tc;
+            v = (z > 0.f && z < hi) ? v : 0.f;
           }
-          v += adv[kx][r];
+          float xh = raw;
+          if constexpr (AUX) {
+            if (P.add) v += Ad[rl * LDX + col];
+            if (sep) xh = Sx[rl * LDX + col];
+          }
           if (cok && row < mend) {
             __builtin_nontemporal_store(v, &P.dx[(size_t)row * P.lddx + col]);
             st1[kx] += v;
-            st2[kx] += v * ((sxv[kx][r] - mu) * is);
+            st2[kx] += v * ((xh - mu) * is);
           }
         }
       }
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void pw_bwd_fused_kernel(FusedArgs P) {
 
 int fused_rows_per_wg(int M) {
   const char *e = getenv("DL3_FUSED_WGS");  // tuning aid: target number of workgroups
-  long want = e && atol(e) > 0 ? atol(e) : 1024;
+  long want = e && atol(e) > 0 ? atol(e) : 2048;  // (B = 128, 16 -> 96 at 256x256: 1024 -> 3.06 ms, 2048 -> 2.45 ms)
   long stages = dl3_cdiv(M, FMS);
   if (want > stages) want = stages;
   return (int)(dl3_cdiv((int)stages, (int)want) * FMS);
@@ -237,9 +246,11 @@ inline bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
 extern "C" int dl3_reduce_partials(const float *partial, int P, int n, float *out, void *stream);
 
+// 1: supported; 2: supported including a residual addend / sums against another tensor than x (K <= 64)
 extern "C" int dl3_pwconv_bwd_fused_supported(int M, int K, int N) {
   if (M <= 0 || K < 4 || N < 4 || K % 4 || N % 4) return 0;
-  return dl3_cdiv(K, 32) * dl3_cdiv(N, 32) <= 5 ? 1 : 0;
+  if (dl3_cdiv(K, 32) * dl3_cdiv(N, 32) > 5) return 0;
+  return K <= 64 ? 2 : 1;
 }
 
 extern "C" int dl3_pwconv_bwd_fused_splits(int M, int K, int N) {
@@ -281,10 +292,17 @@ extern "C" int dl3_pwconv_bwd_fused(const float *x, int ldx, const float *in_sca
   const int S = dl3_cdiv(M, A.Mper);
   hipStream_t st = (hipStream_t)stream;
   const int kb = dl3_cdiv(K, 32), nb = dl3_cdiv(N, 32);
-#define DL3_FUSED(KB_, NB_) \
-  if (kb == KB_ && nb == NB_) hipLaunchKernelGGL((pw_bwd_fused_kernel<KB_, NB_>), dim3(S), dim3(256), 0, st, A)
-  DL3_FUSED(1, 1); DL3_FUSED(1, 2); DL3_FUSED(1, 3); DL3_FUSED(1, 4); DL3_FUSED(1, 5);
-  DL3_FUSED(2, 1); DL3_FUSED(3, 1); DL3_FUSED(4, 1); DL3_FUSED(5, 1); DL3_FUSED(2, 2);
+  const bool aux = dx_add != nullptr || (A.sx != nullptr && A.sx != x);
+  DL3_UNSUPPORTED(aux && kb > 2, "pwconv_bwd_fused: a residual addend / sums against another tensor need K <= 64 (K=%d)", K);
+  DL3_CHECK_ARG(!aux || ((!dx_add || (ldadd % 4 == 0 && al16(dx_add))) && (!A.sx || (ldstatx % 4 == 0 && al16(A.sx)))),
+                "pwconv_bwd_fused: dx_add / stat_x must be 16-byte aligned with leading dimensions that are multiples of 4");
+#define DL3_FUSED(KB_, NB_, AUX_) \
+  if (kb == KB_ && nb == NB_ && aux == AUX_) \
+    hipLaunchKernelGGL((pw_bwd_fused_kernel<KB_, NB_, AUX_>), dim3(S), dim3(256), 0, st, A)
+  DL3_FUSED(1, 1, false); DL3_FUSED(1, 2, false); DL3_FUSED(1, 3, false); DL3_FUSED(1, 4, false); DL3_FUSED(1, 5, false);
+  DL3_FUSED(2, 1, false); DL3_FUSED(3, 1, false); DL3_FUSED(4, 1, false); DL3_FUSED(5, 1, false); DL3_FUSED(2, 2, false);
+  DL3_FUSED(1, 1, true); DL3_FUSED(1, 2, true); DL3_FUSED(1, 3, true); DL3_FUSED(1, 4, true); DL3_FUSED(1, 5, true);
+  DL3_FUSED(2, 1, true); DL3_FUSED(2, 2, true);
 #undef DL3_FUSED
   DL3_LAUNCH_CHECK("pwconv_bwd_fused");
   if (!dw) return DL3_OK;  // the caller folds the [S][K][N] slabs (dl3_reduce_partials / _batched)

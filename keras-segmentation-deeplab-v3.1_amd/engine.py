@@ -1332,10 +1332,15 @@ class PwUnit(_ConvBase):
         """both gradients in one pass (dl3_pwconv_bwd_fused): a small weight matrix, many pixel rows, a trainable kernel
         without bias, a data gradient to hand on, whole aligned tensors on both sides"""
         eng, inv, outv = self.eng, self.inv, self.outv
-        return bool(eng.fused_bwd and not eng.fork and self.img_add is None and not self.bias and self.wrow0 == 0
-                    and self.M >= eng.fused_min_rows and eng.trainable(self.wname()) and inv.buf.requires_grad
-                    and inv.ld % 4 == 0 and inv.off % 4 == 0 and outv.ld % 4 == 0 and outv.off % 4 == 0
-                    and eng.lib.dl3_pwconv_bwd_fused_supported(self.M, self.K, self.N))
+        if not (eng.fused_bwd and not eng.fork and self.img_add is None and not self.bias and self.wrow0 == 0
+                and self.M >= eng.fused_min_rows and eng.trainable(self.wname()) and inv.buf.requires_grad
+                and inv.ld % 4 == 0 and inv.off % 4 == 0 and outv.ld % 4 == 0 and outv.off % 4 == 0):
+            return False
+        sup = eng.lib.dl3_pwconv_bwd_fused_supported(self.M, self.K, self.N)
+        # (2: any epilogue; 1 — K > 64 —: no residual addend and sums against the forward input only, i.e. an input with
+        # one consumer that is not a bare residual Add output)
+        ib = inv.buf
+        return sup == 2 or (sup == 1 and ib.expected == 1 and (bool(ib.bns) or id(ib) not in eng.add_of_buf))
 
     def _bwd_fused(self):
         eng, inv, outv = self.eng, self.inv, self.outv

@@ -461,7 +461,8 @@ FUSED_CASES = [
     (2500, 24, 144, None, True, True, 2),        # 24 -> 144: 5 column blocks, sums against the Add's other input
     (2048, 144, 24, 2, True, False, 1),          # 144 -> 24: 5 row blocks of the weight matrix, two dX blocks on one wave
     (1000, 96, 24, 1, False, False, 0),          # plain dY, ReLU mask, no sums
-    (777, 144, 32, 2, True, True, 1),
+    (777, 144, 32, 2, True, False, 1),
+    (1500, 64, 64, 1, True, True, 2),            # K = 64: the widest input that may bring an addend / foreign sums
     (640, 64, 64, None, True, False, 1),         # 2 x 2 blocks
     (20, 16, 96, None, True, True, 1),           # fewer rows than one stage
     (40000, 128, 32, 2, True, False, 1),         # 4 x 1, more stages than workgroups
@@ -473,7 +474,7 @@ def test_pwconv_bwd_fused(L, case):
     """dl3_pwconv_bwd_fused == dl3_pwconv_bwd_weight + dl3_pwconv_bwd_data of the same layer (float64 reference): weight
     gradient (slabs folded by the op or left for the caller), masked data gradient + addend, BatchNorm-backward sums"""
     M, K, N, act, two, has_add, stats = case
-    assert L.dl3_pwconv_bwd_fused_supported(M, K, N) == 1
+    assert L.dl3_pwconv_bwd_fused_supported(M, K, N) == (2 if K <= 64 else 1)
     rng = np.random.default_rng(16)
     g = rng.normal(0, 1, (M, N)).astype(np.float32)
     yraw = rng.normal(0, 1, (M, N)).astype(np.float32)
@@ -519,6 +520,9 @@ def test_pwconv_bwd_fused(L, case):
     call("dl3_reduce_partials", ptr(ws2), S, K * N, ptr(dw2))
     assert np.array_equal(host(dw2), host(dw)) and np.array_equal(host(dx2), host(dx))
     assert L.dl3_pwconv_bwd_fused_supported(M, 192, 32) == 0 and L.dl3_pwconv_bwd_fused_supported(M, 30, 32) == 0
+    if K > 64:   # a residual addend next to a wide input is refused, not mishandled
+        assert L.dl3_pwconv_bwd_fused(*args(ptr(dw), ptr(dx), None, ptr(ws))[:16], ptr(dx2), K,
+                                      *args(ptr(dw), ptr(dx), None, ptr(ws))[18:], stream()) == -4
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 32, 3, 32, 2), (1, 17, 19, 3, 32, 2), (1, 16, 16, 32, 64, 1)])
