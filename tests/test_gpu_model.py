@@ -951,7 +951,7 @@ def test_engine_adam_follows_the_oracle_on_given_gradients(opt):
     iterations + 1, bias correction folded into lr_t) + dl3_adam_step — over FOUR steps on gradients handed in, against
     oracle/dl3_oracle.adam_update in float64 on the same numbers: weights, m and v to fp32 rounding.  With the
     gradients given there is no trajectory noise: a wrong schedule, epsilon placement or moment update shows at 1e-1,
-    the bar is 1e-5 of the update.  (Gradient magnitudes span 1e-9 .. 1e+1: both sides of epsilon.)"""
+    the bar is 1e-4 of the update.  (Gradient magnitudes span 1e-9 .. 1e+1: both sides of epsilon.)"""
     model, params = _build("mobilenetv2", (64, 64, 3), 3, "deeplab")
     _load(model, params)
     eng = model._engine(2, True, dropout=False, use_graph=False)
@@ -972,12 +972,14 @@ def test_engine_adam_follows_the_oracle_on_given_gradients(opt):
     assert eng.iteration == 4
     gp = eng.params[:n].cpu().numpy().astype(np.float64)
     gm, gv = eng.adam_m[:n].cpu().numpy().astype(np.float64), eng.adam_v[:n].cpu().numpy().astype(np.float64)
+    # fp32 arithmetic of the update: (1 - beta_2) evaluated in float32 is 0.0010000467 for beta_2 = 0.999f — 4.7e-5 off,
+    # in this kernel exactly as in TF's float32 graph; it enters v linearly and the step through 1/sqrt(v)
     assert np.abs(gm - m).max() <= 1e-6 * np.abs(m).max() and _l2(gm, m) < 1e-6
-    assert _l2(gv, v) < 1e-6 and np.all(np.abs(gv - v) <= 2e-6 * v + 1e-37)
+    assert _l2(gv, v) < 1e-4 and np.all(np.abs(gv - v) <= 1e-4 * v + 1e-37)
     upd = p - p0
-    # every weight: fp32 representation of the weight itself (4 roundings) + 1e-5 of its update
-    assert np.all(np.abs(gp - p) <= 4 * 6e-8 * np.maximum(np.abs(p), np.abs(p0)) + 1e-5 * np.abs(upd) + 1e-12)
-    assert _l2(gp - p0, upd) < 2e-5, _l2(gp - p0, upd)
+    # every weight: fp32 representation of the weight itself (4 roundings) + 1e-4 of its update
+    assert np.all(np.abs(gp - p) <= 4 * 6e-8 * np.maximum(np.abs(p), np.abs(p0)) + 1e-4 * np.abs(upd) + 1e-12)
+    assert _l2(gp - p0, upd) < 1e-4, _l2(gp - p0, upd)
     # the schedule is visible: the four steps are not four equal steps (decay) and elements below epsilon move less
     big = scale > 1e-2
     small = scale < 1e-8 * max(1.0, o["epsilon"] / 1e-8)

@@ -498,11 +498,13 @@ def test_pwconv_bwd_fused(L, case):
     S = L.dl3_pwconv_bwd_fused_splits(M, K, N)
     nbytes = L.dl3_pwconv_bwd_fused_workspace(M, K, N)
     assert nbytes == S * K * N * 4
+    xd = dev(x)
+    sxd = xd if stats == 1 else dev(other)   # sums against the forward input itself: the SAME device tensor
     args = lambda dwp, dxp, partp, wsp: (
-        ptr(dev(x)), K, ptr(dev(s)) if s is not None else None, ptr(dev(t)) if t is not None else None, a, ptr(dev(g)), N,
+        ptr(xd), K, ptr(dev(s)) if s is not None else None, ptr(dev(t)) if t is not None else None, a, ptr(dev(g)), N,
         ptr(dev(yraw)) if two else None, N, ptr(dev(cA)) if two else None, ptr(dev(cB)) if two else None,
         ptr(dev(cC)) if two else None, ptr(wT), dwp, dxp, K, ptr(dev(add)) if has_add else None, K,
-        ptr(dev(sx)) if stats else None, K, ptr(dev(mean)) if stats else None, ptr(dev(invstd)) if stats else None, partp,
+        ptr(sxd) if stats else None, K, ptr(dev(mean)) if stats else None, ptr(dev(invstd)) if stats else None, partp,
         M, K, N, wsp, nbytes)
     ws = empty(S, K, N)
     dw, dx, part = empty(K, N), empty(M, K), empty(S, K, 2)
