@@ -60,6 +60,9 @@ constexpr int BK = 16;
 #ifndef DL3_STREAM_KT_FWD
 #define DL3_STREAM_KT_FWD 16  // K-tile depth of the forward instantiation (32 measured in round 2: see DESIGN.md)
 #endif
+#ifndef DL3_STREAM_KT_BWD1
+#define DL3_STREAM_KT_BWD1 16  // K-tile depth of the single-tensor bwd-data instantiation (dY materialised, round 4)
+#endif
 #ifndef DL3_WGRAD_WGS_DEFAULT
 #define DL3_WGRAD_WGS_DEFAULT 1024
 #endif
@@ -1371,7 +1374,7 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   do {                                                                                                               \
     if (two) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, true, 16, 0, WN_>), grid, blk, 0, st, A);           \
     else if (fwd) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, DL3_STREAM_KT_FWD, 1, WN_>), grid, blk, 0, st, A); \
-    else hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, 16, 0, WN_>), grid, blk, 0, st, A);              \
+    else hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, DL3_STREAM_KT_BWD1, 0, WN_>), grid, blk, 0, st, A); \
   } while (0)
     if (c.id == 4 && pre_ok(A)) {
       if (two) hipLaunchKernelGGL((pw_gemm_stream_kernel<1, 3, true, 16, 2, 1>), grid, blk, 0, st, A);
