@@ -977,8 +977,9 @@ def test_engine_adam_follows_the_oracle_on_given_gradients(opt):
     assert np.abs(gm - m).max() <= 1e-6 * np.abs(m).max() and _l2(gm, m) < 1e-6
     assert _l2(gv, v) < 1e-4 and np.all(np.abs(gv - v) <= 1e-4 * v + 1e-37)
     upd = p - p0
-    # every weight: fp32 representation of the weight itself (4 roundings) + 1e-4 of its update
-    assert np.all(np.abs(gp - p) <= 4 * 6e-8 * np.maximum(np.abs(p), np.abs(p0)) + 1e-4 * np.abs(upd) + 1e-12)
+    # every weight: fp32 representation of the weight itself (4 roundings) + 1e-4 of the four steps it took (each up to
+    # ~lr; their signs alternate with the random gradients, so the NET update can be far smaller than the steps)
+    assert np.all(np.abs(gp - p) <= 4 * 6e-8 * np.maximum(np.abs(p), np.abs(p0)) + 1e-4 * 4 * o["lr"])
     assert _l2(gp - p0, upd) < 1e-4, _l2(gp - p0, upd)
     # the schedule is visible: the four steps are not four equal steps (decay) and elements below epsilon move less
     big = scale > 1e-2
