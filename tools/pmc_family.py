@@ -44,7 +44,7 @@ def gemm_family(fetch_dir, write_dir, plan):
             for r in csv.DictReader(open(f)):
                 k = r["Kernel_Name"]
                 steps += "adam_kernel" in k
-                if "pw_gemm" in k or "pw_wgrad" in k:
+                if "pw_gemm" in k or "pw_wgrad" in k or "pw_bwd_fused" in k:
                     tot += float(r["Counter_Value"])
         return tot / max(steps, 1), steps
     f, fs = load(fetch_dir)
@@ -53,7 +53,7 @@ def gemm_family(fetch_dir, write_dir, plan):
     fetch, write = 2.0 * f * 1024.0, w * 1024.0
     print(json.dumps({
         "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py --no-graph "
-                "--no-roofline --no-cpu-baseline; per-step sum over the pw_gemm_* / pw_wgrad_* dispatches; FETCH_SIZE "
+                "--no-roofline --no-cpu-baseline; per-step sum over the pw_gemm_* / pw_wgrad_* / pw_bwd_fused_* dispatches; FETCH_SIZE "
                 "doubled (gfx950 correction of MI355X_MICROARCH.md; calibrated on wide coalesced reads — the GEMM A "
                 "operand is read in 16-byte pieces per lane, so treat the absolute as approximate), WRITE_SIZE as reported. "
                 "Algorithmic bytes count every operand once per launch; column tiles of a row tile re-read the activation "
