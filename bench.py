@@ -426,7 +426,7 @@ def compact_leg(args, **over):
     out = {"value": a.batch * steps / dt, "unit": "img/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "batch": a.batch,
            "workload": "%s %dx%d OS=%d head=%s B=%d" % (a.backbone, a.size, a.size, a.os, a.head, a.batch),
            "launches_per_step": len(eng.ops_fwd) + len(eng.ops_bwd) + 1, "device_gb": round(torch.cuda.memory_allocated() / 1e9, 2)}
-    rb = roofline_blocks(insitu_profile(eng, passes=1), a)
+    rb = {} if a.no_roofline else roofline_blocks(insitu_profile(eng, passes=1), a)
     if "roofline" in rb:
         out["gemm_frac_of_fp32_mfma_peak"] = round(rb["roofline"]["frac"], 4)
         out["gemm_share_of_step"] = round(rb["roofline"]["share_of_step"], 4)

@@ -19,15 +19,15 @@ $B --backbone xception --os 8 --batch 32 --steps 10 2>/dev/null | tail -1 >> $L
 $B --backbone xception --os 16 --batch 16 --steps 10 --no-split-leg --no-roofline 2>/dev/null | tail -1 >> $L
 # 3. rocprofv3 kernel stats of the same commands
 cd /tmp
-prof() { tag=$1; shift; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$tag -o bench -- python $REPO/bench.py --no-cpu-baseline --no-split-leg --steps 10 --warmup 3 --plan-json $out/plan_$tag.json "$@" > $out/prof_$tag.log 2>&1; }
+prof() { tag=$1; shift; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$tag -o bench -- python $REPO/bench.py --no-cpu-baseline --no-split-leg --no-legs --steps 10 --warmup 3 --plan-json $out/plan_$tag.json "$@" > $out/prof_$tag.log 2>&1; }
 prof cfg2_b128
 prof cfg3_subpixel_b128 --head subpixel
 prof cfg4_b16 --backbone xception --os 8 --batch 16 --steps 6
 DL3_GEMM_MATH=split prof cfg2_split_b128
 # 4. PMC passes (own runs, --kernel-trace only)
-pmc() { tag=$1; ctr=$2; shift 2; timeout 500 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/pmc_${tag}_$(echo $ctr | tr ' ' '_') -o pmc -- python $REPO/bench.py --no-cpu-baseline --no-split-leg --no-roofline --no-graph --steps 3 --warmup 2 "$@" > $out/pmc_${tag}.log 2>&1; }
+pmc() { tag=$1; ctr=$2; shift 2; timeout 500 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out/pmc_${tag}_$(echo $ctr | tr ' ' '_') -o pmc -- python $REPO/bench.py --no-cpu-baseline --no-split-leg --no-legs --no-roofline --no-graph --steps 3 --warmup 2 "$@" > $out/pmc_${tag}.log 2>&1; }
 for c in FETCH_SIZE WRITE_SIZE; do pmc cfg2_b128 $c; pmc cfg4_b16 $c --backbone xception --os 8 --batch 16; done
-timeout 500 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_cfg2_b128_SQ -o sq -- python $REPO/bench.py --no-cpu-baseline --no-split-leg --no-roofline --no-graph --steps 3 --warmup 2 > $out/pmc_sq.log 2>&1
+timeout 500 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_cfg2_b128_SQ -o sq -- python $REPO/bench.py --no-cpu-baseline --no-split-leg --no-legs --no-roofline --no-graph --steps 3 --warmup 2 > $out/pmc_sq.log 2>&1
 cd $REPO
 # 5. summaries
 for t in cfg2_b128 cfg4_b16; do
