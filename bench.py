@@ -181,7 +181,7 @@ def _pmc_traffic(family, args):
     WRITE_SIZE, separate runs, corrected as MI355X_MICROARCH.md prescribes; tools/collect_profiles.sh +
     tools/pmc_family.py).  It is a constant read from profiles/, not a measurement of this run — the line says so in
     `traffic_source` — and only reported for the configuration it was collected on, else (None, None)."""
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         rel = os.path.join("profiles", "%s_%s_b%d_pmc.json" % (rnd, family, args.batch))
         pmc = os.path.join(ROOT, rel)
         if os.path.exists(pmc) and args.head == "deeplab" and args.size == 512:
