@@ -850,7 +850,31 @@ class Engine:
         self.views[id(l.output)] = v
 
     # ------------------------------------------------------------------ backward lowering
+    def _prune_gradients(self):
+        """which buffers need a gradient at all: those computed from at least one TRAINABLE parameter.  With every layer
+        trainable that is everything but the image; with the notebook's fine-tuning (json 147-155: `l.trainable = False`
+        up to `concat_projection`) it is the tail only, and the backward pass below it — the whole backbone and the ASPP
+        branches — is never lowered: no data gradient would reach a trainable weight through it (round 4; before, the
+        frozen layers merely skipped their weight gradients).  DL3_PRUNE_BWD=0 restores that."""
+        if os.environ.get("DL3_PRUNE_BWD", "1") == "0":
+            return
+        for b in self.bufs:
+            b.requires_grad = False
+        for u in self.units:   # forward order: producers before consumers
+            ins = [w.buf for w in (getattr(u, "inv", None), getattr(u, "a", None), getattr(u, "b", None)) if w is not None]
+            if getattr(u, "img_add", None) is not None:
+                ins.append(u.img_add)
+            own = False
+            if isinstance(u, _ConvBase):
+                names = [u.wname()] + ([u.bias] if getattr(u, "bias", None) else [])
+                if u.bn is not None:
+                    names += [u.bn.name + "/gamma:0", u.bn.name + "/beta:0"]
+                own = any(self.trainable(n) for n in names)
+            if own or any(b.requires_grad for b in ins):
+                u.outv.buf.requires_grad = True   # (a Concatenate buffer: any of its producers)
+
     def _lower_backward(self):
+        self._prune_gradients()
         v = self.logits_view
         buf = v.buf
         M, C = buf.M, v.C
@@ -897,7 +921,8 @@ class Engine:
         if n:
             self.dy_buf = self.empty(n)
         for u in reversed(self.units):
-            u.bwd()
+            if u.outv.buf.requires_grad:   # (else: no trainable parameter at or above this unit)
+                u.bwd()
         if self._transposes:
             # every W -> WT of the backward pass in ONE launch at its start (54 tiny launches otherwise)
             rows, t0 = [], 0

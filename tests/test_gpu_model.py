@@ -985,3 +985,87 @@ def test_engine_adam_follows_the_oracle_on_given_gradients(opt):
     big = scale > 1e-2
     small = scale < 1e-8 * max(1.0, o["epsilon"] / 1e-8)
     assert np.abs(upd[big]).mean() > o["lr"] / (1 + 3 * o["decay"]) and np.abs(upd[small]).mean() < 0.5 * np.abs(upd[big]).mean()
+
+
+def test_notebook_fine_tuning_freezes_the_backbone(monkeypatch):
+    """segmentation.ipynb json 147-155 ("fine-tune model (train only last conv layers)"): every layer before
+    `concat_projection` gets `trainable = False`.  Keras 2.2.4 semantics: frozen weights never move, a frozen
+    BatchNormalization still normalises with batch statistics in the training phase but its moving statistics stay; the
+    trainable tail — concat_projection(+BN), the logits convolution — trains as always.  Checked against the oracle's
+    train_steps(frozen=...) over two steps, and: the backward pass below the first trainable parameter is not lowered at
+    all (round 4), with bit-identical gradients for what does train."""
+    from dl3_amd.optimizers import Adam
+    classes, B, shape = 3, 3, (64, 64, 3)
+    model, params = _build("mobilenetv2", shape, classes, "deeplab")
+    rng = np.random.default_rng(41)
+    kw = dict(backbone="mobilenetv2", input_shape=shape, classes=classes, OS=16, head="deeplab")
+    params = O.calibrate_bn(params, rng.integers(0, 256, (B,) + shape).astype(np.float32), **kw)
+    _load(model, params)
+    flag = 0
+    for l in model.layers:              # the notebook's loop, verbatim in effect
+        l.trainable = False
+        if l.name == "concat_projection":
+            flag = 1
+        if flag:
+            l.trainable = True
+    frozen = {n for l in model.layers if not l.trainable for n in l.weights}
+    live = {n for l in model.layers if l.trainable for n in l.weights}
+    assert "concat_projection/kernel:0" in live and "custom_logits_semantic/bias:0" in live and "aspp0/kernel:0" in frozen
+    o = dict(O.ADAM_DEFAULTS, lr=1e-4)
+    model.compile(optimizer=Adam(**o))
+    batches = []
+    for _ in range(2):
+        x = rng.integers(0, 256, (B,) + shape).astype(np.float32)
+        y = rng.integers(0, classes + 1, (B, shape[0] * shape[1])).astype(np.float32)
+        sw = ((y < classes) * rng.uniform(0.5, 2.0, y.shape)).astype(np.float32)
+        batches.append((x, y, sw))
+    losses = [model.train_on_batch(x, y[..., None], sw, dropout=False) for x, y, sw in batches]
+    eng = model._active
+    # nothing below concat_projection is differentiated: a handful of launches instead of ~160
+    names = [op[0] for op in eng.ops_bwd]
+    assert len(names) < 30 and not any(n.startswith("dl3_dwconv3x3") for n in names), names
+    assert sum(n.startswith("dl3_pwconv_bwd_data") for n in names) == 1   # logits -> concat_projection's output only
+    g_pruned = {n: eng.grad_of(n).copy() for n in live if "/moving_" not in n}
+    eng.sync_all_to_host()
+    got = {}
+    for l in model.layers:
+        got.update(l.weights)
+    for n in frozen:
+        assert np.array_equal(got[n], params[n]), n        # kernels, gamma / beta AND moving statistics of frozen layers
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    b64 = [tuple(a.astype(np.float64) for a in b) for b in batches]
+    l64, w64, _ = O.train_steps(p64, b64, opt=o, frozen=frozen, **kw)
+    l32, w32, _ = O.train_steps(params, batches, opt=o, frozen=frozen, **kw)
+    print("losses gpu", losses, "float64", l64, "numpy-fp32", l32)
+    assert abs(losses[0] - l64[0]) < 1e-4 * abs(l64[0])
+    assert abs(losses[1] - l64[1]) <= max(2e-4 * abs(l64[1]), 2.0 * abs(l32[1] - l64[1]))
+    for n in sorted(live):
+        ref = w64[n]
+        g = np.asarray(got[n], np.float64).reshape(ref.shape)
+        if "/moving_" in n:
+            assert np.abs(g - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-3), n
+            assert not np.array_equal(got[n], params[n]), n   # a trainable BatchNorm's statistics do move
+            continue
+        upd = ref - p64[n]
+        err, y32 = _l2(g - p64[n], upd), _l2(np.asarray(w32[n], np.float64).reshape(ref.shape) - p64[n], upd)
+        print("   %-44s update rel-L2 gpu %.2e numpy-fp32 %.2e" % (n, err, y32))
+        assert err <= max(2e-2, 2.0 * y32), (n, err, y32)
+    # the same step with the whole backward lowered (DL3_PRUNE_BWD=0): identical gradients for everything that trains
+    monkeypatch.setenv("DL3_PRUNE_BWD", "0")
+    _load(model, {k: got[k] for k in got})
+    full = model._engine(B, True, dropout=False, use_graph=False, seed=77)
+    assert len(full.ops_bwd) > 100
+    monkeypatch.delenv("DL3_PRUNE_BWD")
+    lean = model._engine(B, True, dropout=False, use_graph=False, seed=78)
+    x, y, sw = batches[1]
+    res = []
+    for e in (full, lean):
+        e.activate()
+        e.sync_all_to_device()
+        e.set_input(x)
+        e.set_targets(y, sw)
+        e.fwd_bwd()
+        torch.cuda.synchronize()
+        res.append({n: e.grad_of(n).copy() for n in g_pruned})
+    for n in g_pruned:
+        assert np.array_equal(res[0][n], res[1][n]), n
