@@ -79,6 +79,16 @@ int dl3_dwconv3x3_bwd(const float *g, const float *yraw, const float *cA, const 
                       const float *x_invstd, float *dstat_partial, float *dw_partial, int N, int H, int W,
                       int C, int stride, int rate, int pad_t, int pad_l, int Ho, int Wo, int impl, void *stream);
 
+/* the same launch with the BatchNorm-backward sums of dx taken against ANOTHER tensor: dstat_partial = sum(dx),
+ * sum(dx * (stat_x - x_mean) * x_invstd), stat_x [N,H,W,C] — the other input of the residual Add whose output gradient
+ * this launch completes (Xception's `sum` shortcuts, deeplabv3p.py:147-149: the gradient reaches the block's last
+ * pointwise BatchNorm unchanged, so its sums need no pass of their own; round 4).  March kernel only (stride 1, SAME). */
+int dl3_dwconv3x3_bwd_sx(const float *g, const float *yraw, const float *cA, const float *cB, const float *cC,
+                         const float *x, const float *in_scale, const float *in_shift, int in_act, const float *w,
+                         float *dx, const float *dx_add, const float *stat_x, const float *x_mean,
+                         const float *x_invstd, float *dstat_partial, float *dw_partial, int N, int H, int W, int C,
+                         int stride, int rate, int pad_t, int pad_l, int Ho, int Wo, int impl, void *stream);
+
 /* ---- Conv2D 1x1 = GEMM on fp32 MFMA (deeplabv3p.py:78-79,:175,:194,:377,:385,:406,:420,:438) -- */
 #define DL3_MATH_ENV (-1)  /* follow the environment (DL3_GEMM_MATH=split selects split math); the default */
 #define DL3_MATH_F32 0     /* v_mfma_f32_32x32x2_f32 */

@@ -295,7 +295,11 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
     const float *__restrict__ sc, const float *__restrict__ sh, int act, const float *__restrict__ w,
     float *__restrict__ dx, const float *__restrict__ dx_add, const float *__restrict__ xmean,
     const float *__restrict__ xinvstd, float *__restrict__ dpart, float *__restrict__ wpart, int H, int W, int C,
-    int r, int nchunk, int TK, int nxseg, int nphase, int ppb, int nslab, int ny, int N, int xcd, int prows) {
+    int r, int nchunk, int TK, int nxseg, int nphase, int ppb, int nslab, int ny, int N, int xcd, int prows,
+    const float *__restrict__ sx) {
+  // sx (nullable, round 4): the BatchNorm-backward sums of dx are taken against x_hat of THIS tensor instead of the
+  // forward input — the other input of the residual Add whose output gradient this launch completes (Xception's `sum`
+  // shortcuts: the gradient reaches the block's last pointwise BatchNorm unchanged, Engine.alias_stats_target)
   __shared__ float red[4 * 8 * 36];
   const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
   DwTile tile;
@@ -368,12 +372,14 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
     ld_e(ks, e_cur, ok_cur);
     ld_e(ks + 1, e_next, ok_next);
     for (int kg = ks; kg <= ke; kg += R) {
-      f32x4 l[R], m[R], rr[R], e_new[R];
+      f32x4 l[R], m[R], rr[R], e_new[R], sxv[R];
       bool ok_new[R];
 #pragma unroll
       for (int j = 0; j < R; j++) {
         ld_dd((kg + j <= ke) ? kg + j : -1, l[j], m[j], rr[j]);
         ld_e(kg + j + 2, e_new[j], ok_new[j]);
+        // slot j of the group finishes dx row kg + j - 1: its x_hat operand (own column, clamped row: always in bounds)
+        if (sx) sxv[j] = ld4(sx + imgc + ((size_t)(a + min(max(kg + j - 1, 0), Kc) * r) * W + xc) * C);
       }
 #pragma unroll
       for (int j = 0; j < R; j++) {
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
           if (dx_add) out += ld4(dx_add + off);
           st4_nt(dx + off, out);
           s1 += out;
-          s2 += out * ((e_prev - mu) * is);
+          s2 += out * (((sx ? sxv[j] : e_prev) - mu) * is);
         }
         accA = accB + h1;
         accB = h2;
@@ -412,7 +418,7 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
       if (dx_add) out += ld4(dx_add + off);
       st4_nt(dx + off, out);
       s1 += out;
-      s2 += out * ((e_prev - mu) * is);
+      s2 += out * (((sx ? ld4(sx + off) : e_prev) - mu) * is);
     }
   }
   }  // phases of this workgroup
@@ -844,20 +850,22 @@ extern "C" int dl3_dwconv3x3_fwd(const float *x, const float *in_scale, const fl
   return DL3_OK;
 }
 
-extern "C" int dl3_dwconv3x3_bwd(const float *g, const float *yraw, const float *cA, const float *cB,
+static int dwconv3x3_bwd_impl(const float *g, const float *yraw, const float *cA, const float *cB,
                                  const float *cC, const float *x, const float *in_scale, const float *in_shift,
                                  int in_act, const float *w, float *dx, const float *dx_add,
                                  const float *x_mean, const float *x_invstd, float *dstat_partial,
                                  float *dw_partial, int N, int H, int W, int C, int stride, int rate, int pad_t,
-                                 int pad_l, int Ho, int Wo, int impl, void *stream) {
+                                 int pad_l, int Ho, int Wo, int impl, const float *stat_x, void *stream) {
   int rc = dw_check(N, H, W, C, stride, rate, Ho, Wo);
   if (rc) return rc;
+  DL3_CHECK_ARG(!stat_x || dstat_partial, "dwconv3x3_bwd_sx: stat_x without dstat_partial");
   DL3_CHECK_ARG(g && x && w && dw_partial, "dwconv3x3_bwd: null pointer");
   DL3_CHECK_ARG(!cA || (yraw && cB && cC), "dwconv3x3_bwd: cA needs yraw, cB, cC");
   DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "dwconv3x3_bwd: scale/shift must come together");
   DL3_CHECK_ARG(!dstat_partial || (dx && x_mean && x_invstd), "dwconv3x3_bwd: dstat needs dx, x_mean, x_invstd");
   const int im = resolve_impl(impl, H, W, stride, rate, pad_t, pad_l, Ho, Wo);
   DL3_UNSUPPORTED(im < 0, "dwconv3x3_bwd: march impl needs stride 1, pad == rate, Ho == H, Wo == W");
+  DL3_UNSUPPORTED(stat_x && im != DL3_IMPL_MARCH, "dwconv3x3_bwd_sx: sums against another tensor need the march kernel (stride 1, SAME)");
   DwPlan p = dw_plan(N, H, W, C, stride, rate, Ho, Wo, im, true);
   hipStream_t st = (hipStream_t)stream;
   // (partial rows beyond this grid's: zeroed by the kernels, see pad_stat_partial)
@@ -866,7 +874,7 @@ extern "C" int dl3_dwconv3x3_bwd(const float *g, const float *yraw, const float 
     dim3 grid(march_grid(p, N));
     hipLaunchKernelGGL(dw_march_bwd, grid, dim3(256), 0, st, g, yraw, cA, cB, cC, x, in_scale, in_shift, in_act,
                        w, dx, dx_add, x_mean, x_invstd, dstat_partial, dw_partial, H, W, C, rate, p.nchunk, p.TK,
-                       p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), Pmax);
+                       p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), Pmax, stat_x);
   } else {
     DwGeom G{N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo, Pmax};
     dim3 grid(p.nslab, p.PB);
@@ -880,4 +888,25 @@ extern "C" int dl3_dwconv3x3_bwd(const float *g, const float *yraw, const float 
   }
   DL3_LAUNCH_CHECK("dwconv3x3_bwd");
   return DL3_OK;
+}
+
+extern "C" int dl3_dwconv3x3_bwd(const float *g, const float *yraw, const float *cA, const float *cB,
+                                 const float *cC, const float *x, const float *in_scale, const float *in_shift,
+                                 int in_act, const float *w, float *dx, const float *dx_add,
+                                 const float *x_mean, const float *x_invstd, float *dstat_partial,
+                                 float *dw_partial, int N, int H, int W, int C, int stride, int rate, int pad_t,
+                                 int pad_l, int Ho, int Wo, int impl, void *stream) {
+  return dwconv3x3_bwd_impl(g, yraw, cA, cB, cC, x, in_scale, in_shift, in_act, w, dx, dx_add, x_mean, x_invstd,
+                            dstat_partial, dw_partial, N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo, impl, nullptr, stream);
+}
+
+extern "C" int dl3_dwconv3x3_bwd_sx(const float *g, const float *yraw, const float *cA, const float *cB,
+                                    const float *cC, const float *x, const float *in_scale, const float *in_shift,
+                                    int in_act, const float *w, float *dx, const float *dx_add, const float *stat_x,
+                                    const float *x_mean, const float *x_invstd, float *dstat_partial,
+                                    float *dw_partial, int N, int H, int W, int C, int stride, int rate, int pad_t,
+                                    int pad_l, int Ho, int Wo, int impl, void *stream) {
+  DL3_CHECK_ARG(stat_x, "dwconv3x3_bwd_sx: stat_x is NULL (use dl3_dwconv3x3_bwd)");
+  return dwconv3x3_bwd_impl(g, yraw, cA, cB, cC, x, in_scale, in_shift, in_act, w, dx, dx_add, x_mean, x_invstd,
+                            dstat_partial, dw_partial, N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo, impl, stat_x, stream);
 }

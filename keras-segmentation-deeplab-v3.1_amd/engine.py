@@ -1494,13 +1494,28 @@ class DwUnit(_ConvBase):
         wpart = eng.empty(self.P * 9 * C)
         gout = add = dpart = None
         need_stat = False
+        tgt = None
         if ibuf.requires_grad:
             gout, add, last = eng.contrib_kernel(ibuf)
             need_stat = last and bool(ibuf.bns)
             dpart = eng.empty(self.P * C * 2) if need_stat else None
-        eng.op(eng.ops_bwd, "dl3_dwconv3x3_bwd", g, y, cA, cB, cC, inv.p(), s, t, a, eng.wptr(self.wname()),
-               ptr(gout), ptr(add), ibuf.vptr(V_MEAN) if need_stat else None,
-               ibuf.vptr(V_INVSTD) if need_stat else None, ptr(dpart), ptr(wpart), *self.geom, eng.dw_impl)
+            B_, H, W, _, stride, rate, pt, pl, Ho, Wo = self.geom
+            if (last and not ibuf.bns and stride == 1 and Ho == H and Wo == W and pt == rate and pl == rate
+                    and eng.dw_impl in (IMPL_AUTO, capi.IMPL_MARCH) and os.environ.get("DL3_DW_ALIAS", "1") != "0"):
+                # this launch completes the gradient of a residual Add's output (Xception's `sum` shortcuts): the sums of the
+                # BatchNorm it reaches unchanged through the Add ride along (round 4; PwUnit.bwd does the same for
+                # MobileNetV2's blocks) instead of a dl3_grad_finish pass over g and y
+                tgt = eng.alias_stats_target(ibuf)
+        if tgt is not None:
+            dpart = eng.empty(self.P * C * 2)
+            eng.op(eng.ops_bwd, "dl3_dwconv3x3_bwd_sx", g, y, cA, cB, cC, inv.p(), s, t, a, eng.wptr(self.wname()),
+                   ptr(gout), ptr(add), ptr(tgt.t), tgt.vptr(V_MEAN), tgt.vptr(V_INVSTD), ptr(dpart), ptr(wpart),
+                   *self.geom, eng.dw_impl)
+            eng.prestat[id(tgt)] = (dpart, self.P, C)
+        else:
+            eng.op(eng.ops_bwd, "dl3_dwconv3x3_bwd", g, y, cA, cB, cC, inv.p(), s, t, a, eng.wptr(self.wname()),
+                   ptr(gout), ptr(add), ibuf.vptr(V_MEAN) if need_stat else None,
+                   ibuf.vptr(V_INVSTD) if need_stat else None, ptr(dpart), ptr(wpart), *self.geom, eng.dw_impl)
         eng.fold(ptr(wpart), self.P, 9 * C, eng.gptr(self.wname()))
         if need_stat:
             eng.finish_bn_bwd(ibuf, dpart, self.P, C)

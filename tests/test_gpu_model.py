@@ -993,7 +993,7 @@ def test_notebook_fine_tuning_freezes_the_backbone(monkeypatch):
     BatchNormalization still normalises with batch statistics in the training phase but its moving statistics stay; the
     trainable tail — concat_projection(+BN), the logits convolution — trains as always.  Checked against the oracle's
     train_steps(frozen=...) over two steps, and: the backward pass below the first trainable parameter is not lowered at
-    all (round 4), with bit-identical gradients for what does train."""
+    all (round 4), with the same gradients (to fp32 rounding) for what does train."""
     from dl3_amd.optimizers import Adam
     classes, B, shape = 3, 3, (64, 64, 3)
     model, params = _build("mobilenetv2", shape, classes, "deeplab")
@@ -1067,5 +1067,7 @@ def test_notebook_fine_tuning_freezes_the_backbone(monkeypatch):
         e.fwd_bwd()
         torch.cuda.synchronize()
         res.append({n: e.grad_of(n).copy() for n in g_pruned})
+    # (not bit for bit: with the data gradient lowered the layer's dY is written once by its weight-gradient launch and
+    # the per-image column sums are taken of that rounded tensor — one fp32 rounding apart)
     for n in g_pruned:
-        assert np.array_equal(res[0][n], res[1][n]), n
+        assert _l2(res[1][n], res[0][n]) < 1e-5, (n, _l2(res[1][n], res[0][n]))

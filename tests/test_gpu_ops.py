@@ -129,6 +129,47 @@ def test_dwconv_bwd(L, case):
     assert relerr(s2, (dx_ref * (x - mean) * invstd).sum((0, 1, 2))) < 1e-3
 
 
+@pytest.mark.parametrize("case", [(2, 16, 16, 96, 1, 2, None, 0, 1), (1, 33, 33, 1536, 1, 4, None, 0, 1),
+                                  (3, 64, 64, 144, 1, 1, None, 0, 2), (1, 64, 64, 96, 1, 12, None, 2, 1),
+                                  (2, 17, 19, 40, 1, 3, None, 0, None)])
+def test_dwconv_bwd_sums_against_another_tensor(L, case):
+    """dl3_dwconv3x3_bwd_sx (round 4): the same gradients bit for bit, the second BatchNorm-backward sum taken against
+    x_hat of ANOTHER tensor (the other input of the residual Add whose output gradient the launch completes)"""
+    N, H, W, C, stride, rate, pads, impl, act = case
+    rng = np.random.default_rng(18)
+    Ho, Wo, pt, pl = _dw_geom(H, W, stride, rate, pads)
+    x = rng.normal(0, 1, (N, H, W, C)).astype(np.float32)
+    other = rng.normal(0, 1, (N, H, W, C)).astype(np.float32)
+    w = rng.normal(0, 0.3, (3, 3, C)).astype(np.float32)
+    g = rng.normal(0, 1, (N, Ho, Wo, C)).astype(np.float32)
+    yraw = rng.normal(0, 1, (N, Ho, Wo, C)).astype(np.float32)
+    cA, cB, cC = [rng.normal(0, 1, C).astype(np.float32) for _ in range(3)]
+    add = rng.normal(0, 1, (N, H, W, C)).astype(np.float32)
+    mean = rng.normal(0, 1, C).astype(np.float32)
+    invstd = rng.uniform(0.5, 2, C).astype(np.float32)
+    s, t, a = _xform(rng, C, act)
+    P = L.dl3_dwconv3x3_partials(N, H, W, C, stride, rate, Ho, Wo, impl)
+    head = (ptr(dev(g)), ptr(dev(yraw)), ptr(dev(cA)), ptr(dev(cB)), ptr(dev(cC)), ptr(dev(x)),
+            ptr(dev(s)) if s is not None else None, ptr(dev(t)) if t is not None else None, a, ptr(dev(w)))
+    tail = (ptr(dev(mean)), ptr(dev(invstd)))
+    geom = (N, H, W, C, stride, rate, pt, pl, Ho, Wo, impl)
+    dx0, dp0, wp0 = empty(N, H, W, C), empty(P, C, 2), empty(P, 9, C)
+    dx1, dp1, wp1 = empty(N, H, W, C), empty(P, C, 2), empty(P, 9, C)
+    addd = dev(add)
+    call("dl3_dwconv3x3_bwd", *head, ptr(dx0), ptr(addd), *tail, ptr(dp0), ptr(wp0), *geom)
+    call("dl3_dwconv3x3_bwd_sx", *head, ptr(dx1), ptr(addd), ptr(dev(other)), *tail, ptr(dp1), ptr(wp1), *geom)
+    assert np.array_equal(host(dx0), host(dx1)) and np.array_equal(host(wp0), host(wp1))
+    d0, d1 = host(dp0).reshape(P, C, 2), host(dp1).reshape(P, C, 2)
+    assert np.array_equal(d0[:, :, 0], d1[:, :, 0])                      # sum(dx): the same
+    dxv = host(dx1).astype(np.float64)
+    s2 = d1[:, :, 1].astype(np.float64).sum(0)
+    assert relerr(s2, (dxv * (other - mean) * invstd).sum((0, 1, 2))) < 1e-3
+    # the gather kernels do not take it: refused, not ignored
+    if stride == 1:
+        assert L.dl3_dwconv3x3_bwd_sx(*head, ptr(dx1), ptr(addd), ptr(dev(other)), *tail, ptr(dp1), ptr(wp1),
+                                      N, H, W, C, stride, rate, pt, pl, Ho, Wo, 1, stream()) == -4
+
+
 @pytest.mark.parametrize("ppb", [2, 3, 5])
 def test_dwconv_phases_per_workgroup(L, ppb, monkeypatch):
     """march kernels with a forced number of row phases per workgroup (uneven last group, rate 5 on 16 rows)"""
