@@ -140,11 +140,12 @@ def _work(name, a):
         fam = "dw_dilated" if (rate > 1 and stride == 1) else "dw"
         return (fam, "fwd %dx%dx%dx%d s%d r%d" % (N, H, W, C, stride, rate), 2.0 * 9 * N * Ho * Wo * C,
                 4.0 * (N * H * W * C + N * Ho * Wo * C + 9 * C))
-    if name == "dl3_dwconv3x3_bwd":
-        N, H, W, C, stride, rate, Ho, Wo = a[16], a[17], a[18], a[19], a[20], a[21], a[24], a[25]
+    if name in ("dl3_dwconv3x3_bwd", "dl3_dwconv3x3_bwd_sx"):
+        o = 1 if name.endswith("_sx") else 0   # (_sx: one more operand, stat_x, behind dx_add)
+        N, H, W, C, stride, rate, Ho, Wo = a[16 + o], a[17 + o], a[18 + o], a[19 + o], a[20 + o], a[21 + o], a[24 + o], a[25 + o]
         fam = "dw_dilated" if (rate > 1 and stride == 1) else "dw"
         out_e, in_e = N * Ho * Wo * C, N * H * W * C
-        by = out_e * (2 if nz(a[1]) else 1) + in_e * (1 + (1 if nz(a[10]) else 0) + (1 if nz(a[11]) else 0)) + 18 * C
+        by = out_e * (2 if nz(a[1]) else 1) + in_e * (1 + (1 if nz(a[10]) else 0) + (1 if nz(a[11]) else 0) + o) + 18 * C
         return fam, "bwd %dx%dx%dx%d s%d r%d" % (N, H, W, C, stride, rate), 2.0 * 2 * 9 * out_e, 4.0 * by
     if name == "dl3_reduce_partials_batched":
         # every weight-gradient slab fold of the pass in one launch: charged to the GEMM family (no FLOPs), as the fold
