@@ -135,9 +135,8 @@ def _work(name, a):
         by = M * K + M * N * (2 if nz(a[7]) else 1) + K * N + M * K * (1 + (1 if nz(a[16]) else 0) +
                                                                       (1 if (nz(a[18]) and a[18] != a[0]) else 0))
         return "gemm", "bwd-fused M=%d K=%d N=%d" % (M, K, N), 4.0 * M * K * N, 4.0 * by
-    if name in ("dl3_dwconv3x3_fwd", "dl3_dwconv3x3_fwd_bias"):
-        o = 1 if name.endswith("_bias") else 0
-        N, H, W, C, stride, rate, Ho, Wo = a[6 + o], a[7 + o], a[8 + o], a[9 + o], a[10 + o], a[11 + o], a[14 + o], a[15 + o]
+    if name == "dl3_dwconv3x3_fwd":
+        N, H, W, C, stride, rate, Ho, Wo = a[6], a[7], a[8], a[9], a[10], a[11], a[14], a[15]
         fam = "dw_dilated" if (rate > 1 and stride == 1) else "dw"
         return (fam, "fwd %dx%dx%dx%d s%d r%d" % (N, H, W, C, stride, rate), 2.0 * 9 * N * Ho * Wo * C,
                 4.0 * (N * H * W * C + N * Ho * Wo * C + 9 * C))

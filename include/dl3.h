@@ -68,12 +68,6 @@ int dl3_dwconv3x3_partials(int N, int H, int W, int C, int stride, int rate, int
 int dl3_dwconv3x3_fwd(const float *x, const float *in_scale, const float *in_shift, int in_act,
                       const float *w, float *y, int N, int H, int W, int C, int stride, int rate,
                       int pad_t, int pad_l, int Ho, int Wo, float *stat_partial, int impl, void *stream);
-/* the same with a per-channel addend on the output, y += bias[c] (nullable) — DepthwiseConv2D has no bias on the path
- * (use_bias=False, deeplabv3p.py:74,:187); the slot carries -moving_mean of the frozen BatchNorm behind the layer
- * (dl3_bn_frozen_centered, round 4) */
-int dl3_dwconv3x3_fwd_bias(const float *x, const float *in_scale, const float *in_shift, int in_act, const float *w,
-                           const float *bias, float *y, int N, int H, int W, int C, int stride, int rate, int pad_t,
-                           int pad_l, int Ho, int Wo, float *stat_partial, int impl, void *stream);
 /* fused bwd-data + bwd-weight.
  *   dY = cA*g + cB*yraw + cC                                   [N,Ho,Wo,C]
  *   dw_partial[p][i][j][c] = partial sum_{n,oy,ox} T(x)[...tap...] * dY

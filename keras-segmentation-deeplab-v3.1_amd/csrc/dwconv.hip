@@ -95,8 +95,7 @@ __global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x,
                                                     const float *__restrict__ w, float *__restrict__ y,
                                                     int H, int W, int C, int r, int nchunk, int TK, int nxseg,
                                                     int nphase, int ppb, int nslab, int ny, int N, int xcd,
-                                                    float *__restrict__ part, int prows,
-                                                    const float *__restrict__ bias) {
+                                                    float *__restrict__ part, int prows) {
   __shared__ float red[4 * 8 * 8];
   const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
   DwTile tile;
@@ -110,9 +109,6 @@ __global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x,
 #pragma unroll
   for (int i = 0; i < 9; i++) wv[i] = ld4(w + (size_t)i * C + min(c, C - 4));
   if (sc) { s = ld4(sc + min(c, C - 4)); t = ld4(sh + min(c, C - 4)); }
-  // per-channel addend of the output (nullable): -moving_mean of the frozen BatchNorm behind this layer (round 4,
-  // dl3_bn_frozen_centered: the tensor then holds y - mean and consumers read scale * (y - mean) + beta)
-  const f32x4 bv = bias ? ld4(bias + min(c, C - 4)) : splat4(0.f);
   f32x4 s1 = splat4(0.f), s2 = splat4(0.f);
   // a workgroup owns `ppb` consecutive row phases (large rates leave only 2-3 rows per phase: several phases per
   // workgroup amortise the prologue) or, for ppb == 1, one chunk of TK rows of one phase
@@ -163,7 +159,7 @@ __global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x,
       f32x4 h0 = wv[0] * l[j] + wv[1] * m[j] + wv[2] * rr[j];
       f32x4 h1 = wv[3] * l[j] + wv[4] * m[j] + wv[5] * rr[j];
       f32x4 h2 = wv[6] * l[j] + wv[7] * m[j] + wv[8] * rr[j];
-      f32x4 out = (accA + h2) + bv;
+      f32x4 out = accA + h2;
       if (active && k - 1 >= k0 && k - 1 < k1) {
         st4_nt(ybase + ((size_t)(a + (k - 1) * r) * W + xx) * C, out);
         s1 += out;
@@ -174,10 +170,9 @@ __global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x,
     }
   }
   if (!bot_halo && k0 < k1 && active) {  // last row of the phase: no row below contributes
-    const f32x4 out = accA + bv;
-    st4_nt(ybase + ((size_t)(a + (k1 - 1) * r) * W + xx) * C, out);
-    s1 += out;
-    s2 += out * out;
+    st4_nt(ybase + ((size_t)(a + (k1 - 1) * r) * W + xx) * C, accA);
+    s1 += accA;
+    s2 += accA * accA;
   }
   }  // phases of this workgroup
   if (part) {
@@ -205,15 +200,13 @@ __global__ __launch_bounds__(256) void dw_march2_fwd(const float *__restrict__ x
                                                      const float *__restrict__ w, float *__restrict__ y,
                                                      int H, int W, int C, int r, int nchunk, int TK, int nxseg,
                                                      int nphase, int ppb, int nslab, int ny, int N, int xcd,
-                                                     float *__restrict__ part, int prows,
-                                                     const float *__restrict__ bias) {
+                                                     float *__restrict__ part, int prows) {
   __shared__ float red[4 * 8 * 8];
   const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
   DwTile tile;
   if (!dw_tile(nxseg, nslab, ny, N, xcd, tile)) return;
   const int xs = tile.xs, slab = tile.slab, pc = tile.pc, n = tile.n;
   const int c = slab * 32 + cq * 4;
-  const f32x4 bv = bias ? ld4(bias + min(c, C - 4)) : splat4(0.f);  // see dw_march_fwd
   const int xa = xs * 64 + (pl / r) * 2 * r + pl % r, xb = xa + r;
   const bool ca = c < C;
   const bool act_a = ca && xa < W, act_b = ca && xb < W;
@@ -265,7 +258,7 @@ __global__ __launch_bounds__(256) void dw_march2_fwd(const float *__restrict__ x
         const f32x4 b0 = wv[0] * p[j][1] + wv[1] * p[j][2] + wv[2] * p[j][3];
         const f32x4 b1 = wv[3] * p[j][1] + wv[4] * p[j][2] + wv[5] * p[j][3];
         const f32x4 b2 = wv[6] * p[j][1] + wv[7] * p[j][2] + wv[8] * p[j][3];
-        const f32x4 oa = (aA + a2) + bv, ob = (bA + b2) + bv;
+        const f32x4 oa = aA + a2, ob = bA + b2;
         if (k - 1 >= k0 && k - 1 < k1) {
           float *orow = ybase + (size_t)(a + (k - 1) * r) * W * C;
           if (act_a) { st4_nt(orow + (size_t)xa * C, oa); s1 += oa; s2 += oa * oa; }
@@ -277,9 +270,8 @@ __global__ __launch_bounds__(256) void dw_march2_fwd(const float *__restrict__ x
     }
     if (!bot_halo && k0 < k1) {  // last row of the phase: no row below contributes
       float *orow = ybase + (size_t)(a + (k1 - 1) * r) * W * C;
-      const f32x4 oa = aA + bv, ob = bA + bv;
-      if (act_a) { st4_nt(orow + (size_t)xa * C, oa); s1 += oa; s2 += oa * oa; }
-      if (act_b) { st4_nt(orow + (size_t)xb * C, ob); s1 += ob; s2 += ob * ob; }
+      if (act_a) { st4_nt(orow + (size_t)xa * C, aA); s1 += aA; s2 += aA * aA; }
+      if (act_b) { st4_nt(orow + (size_t)xb * C, bA); s1 += bA; s2 += bA * bA; }
     }
   }
   if (part) {
@@ -467,12 +459,11 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
 __global__ __launch_bounds__(256) void dw_gather_fwd(const float *__restrict__ x, const float *__restrict__ sc,
                                                      const float *__restrict__ sh, int act,
                                                      const float *__restrict__ w, float *__restrict__ y, DwGeom G,
-                                                     float *__restrict__ part, const float *__restrict__ bias) {
+                                                     float *__restrict__ part) {
   __shared__ float red[4 * 8 * 8];
   const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
   const int c = blockIdx.x * 32 + cq * 4;
   const bool cok = c < G.C;
-  const f32x4 bv = (bias && cok) ? ld4(bias + c) : splat4(0.f);  // see dw_march_fwd
   f32x4 wv[9], s = splat4(1.f), t = splat4(0.f);
 #pragma unroll
   for (int i = 0; i < 9; i++) wv[i] = cok ? ld4(w + (size_t)i * G.C + c) : splat4(0.f);
@@ -500,7 +491,6 @@ __global__ __launch_bounds__(256) void dw_gather_fwd(const float *__restrict__ x
     }
 #pragma unroll
     for (int q = 0; q < 9; q++) acc += (wv[q] * splat4(okf[q])) * dl3_act4(s * tap[q] + t, act);
-    acc += bv;
     st4_nt(y + (size_t)p * G.C + c, acc);
     s1 += acc;
     s2 += acc * acc;
@@ -827,9 +817,9 @@ static int dw_check(int N, int H, int W, int C, int stride, int rate, int Ho, in
   return DL3_OK;
 }
 
-static int dwconv3x3_fwd_impl(const float *x, const float *in_scale, const float *in_shift, int in_act,
-                                 const float *w, const float *bias, float *y, int N, int H, int W, int C, int stride,
-                                 int rate, int pad_t, int pad_l, int Ho, int Wo, float *stat_partial, int impl,
+extern "C" int dl3_dwconv3x3_fwd(const float *x, const float *in_scale, const float *in_shift, int in_act,
+                                 const float *w, float *y, int N, int H, int W, int C, int stride, int rate,
+                                 int pad_t, int pad_l, int Ho, int Wo, float *stat_partial, int impl,
                                  void *stream) {
   int rc = dw_check(N, H, W, C, stride, rate, Ho, Wo);
   if (rc) return rc;
@@ -846,36 +836,18 @@ static int dwconv3x3_fwd_impl(const float *x, const float *in_scale, const float
     dim3 grid(march_grid(p, N));
     if (p.two)
       hipLaunchKernelGGL(dw_march2_fwd, grid, dim3(256), 0, st, x, in_scale, in_shift, in_act, w, y, H, W, C, rate,
-                         p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial, Pmax,
-                         bias);
+                         p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial, Pmax);
     else
       hipLaunchKernelGGL(dw_march_fwd, grid, dim3(256), 0, st, x, in_scale, in_shift, in_act, w, y, H, W, C, rate,
-                         p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial, Pmax,
-                         bias);
+                         p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial, Pmax);
   } else {
     DwGeom G{N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo, Pmax};
     dim3 grid(p.nslab, p.PB);
     hipLaunchKernelGGL(dw_gather_fwd, grid, dim3(256), 0, st, x, in_scale, in_shift, in_act, w, y, G,
-                       stat_partial, bias);
+                       stat_partial);
   }
   DL3_LAUNCH_CHECK("dwconv3x3_fwd");
   return DL3_OK;
-}
-
-extern "C" int dl3_dwconv3x3_fwd(const float *x, const float *in_scale, const float *in_shift, int in_act,
-                                 const float *w, float *y, int N, int H, int W, int C, int stride, int rate,
-                                 int pad_t, int pad_l, int Ho, int Wo, float *stat_partial, int impl,
-                                 void *stream) {
-  return dwconv3x3_fwd_impl(x, in_scale, in_shift, in_act, w, nullptr, y, N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo,
-                            stat_partial, impl, stream);
-}
-
-extern "C" int dl3_dwconv3x3_fwd_bias(const float *x, const float *in_scale, const float *in_shift, int in_act,
-                                      const float *w, const float *bias, float *y, int N, int H, int W, int C,
-                                      int stride, int rate, int pad_t, int pad_l, int Ho, int Wo, float *stat_partial,
-                                      int impl, void *stream) {
-  return dwconv3x3_fwd_impl(x, in_scale, in_shift, in_act, w, bias, y, N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo,
-                            stat_partial, impl, stream);
 }
 
 static int dwconv3x3_bwd_impl(const float *g, const float *yraw, const float *cA, const float *cB,

@@ -618,8 +618,7 @@ class Engine:
                     v.buf.vptr(V_SCALE, v.off), v.buf.vptr(V_SHIFT, v.off), v.buf.vptr(V_MEAN, v.off),
                     v.buf.vptr(V_INVSTD, v.off), self.wptr(n + "/moving_mean:0") if upd else None,
                     self.wptr(n + "/moving_variance:0") if upd else None)
-        elif ((isinstance(unit, PwUnit) and unit.bias is None and os.environ.get("DL3_BN_CENTER", "1") != "0")
-              or (isinstance(unit, DwUnit) and os.environ.get("DL3_BN_CENTER", "1") == "2")):
+        elif isinstance(unit, PwUnit) and unit.bias is None and os.environ.get("DL3_BN_CENTER", "1") != "0":
             # moving statistics, 1x1 convolution in front (round 4): the GEMM's free bias slot takes -mean, the tensor holds
             # y - mean and consumers read scale*(y - mean) + beta — the reference's own gamma*(x - mean)/sqrt(var + eps) +
             # beta instead of scale*y + (beta - mean*scale), whose shift carries half an ulp of |mean*scale| into every
@@ -629,9 +628,8 @@ class Engine:
                     self.wptr(n + "/moving_mean:0"), self.wptr(n + "/moving_variance:0"), l.cfg["eps"], C,
                     v.buf.vptr(V_SCALE, v.off), v.buf.vptr(V_SHIFT, v.off), v.buf.vptr(V_MEAN, v.off),
                     v.buf.vptr(V_INVSTD, v.off), negm)
-            slot = 5 if isinstance(unit, DwUnit) else 6   # the bias argument of the producing launch
-            assert unit.fwd_rec[0] in ("dl3_pwconv_fwd", "dl3_pwconv_fwd_add", "dl3_dwconv3x3_fwd_bias") and unit.fwd_rec[2][slot] is None
-            unit.fwd_rec[2][slot] = negm
+            assert unit.fwd_rec[0] in ("dl3_pwconv_fwd", "dl3_pwconv_fwd_add") and unit.fwd_rec[2][6] is None
+            unit.fwd_rec[2][6] = negm
         else:
             self.op(self.ops_prep, "dl3_bn_frozen", self.wptr(n + "/gamma:0"), self.wptr(n + "/beta:0"),
                     self.wptr(n + "/moving_mean:0"), self.wptr(n + "/moving_variance:0"), l.cfg["eps"], C,
@@ -1480,9 +1478,8 @@ class DwUnit(_ConvBase):
         if want_stat:
             self.stat = eng.empty(self.P * C * 2)
         s, t, a = inv.xform()
-        # (bias slot, args[5]: NULL unless a frozen BatchNorm behind the layer puts -moving_mean there, _lo_BatchNormalization)
-        self.fwd_rec = eng.op(eng.ops_fwd, "dl3_dwconv3x3_fwd_bias", inv.p(), s, t, a, eng.wptr(self.wname()), None,
-                              outv.p(), *self.geom, ptr(self.stat), eng.dw_impl)
+        eng.op(eng.ops_fwd, "dl3_dwconv3x3_fwd", inv.p(), s, t, a, eng.wptr(self.wname()), outv.p(), *self.geom,
+               ptr(self.stat), eng.dw_impl)
 
     def wname(self):
         return self.layer.name + "/depthwise_kernel:0"

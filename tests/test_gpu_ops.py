@@ -90,14 +90,6 @@ def test_dwconv_fwd(L, case):
     s1, s2 = fold_partials(part, P, C)
     assert relerr(s1, ref.sum((0, 1, 2))) < 1e-3
     assert relerr(s2, (ref ** 2).sum((0, 1, 2))) < 1e-3
-    # the same launch with a per-channel addend on the output (the slot of -moving_mean, dl3_bn_frozen_centered): y + bias
-    # exactly — one fp32 addition behind the same sum
-    bias = rng.normal(0, 1, C).astype(np.float32)
-    y2 = empty(N, Ho, Wo, C)
-    call("dl3_dwconv3x3_fwd_bias", ptr(dev(x)), ptr(dev(s)) if s is not None else None,
-         ptr(dev(t)) if t is not None else None, a, ptr(dev(w)), ptr(dev(bias)), ptr(y2), N, H, W, C, stride, rate, pt, pl,
-         Ho, Wo, None, impl)
-    assert np.array_equal(host(y2), host(y) + bias)
 
 
 @pytest.mark.parametrize("case", DW_CASES)
