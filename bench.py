@@ -117,10 +117,10 @@ def build_engine(args):
 def _work(name, a):
     """(family, shape string, algorithmic FLOPs, algorithmic bytes) of one C-ABI launch; None = not accounted"""
     nz = lambda p: p is not None and p != 0
-    if name in ("dl3_pwconv_fwd", "dl3_pwconv_fwd_add", "dl3_pwconv_fwd_ws"):
+    if name in ("dl3_pwconv_fwd", "dl3_pwconv_fwd_add"):
         M, K, N = a[9], a[10], a[11]
         return "gemm", "fwd M=%d K=%d N=%d" % (M, K, N), 2.0 * M * K * N, 4.0 * (M * K + M * N + K * N)
-    if name in ("dl3_pwconv_bwd_data", "dl3_pwconv_bwd_data_ws"):
+    if name == "dl3_pwconv_bwd_data":
         M, K, N = a[22], a[23], a[24]
         by = M * N * (2 if nz(a[2]) else 1) + K * N + M * K * (1 + (1 if nz(a[10]) else 0) + (1 if nz(a[15]) else 0))
         return "gemm", "bwd-data M=%d K=%d N=%d" % (M, K, N), 2.0 * M * K * N, 4.0 * by

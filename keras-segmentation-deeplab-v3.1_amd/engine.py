@@ -217,9 +217,6 @@ class Engine:
         self.dy_mat_mink = int(os.environ.get("DL3_DY_MAT_K", "96"))
         # both gradients of an HBM-bound 1x1 convolution with a small weight matrix in one pass (dl3_pwconv_bwd_fused):
         # layers with at least DL3_FUSED_ROWS pixel rows (DL3_FUSED_BWD=0 disables)
-        # split-K for launches of few workgroups with a long reduction (dl3_pwconv_fwd_ws / _bwd_data_ws; the library decides
-        # per shape, DL3_SPLITK=0 disables it there as well)
-        self.splitk = os.environ.get("DL3_SPLITK", "1") != "0"
         self.fused_bwd = os.environ.get("DL3_FUSED_BWD", "1") != "0"
         self.fused_min_rows = int(os.environ.get("DL3_FUSED_ROWS", "131072"))
         self.dy_buf = None
@@ -631,7 +628,7 @@ class Engine:
                     self.wptr(n + "/moving_mean:0"), self.wptr(n + "/moving_variance:0"), l.cfg["eps"], C,
                     v.buf.vptr(V_SCALE, v.off), v.buf.vptr(V_SHIFT, v.off), v.buf.vptr(V_MEAN, v.off),
                     v.buf.vptr(V_INVSTD, v.off), negm)
-            assert unit.fwd_rec[0] in ("dl3_pwconv_fwd", "dl3_pwconv_fwd_add", "dl3_pwconv_fwd_ws") and unit.fwd_rec[2][6] is None
+            assert unit.fwd_rec[0] in ("dl3_pwconv_fwd", "dl3_pwconv_fwd_add") and unit.fwd_rec[2][6] is None
             unit.fwd_rec[2][6] = negm
         else:
             self.op(self.ops_prep, "dl3_bn_frozen", self.wptr(n + "/gamma:0"), self.wptr(n + "/beta:0"),
@@ -1318,18 +1315,7 @@ class PwUnit(_ConvBase):
             self.stat = eng.empty(self.P * self.N * 2)
         s, t, a = inv.xform()
         w = eng.wptr(self.wname()) + 4 * self.wrow0 * self.N
-        skws = eng.lib.dl3_pwconv_splitk_workspace(self.M, self.K, self.N) if eng.splitk else 0
-        if skws:
-            # few workgroups, long reduction (small batches): the launch is cut along K into the engine's scratch workspace
-            # and a second kernel sums the slices and runs the epilogue (dl3_pwconv_fwd_ws)
-            assert img_add is None or (img_add.M == eng.B and img_add.ld == self.N and self.M % eng.B == 0)
-            if img_add is not None:
-                eng._consume(View(img_add, 0, self.N))
-            self.fwd_rec = eng.op_ws(eng.ops_fwd, "dl3_pwconv_fwd_ws", skws, 16, inv.p(), inv.ld, s, t, a, w,
-                                     eng.wptr(self.bias) if self.bias else None, outv.p(), outv.ld, self.M, self.K, self.N,
-                                     ptr(self.stat), ptr(img_add.t) if img_add is not None else None, self.N,
-                                     (self.M // eng.B) if img_add is not None else 1, 0, skws)
-        elif img_add is None:
+        if img_add is None:
             self.fwd_rec = eng.op(eng.ops_fwd, "dl3_pwconv_fwd", inv.p(), inv.ld, s, t, a, w,
                                   eng.wptr(self.bias) if self.bias else None, outv.p(), outv.ld, self.M, self.K, self.N,
                                   ptr(self.stat))
@@ -1463,28 +1449,19 @@ class PwUnit(_ConvBase):
             # the epilogue's forward-input slot is free (no mask, no BatchNorm on the Add output): use it for the sums of
             # the BatchNorm this gradient reaches unchanged through the residual Add
             tgt = eng.alias_stats_target(ibuf)
-        # (the bwd-data GEMM is [M,N] x [N,K]: its reduction is N)
-        skws = eng.lib.dl3_pwconv_splitk_workspace(M, N, K) if eng.splitk else 0
-
-        def bwd_data(*args):
-            if skws:
-                eng.op_ws(eng.ops_bwd, "dl3_pwconv_bwd_data_ws", skws, 25, *args, 0, skws)
-            else:
-                eng.op(eng.ops_bwd, "dl3_pwconv_bwd_data", *args)
-
         if tgt is not None:
             dpart = eng.empty(P * tgt.ld * 2)
-            bwd_data(g, ldg, y, ldy, cA, cB, cC, ptr(wT), ptr(gout), ibuf.ld,
-                     ptr(tgt.t), tgt.ld, None, None, ACT_NONE, ptr(add), ibuf.ld, 1, 1.0,
-                     tgt.vptr(V_MEAN), tgt.vptr(V_INVSTD), ptr(dpart), M, K, N)
+            eng.op(eng.ops_bwd, "dl3_pwconv_bwd_data", g, ldg, y, ldy, cA, cB, cC, ptr(wT), ptr(gout), ibuf.ld,
+                   ptr(tgt.t), tgt.ld, None, None, ACT_NONE, ptr(add), ibuf.ld, 1, 1.0,
+                   tgt.vptr(V_MEAN), tgt.vptr(V_INVSTD), ptr(dpart), M, K, N)
             eng.prestat[id(tgt)] = (dpart, P, tgt.ld)
             return
-        bwd_data(g, ldg, y, ldy, cA, cB, cC, ptr(wT),
-                 gout.data_ptr() + 4 * inv.off, ibuf.ld, inv.p() if need_x else None, inv.ld,
-                 s if a != ACT_NONE else None, t if a != ACT_NONE else None, a,
-                 (add.data_ptr() + 4 * inv.off) if add is not None else None, ibuf.ld, 1, 1.0,
-                 ibuf.vptr(V_MEAN, inv.off) if need_stat else None, ibuf.vptr(V_INVSTD, inv.off) if need_stat else None,
-                 ptr(dpart), M, K, N)
+        eng.op(eng.ops_bwd, "dl3_pwconv_bwd_data", g, ldg, y, ldy, cA, cB, cC, ptr(wT),
+               gout.data_ptr() + 4 * inv.off, ibuf.ld, inv.p() if need_x else None, inv.ld,
+               s if a != ACT_NONE else None, t if a != ACT_NONE else None, a,
+               (add.data_ptr() + 4 * inv.off) if add is not None else None, ibuf.ld, 1, 1.0,
+               ibuf.vptr(V_MEAN, inv.off) if need_stat else None, ibuf.vptr(V_INVSTD, inv.off) if need_stat else None,
+               ptr(dpart), M, K, N)
         if need_stat:
             eng.finish_bn_bwd(ibuf, dpart, P, ibuf.ld)
 

@@ -425,105 +425,6 @@ def test_pwconv_bwd_data_single_tensor_masked(L, case, pre, monkeypatch):
     test_pwconv_bwd_data(L, (M, K, N, act, False, addmode, True))
 
 
-SPLITK_FWD = [
-    # M, K, N, act, bias, addend rows (0 none, else rows per addend row)
-    (8192, 960, 160, 2, False, 0),      # notebook batch 2: project conv of blocks 14-16
-    (8192, 576, 96, 2, False, 0),
-    (8192 + 40, 960, 320, 2, False, 0),  # ragged rows
-    (4096, 384, 64, None, True, 0),
-    (8192, 256, 256, 1, False, 4096),   # concat_projection with the per-image addend
-    (2048, 2048, 256, 1, False, 0),     # Xception ASPP pointwise at a small batch
-]
-
-
-@pytest.mark.parametrize("case", SPLITK_FWD)
-def test_pwconv_fwd_split_k(L, case, monkeypatch):
-    """dl3_pwconv_fwd_ws (round 4): few workgroups, long reduction -> the launch is cut along K into the caller's workspace
-    and a second kernel sums the slices and runs the epilogue.  Against float64, and against the uncut launch"""
-    M, K, N, act, has_bias, arows = case
-    nbytes = L.dl3_pwconv_splitk_workspace(M, K, N)
-    assert nbytes > 0 and nbytes % (M * N * 4) == 0 and 2 <= nbytes // (M * N * 4) <= 4
-    assert L.dl3_pwconv_splitk_workspace(524288, K, N) == 0 and L.dl3_pwconv_splitk_workspace(M, 64, N) == 0
-    rng = np.random.default_rng(19)
-    x = rng.normal(0, 1, (M, K)).astype(np.float32)
-    w = rng.normal(0, 0.2, (K, N)).astype(np.float32)
-    b = rng.normal(0, 1, N).astype(np.float32) if has_bias else None
-    s, t, a = _xform(rng, K, act)
-    xin = x.astype(np.float64) if s is None else np_act(s * x.astype(np.float64) + t, a)
-    ref = xin @ w.astype(np.float64)
-    if b is not None:
-        ref = ref + b
-    add = None
-    if arows:
-        add = rng.normal(0, 1, (M // arows, N)).astype(np.float32)
-        ref = ref + np.repeat(add, arows, axis=0)
-    P = L.dl3_pwconv_partials(M, K, N)
-    xd, wd, sd, td = dev(x), dev(w), (dev(s) if s is not None else None), (dev(t) if t is not None else None)
-    bd, ad = (dev(b) if b is not None else None), (dev(add) if add is not None else None)
-    ws = empty(nbytes // 4)
-    y, part = empty(M, N), empty(P, N, 2)
-    call("dl3_pwconv_fwd_ws", ptr(xd), K, ptr(sd), ptr(td), a, ptr(wd), ptr(bd), ptr(y), N, M, K, N, ptr(part), ptr(ad), N,
-         arows if arows else 1, ptr(ws), nbytes)
-    assert relerr(host(y), ref) < TOL
-    s1, s2 = fold_partials(part, P, N)
-    assert relerr(s1, ref.sum(0)) < 1e-3 and relerr(s2, (ref ** 2).sum(0)) < 1e-3
-    # without a workspace the same entry point runs the uncut launch: same values up to the association of the fp32 sum
-    y0 = empty(M, N)
-    call("dl3_pwconv_fwd_ws", ptr(xd), K, ptr(sd), ptr(td), a, ptr(wd), ptr(bd), ptr(y0), N, M, K, N, None, ptr(ad), N,
-         arows if arows else 1, None, 0)
-    assert relerr(host(y), host(y0)) < 2e-6 and not np.array_equal(host(y), host(y0))
-    monkeypatch.setenv("DL3_SPLITK", "0")
-    assert L.dl3_pwconv_splitk_workspace(M, K, N) == 0
-
-
-@pytest.mark.parametrize("case", [(8192, 160, 960, None, True, 1, True), (8192, 96, 576, None, True, 0, True),
-                                  (8192, 64, 384, 2, False, 0, True), (4096 + 24, 320, 256, None, True, 2, True),
-                                  (8192, 160, 960, None, False, 1, False)])
-def test_pwconv_bwd_data_split_k(L, case):
-    """dl3_pwconv_bwd_data_ws: the expand convolutions' bwd-data at small batches (reduction N = 384 ... 960 into a narrow
-    output) cut along the reduction; mask, addend (tensor / per-image), BatchNorm-backward sums in the fold kernel"""
-    M, K, N, act, two, addmode, stats = case
-    nbytes = L.dl3_pwconv_splitk_workspace(M, N, K)
-    assert nbytes > 0
-    rng = np.random.default_rng(20)
-    g = rng.normal(0, 1, (M, N)).astype(np.float32)
-    yraw = rng.normal(0, 1, (M, N)).astype(np.float32)
-    cA, cB, cC = [rng.normal(0, 1, N).astype(np.float32) for _ in range(3)]
-    w = rng.normal(0, 0.2, (K, N)).astype(np.float32)
-    x = rng.normal(0, 1, (M, K)).astype(np.float32)
-    s, t, a = _xform(rng, K, act)
-    mean = rng.normal(0, 1, K).astype(np.float32)
-    invstd = rng.uniform(0.5, 2, K).astype(np.float32)
-    dY = (cA * g.astype(np.float64) + cB * yraw + cC) if two else g.astype(np.float64)
-    ref = dY @ w.astype(np.float64).T
-    if s is not None:
-        ref = ref * np_mask(s * x.astype(np.float64) + t, a)
-    add_div, add_scale, add = 1, 1.0, None
-    if addmode == 1:
-        add = rng.normal(0, 1, (M, K)).astype(np.float32)
-        ref = ref + add
-    elif addmode == 2:
-        add_div, add_scale = 8, 0.25
-        add = rng.normal(0, 1, (M // add_div, K)).astype(np.float32)
-        ref = ref + add_scale * np.repeat(add, add_div, axis=0)
-    wT = empty(N, K)
-    call("dl3_transpose", ptr(dev(w)), ptr(wT), K, N)
-    P = L.dl3_pwconv_partials(M, N, K)
-    dx, dpart, ws = empty(M, K), empty(P, K, 2), empty(nbytes // 4)
-    need_x = s is not None or stats
-    call("dl3_pwconv_bwd_data_ws", ptr(dev(g)), N, ptr(dev(yraw)) if two else None, N, ptr(dev(cA)) if two else None,
-         ptr(dev(cB)) if two else None, ptr(dev(cC)) if two else None, ptr(wT), ptr(dx), K,
-         ptr(dev(x)) if need_x else None, K, ptr(dev(s)) if s is not None else None,
-         ptr(dev(t)) if t is not None else None, a, ptr(dev(add)) if add is not None else None, K, add_div, add_scale,
-         ptr(dev(mean)) if stats else None, ptr(dev(invstd)) if stats else None, ptr(dpart) if stats else None, M, K, N,
-         ptr(ws), nbytes)
-    assert relerr(host(dx), ref) < TOL
-    if stats:
-        s1, s2 = fold_partials(dpart, P, K)
-        assert relerr(s1, ref.sum(0)) < 1e-3
-        assert relerr(s2, (ref * (x - mean) * invstd).sum(0)) < 1e-3
-
-
 BW_CASES = [
     # M, K, N, act, two-tensor, dbias
     (1024, 16, 96, 2, True, False),
