@@ -119,22 +119,6 @@ int dl3_pwconv_bwd_data(const float *g, int ldg, const float *yraw, int ldyraw, 
                         const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
                         const float *dx_add, int ldadd, int add_div, float add_scale, const float *x_mean,
                         const float *x_invstd, float *dstat_partial, int M, int K, int N, void *stream);
-/* Split-K for launches of few workgroups with a long reduction (round 4; the reference's own regime — notebook batch 2 =
- * 8 192 pixel rows per 64x64 map: 960 -> 160 is 512 workgroups x 60 K-tiles): handed a workspace of
- * dl3_pwconv_splitk_workspace(M, K, N) bytes (bwd_data: ask with (M, N, K), its GEMM is [M,N]x[N,K]; 0 = the launch is not
- * cut, pass NULL), the launch walks the reduction in 2-4 slices on separate workgroups and a second kernel sums the
- * slices in a fixed order and runs the epilogue (bias, mask, addend, BatchNorm partial sums): same results up to the
- * association of the fp32 sum, deterministic.  _fwd_ws covers dl3_pwconv_fwd and _fwd_add (add nullable). */
-size_t dl3_pwconv_splitk_workspace(int M, int K, int N);
-int dl3_pwconv_fwd_ws(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act, const float *w,
-                      const float *bias, float *y, int ldy, int M, int K, int N, float *stat_partial, const float *add,
-                      int ldadd, int add_div, void *workspace, size_t workspace_bytes, void *stream);
-int dl3_pwconv_bwd_data_ws(const float *g, int ldg, const float *yraw, int ldyraw, const float *cA, const float *cB,
-                           const float *cC, const float *wT, float *dx, int lddx, const float *x, int ldx,
-                           const float *in_scale, const float *in_shift, int in_act, const float *dx_add, int ldadd,
-                           int add_div, float add_scale, const float *x_mean, const float *x_invstd,
-                           float *dstat_partial, int M, int K, int N, void *workspace, size_t workspace_bytes,
-                           void *stream);
 size_t dl3_pwconv_bwd_weight_workspace(int M, int K, int N);
 /* dw[K,N] = T(x)^T . dY ; dbias[N] (nullable) = colsum(dY).  The launch reduces over M in S =
  * dl3_pwconv_bwd_weight_splits(M, K, N, cA != NULL) deterministic slabs [S][K][N] at the head of the workspace and folds

@@ -40,9 +40,6 @@ struct GemmArgs {
   int part_rows;  // rows the caller's partial buffer holds: the launch writes gridDim.y of them and zeroes the rest itself
   int mtiles;
   const void *bp; int nsub;  // split math: weights pre-split into 3 bf16 planes in MFMA fragment order (pack_b_kernel)
-  // split-K (round 4, small M): gridDim.z = ksplit workgroups share a tile, each walks its slice of the reduction and
-  // leaves raw accumulators in kpart [ksplit][M][N]; splitk_fold_kernel sums them in a fixed order and runs the epilogue
-  float *kpart; int ksplit;
 #ifdef DL3_PHASE_TIMING
   long long *dbg;  // probe build (tools/r3/phase_probe.py): per-workgroup cycles in prologue / K loop / epilogue
 #endif
@@ -504,13 +501,6 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
   const int ktiles = (P.K + KT - 1) / KT;
   const int KC = SPL ? ktiles * KT : KCS;
   const bool xform = (P.ka != nullptr);
-  // split-K exists in the 32-row instantiations only (WN = 4: the small-M tiles — it is for launches of few row tiles;
-  // compiled into the 128 / 256-row kernels it cost the prefetching 128x96 kernel 25 VGPRs and 12 B of scratch), and
-  // never together with split math (run_gemm)
-  constexpr bool KSP_OK = (WN == 4) && !SPL;
-  const bool ksp = KSP_OK && P.ksplit > 1;
-  const int kt0 = ksp ? (int)(((long)ktiles * blockIdx.z) / P.ksplit) : 0;
-  const int kt1 = ksp ? (int)(((long)ktiles * (blockIdx.z + 1)) / P.ksplit) : ktiles;
   const int wm = wave / WN, wn = wave % WN;
   const int nw0 = n0 + wn * TN * 32;  // first column of this wave's sub-tile
 
@@ -704,16 +694,16 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
         if (more) take_next();
       }
     } else {
-    load_A(kt0);
-    load_B(kt0);
+    load_A(0);
+    load_B(0);
     __syncthreads();  // the previous row tile is done with the LDS
-    store_B(lds + (kt0 & 1) * KT * LDB);
-    transform(kt0);
+    store_B(lds);
+    transform(0);
     __syncthreads();
     DL3_T(tq1 = clock64();)
-    for (int kt = kt0; kt < kt1; ++kt) {
+    for (int kt = 0; kt < ktiles; ++kt) {
       const float *Bs = lds + (kt & 1) * KT * LDB;
-      const bool more = kt + 1 < kt1;
+      const bool more = kt + 1 < ktiles;
       if (more) {
         load_A(kt + 1);
         load_B(kt + 1);
@@ -759,24 +749,6 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
 #else
     const int m0e = m0, nw0e = nw0;
 #endif
-    if (ksp) {
-      // raw accumulators of this slice of the reduction: no bias, mask, addend or sums here (splitk_fold_kernel)
-      float *pz = P.kpart + (size_t)blockIdx.z * P.M * P.N;
-#pragma unroll
-      for (int j = 0; j < TN; j++) {
-        const int col = nw0e + j * 32 + l31;
-#pragma unroll
-        for (int i = 0; i < TM; i++) {
-          const int rbase = m0e + (wm * TM + i) * 32 + 4 * lhi;
-#pragma unroll
-          for (int r = 0; r < 16; r++) {
-            const int row = rbase + (r & 3) + 8 * (r >> 2);
-            if (row < P.M && col < P.N) pz[(size_t)row * P.N + col] = acc[i][j][r];
-          }
-        }
-      }
-      continue;
-    }
     if (FWD && full) {
       if (!P.ep_add) stream_epilogue_full<TM, TN, false, false, false>(P, acc, m0e, nw0e, wm, l31, lhi, st1, st2);
       else stream_epilogue_full<TM, TN, false, true, false>(P, acc, m0e, nw0e, wm, l31, lhi, st1, st2);
@@ -864,7 +836,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
   }
 #endif
 
-  if (P.stat_mode != 0 && !ksp) {
+  if (P.stat_mode != 0) {
     float *sred = lds;  // [WM][BN][2]
     __syncthreads();
 #pragma unroll
@@ -1223,64 +1195,6 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const long long 
     if (c0 + i < cols && r0 + tx < rows) out[(size_t)(c0 + i) * rows + r0 + tx] = tile[tx][i];
 }
 
-// split-K fold + epilogue (round 4): c = sum over the ksplit slices of the reduction (fixed order) + bias -> activation
-// mask -> addend -> store, BatchNorm partial sums — what the GEMM's own epilogue does when it owns the whole reduction.
-// Block = 64 column quads x 4 row lanes over `rpb` rows; grid (ceil(N / 256), ceil(M / rpb)).
-__global__ __launch_bounds__(256) void splitk_fold_kernel(GemmArgs P, int rpb) {
-  __shared__ float red[4 * 64 * 8];
-  const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int col = (blockIdx.x * 64 + cq) * 4;
-  const bool cok = col < P.N;  // N % 4 == 0 on this path
-  const int cc = min(col, P.N - 4);
-  const int r0 = blockIdx.y * rpb, r1 = min(P.M, r0 + rpb);
-  f32x4 bias = splat4(0.f), es = splat4(1.f), et = splat4(0.f), mu = splat4(0.f), is = splat4(0.f);
-  if (P.bias) bias = ld4(P.bias + cc);
-  if (P.ep_x && P.ep_scale) { es = ld4(P.ep_scale + cc); et = ld4(P.ep_shift + cc); }
-  if (P.stat_mode == 2) { mu = ld4(P.ep_mean + cc); is = ld4(P.ep_invstd + cc); }
-  f32x4 s1 = splat4(0.f), s2 = splat4(0.f);
-  if (cok) {
-    for (int row = r0 + rl; row < r1; row += 4) {
-      f32x4 v = ld4(P.kpart + (size_t)row * P.N + col);
-      for (int z = 1; z < P.ksplit; z++) v += ld4(P.kpart + ((size_t)z * P.M + row) * P.N + col);
-      v += bias;
-      f32x4 xr = splat4(0.f);
-      if (P.ep_x) {
-        xr = ld4(P.ep_x + (size_t)row * P.ld_epx + col);
-        v = v * dl3_mask4(es * xr + et, P.ep_act);
-      }
-      if (P.ep_add) {
-        const int arow = (P.add_div > 1) ? row / P.add_div : row;
-        v += splat4(P.add_scale) * ld4(P.ep_add + (size_t)arow * P.ld_add + col);
-      }
-      st4_nt(P.c + (size_t)row * P.ldc + col, v);
-      s1 += v;
-      s2 += (P.stat_mode == 2) ? v * ((xr - mu) * is) : v * v;
-    }
-  }
-  if (P.stat_mode != 0) {
-    float *d = red + (rl * 64 + cq) * 8;
-    d[0] = s1.x; d[1] = s1.y; d[2] = s1.z; d[3] = s1.w; d[4] = s2.x; d[5] = s2.y; d[6] = s2.z; d[7] = s2.w;
-    __syncthreads();
-    if (rl == 0 && cok) {
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          a1 += red[(q * 64 + cq) * 8 + e];
-          a2 += red[(q * 64 + cq) * 8 + 4 + e];
-        }
-        P.part[((size_t)blockIdx.y * P.N + col + e) * 2 + 0] = a1;
-        P.part[((size_t)blockIdx.y * P.N + col + e) * 2 + 1] = a2;
-        for (int r = blockIdx.y + (int)gridDim.y; r < P.part_rows; r += (int)gridDim.y) {
-          P.part[((size_t)r * P.N + col + e) * 2 + 0] = 0.f;
-          P.part[((size_t)r * P.N + col + e) * 2 + 1] = 0.f;
-        }
-      }
-    }
-  }
-}
-
 // ---- configuration choice -------------------------------------------------------------
 struct GemmCfg { int id, BM, BN; };
 const GemmCfg kGemmCfgs[] = {{0, 128, 128}, {1, 256, 64}, {2, 256, 32}, {3, 128, 160}, {4, 128, 96},
@@ -1355,23 +1269,6 @@ int gemm_grid_y(int M, int N, const GemmCfg &c) {
   return even;
 }
 
-// split-K (round 4): a launch of few workgroups, each a long serial K loop, is cut along the reduction so that the
-// chain every workgroup walks is shorter and the chip's workgroup slots (up to four per CU for the 32-row tiles) are
-// filled — the small-batch regime of the reference (notebook batch 2: 8 192 pixel rows per 64 x 64 map; 960 -> 160
-// forward: 512 workgroups x 60 K-tiles, 66 us at 38 TFLOP/s).  1 = no split.  DL3_SPLITK=0 disables, =n forces n.
-int splitk_factor(int M, int K, int N, const GemmCfg &c) {
-  const int e = env_int("DL3_SPLITK");
-  if (e == 0 || M > 32768) return 1;
-  const long blocks = (long)dl3_cdiv(M, c.BM) * dl3_cdiv(N, c.BN);
-  const int ktiles = dl3_cdiv(K, 16);
-  if (e > 1) return e <= ktiles ? e : ktiles;
-  if (blocks > 512 || ktiles < 16) return 1;
-  int ks = (int)(1024 / blocks);
-  if (ks > 4) ks = 4;
-  if (ks > ktiles / 8) ks = ktiles / 8;
-  return ks < 1 ? 1 : ks;
-}
-
 // split math (opt-in): device scratch for the packed weights of the launch in flight, one buffer per DEVICE.  Launches on
 // one stream are ordered, so one buffer serves them all — split-math launches of a device must not be issued from two
 // streams at once (the engine issues them on one stream, eagerly or under capture; the weight-gradient kernels, the
@@ -1423,7 +1320,7 @@ void launch_gemm(const GemmArgs &A, dim3 grid, hipStream_t st, bool vec) {
 inline bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
 // returns the number of stat partial rows the launch writes (= grid.y)
-int run_gemm(GemmArgs A, hipStream_t st, void *ws = nullptr, size_t ws_bytes = 0) {
+int run_gemm(GemmArgs A, hipStream_t st) {
   const bool two = A.a2 != nullptr;
   const bool avec = (A.K % 4 == 0) && (A.lda % 4 == 0) && al16(A.a) && (!two || ((A.lda2 % 4 == 0) && al16(A.a2)));
   const bool bvec = (A.N % 4 == 0) && (A.ldb % 4 == 0) && al16(A.b);
@@ -1433,20 +1330,10 @@ int run_gemm(GemmArgs A, hipStream_t st, void *ws = nullptr, size_t ws_bytes = 0
   // inside one image)
   const bool fwd = !two && !A.ep_x && A.stat_mode != 2 && !(A.ep_add && A.add_div > 1 && A.add_div % 32 != 0);
   GemmCfg c = pick_gemm(A.M, A.K, A.N, two, stream, fwd);
-  // split-K: f32 stream kernels only, with a caller workspace for the slices and 16-byte aligned epilogue operands
-  // (the fold kernel moves float4s)
-  int ks = 1;
-  if (stream && ws && !split_math() && A.ldc % 4 == 0 && al16(A.c) && (!A.ep_x || (A.ld_epx % 4 == 0 && al16(A.ep_x))) &&
-      (!A.ep_add || (A.ld_add % 4 == 0 && al16(A.ep_add)))) {
-    if (c.BM == 32) ks = splitk_factor(A.M, A.K, A.N, c);  // (the 32-row instantiations carry the split-K code)
-    while (ks > 1 && (size_t)ks * A.M * A.N * sizeof(float) > ws_bytes) --ks;
-  }
-  if (ks == 1 && stream && pre_ok(A) && pre_wanted(A)) c = kGemmCfgs[4];
+  if (stream && pre_ok(A) && pre_wanted(A)) c = kGemmCfgs[4];
   A.mtiles = dl3_cdiv(A.M, c.BM);
-  A.ksplit = ks;
-  A.kpart = ks > 1 ? (float *)ws : nullptr;
   DL3_T(A.dbg = g_phase_dbg;)
-  dim3 grid(dl3_cdiv(A.N, c.BN), gemm_grid_y(A.M, A.N, c), ks);
+  dim3 grid(dl3_cdiv(A.N, c.BN), gemm_grid_y(A.M, A.N, c));
   // stream-A kernel: 10-25 % faster than the LDS-staged kernel on every layer shape, forward and bwd-data
   // (tools/gemm_tune.py).  The two-tensor bwd-data operand uses 16-deep K-tiles so that its register budget does not
   // spill.  DL3_GEMM_IMPL=0 forces the staged kernel (which also serves unaligned operands).
@@ -1489,7 +1376,7 @@ int run_gemm(GemmArgs A, hipStream_t st, void *ws = nullptr, size_t ws_bytes = 0
     else if (fwd) hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, DL3_STREAM_KT_FWD, 1, WN_>), grid, blk, 0, st, A); \
     else hipLaunchKernelGGL((pw_gemm_stream_kernel<TM_, TN_, false, DL3_STREAM_KT_BWD1, 0, WN_>), grid, blk, 0, st, A); \
   } while (0)
-    if (c.id == 4 && pre_ok(A) && ks == 1) {
+    if (c.id == 4 && pre_ok(A)) {
       if (two) hipLaunchKernelGGL((pw_gemm_stream_kernel<1, 3, true, 16, 2, 1>), grid, blk, 0, st, A);
       else hipLaunchKernelGGL((pw_gemm_stream_kernel<1, 3, false, 16, 2, 1>), grid, blk, 0, st, A);
       return (int)grid.y;
@@ -1504,13 +1391,6 @@ int run_gemm(GemmArgs A, hipStream_t st, void *ws = nullptr, size_t ws_bytes = 0
       default: DL3_STREAM(1, 3, 1); break;
     }
 #undef DL3_STREAM
-    if (ks > 1) {
-      int rpb = 64;
-      if (A.stat_mode != 0 && A.part_rows > 0 && dl3_cdiv(A.M, rpb) > A.part_rows) rpb = dl3_cdiv(dl3_cdiv(A.M, A.part_rows), 4) * 4;
-      dim3 fg(dl3_cdiv(A.N, 256), dl3_cdiv(A.M, rpb));
-      hipLaunchKernelGGL(splitk_fold_kernel, fg, blk, 0, st, A, rpb);
-      return (int)fg.y;
-    }
     return (int)grid.y;
   }
   switch (c.id) {
@@ -1622,60 +1502,60 @@ static int gemm_common_check(const char *name, int M, int K, int N) {
   return DL3_OK;
 }
 
-static int pwconv_fwd_impl(const char *name, const float *x, int ldx, const float *in_scale, const float *in_shift,
-                           int in_act, const float *w, const float *bias, float *y, int ldy, int M, int K, int N,
-                           float *stat_partial, const float *add, int ldadd, int add_div, void *workspace,
-                           size_t workspace_bytes, void *stream) {
-  int rc = gemm_common_check(name, M, K, N);
+extern "C" int dl3_pwconv_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
+                              const float *w, const float *bias, float *y, int ldy, int M, int K, int N,
+                              float *stat_partial, void *stream) {
+  int rc = gemm_common_check("pwconv_fwd", M, K, N);
   if (rc) return rc;
-  DL3_CHECK_ARG(x && w && y, "%s: null pointer", name);
-  DL3_CHECK_ARG(ldx >= K && ldy >= N && (!add || (ldadd >= N && add_div >= 1)), "%s: bad leading dimension / add_div", name);
-  DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "%s: scale/shift must come together", name);
+  DL3_CHECK_ARG(x && w && y, "pwconv_fwd: null pointer");
+  DL3_CHECK_ARG(ldx >= K && ldy >= N, "pwconv_fwd: leading dimension too small");
+  DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "pwconv_fwd: scale/shift must come together");
   GemmArgs A{};
   A.a = x; A.lda = ldx; A.a2 = nullptr; A.lda2 = 0;
   A.ka = in_scale; A.kb = nullptr; A.kc = in_shift; A.a_act = in_act;
   A.b = w; A.ldb = N; A.bias = bias; A.c = y; A.ldc = ldy;
   A.M = M; A.K = K; A.N = N;
-  A.ep_add = add; A.ld_add = ldadd; A.add_div = add ? add_div : 1; A.add_scale = 1.f;
+  A.add_div = 1; A.add_scale = 1.f;
   A.stat_mode = stat_partial ? 1 : 0;
   A.part = stat_partial;
   A.part_rows = stat_partial ? dl3_pwconv_partials(M, K, N) : 0;
   hipStream_t st = (hipStream_t)stream;
-  const int written = run_gemm(A, st, workspace, workspace_bytes);
-  DL3_CHECK_ARG(written >= 0, "%s: split-math weight scratch unavailable (first launch inside a stream capture?)", name);
-  DL3_LAUNCH_CHECK(name);
+  const int written = run_gemm(A, st);
+  DL3_CHECK_ARG(written >= 0, "pwconv_fwd: split-math weight scratch unavailable (first launch inside a stream capture?)");
+  DL3_LAUNCH_CHECK("pwconv_fwd");
   return DL3_OK;
-}
-
-extern "C" int dl3_pwconv_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
-                              const float *w, const float *bias, float *y, int ldy, int M, int K, int N,
-                              float *stat_partial, void *stream) {
-  return pwconv_fwd_impl("pwconv_fwd", x, ldx, in_scale, in_shift, in_act, w, bias, y, ldy, M, K, N, stat_partial, nullptr, 0,
-                         1, nullptr, 0, stream);
 }
 
 extern "C" int dl3_pwconv_fwd_add(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
                                   const float *w, const float *bias, float *y, int ldy, int M, int K, int N,
                                   float *stat_partial, const float *add, int ldadd, int add_div, void *stream) {
-  DL3_CHECK_ARG(add, "pwconv_fwd_add: null pointer");
-  return pwconv_fwd_impl("pwconv_fwd_add", x, ldx, in_scale, in_shift, in_act, w, bias, y, ldy, M, K, N, stat_partial, add,
-                         ldadd, add_div, nullptr, 0, stream);
+  int rc = gemm_common_check("pwconv_fwd_add", M, K, N);
+  if (rc) return rc;
+  DL3_CHECK_ARG(x && w && y && add, "pwconv_fwd_add: null pointer");
+  DL3_CHECK_ARG(ldx >= K && ldy >= N && ldadd >= N && add_div >= 1, "pwconv_fwd_add: bad leading dimension / add_div");
+  DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "pwconv_fwd_add: scale/shift must come together");
+  GemmArgs A{};
+  A.a = x; A.lda = ldx; A.a2 = nullptr; A.lda2 = 0;
+  A.ka = in_scale; A.kb = nullptr; A.kc = in_shift; A.a_act = in_act;
+  A.b = w; A.ldb = N; A.bias = bias; A.c = y; A.ldc = ldy;
+  A.M = M; A.K = K; A.N = N;
+  A.ep_add = add; A.ld_add = ldadd; A.add_div = add_div; A.add_scale = 1.f;
+  A.stat_mode = stat_partial ? 1 : 0;
+  A.part = stat_partial;
+  A.part_rows = stat_partial ? dl3_pwconv_partials(M, K, N) : 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int written = run_gemm(A, st);
+  DL3_CHECK_ARG(written >= 0, "pwconv_fwd_add: split-math weight scratch unavailable (first launch inside a stream capture?)");
+  DL3_LAUNCH_CHECK("pwconv_fwd_add");
+  return DL3_OK;
 }
 
-extern "C" int dl3_pwconv_fwd_ws(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
-                                 const float *w, const float *bias, float *y, int ldy, int M, int K, int N,
-                                 float *stat_partial, const float *add, int ldadd, int add_div, void *workspace,
-                                 size_t workspace_bytes, void *stream) {
-  return pwconv_fwd_impl("pwconv_fwd_ws", x, ldx, in_scale, in_shift, in_act, w, bias, y, ldy, M, K, N, stat_partial, add, ldadd,
-                         add_div, workspace, workspace_bytes, stream);
-}
-
-static int pwconv_bwd_data_impl(const float *g, int ldg, const float *yraw, int ldyraw, const float *cA,
+extern "C" int dl3_pwconv_bwd_data(const float *g, int ldg, const float *yraw, int ldyraw, const float *cA,
                                    const float *cB, const float *cC, const float *wT, float *dx, int lddx,
                                    const float *x, int ldx, const float *in_scale, const float *in_shift,
                                    int in_act, const float *dx_add, int ldadd, int add_div, float add_scale,
                                    const float *x_mean, const float *x_invstd, float *dstat_partial, int M,
-                                   int K, int N, void *workspace, size_t workspace_bytes, void *stream) {
+                                   int K, int N, void *stream) {
   int rc = gemm_common_check("pwconv_bwd_data", M, K, N);
   if (rc) return rc;
   DL3_CHECK_ARG(g && wT && dx, "pwconv_bwd_data: null pointer");
@@ -1699,44 +1579,10 @@ static int pwconv_bwd_data_impl(const float *g, int ldg, const float *yraw, int 
   A.part = dstat_partial;
   A.part_rows = dstat_partial ? dl3_pwconv_partials(M, N, K) : 0;
   hipStream_t st = (hipStream_t)stream;
-  const int written = run_gemm(A, st, workspace, workspace_bytes);
+  const int written = run_gemm(A, st);
   DL3_CHECK_ARG(written >= 0, "pwconv_bwd_data: split-math weight scratch unavailable (first launch inside a stream capture?)");
   DL3_LAUNCH_CHECK("pwconv_bwd_data");
   return DL3_OK;
-}
-
-extern "C" int dl3_pwconv_bwd_data(const float *g, int ldg, const float *yraw, int ldyraw, const float *cA,
-                                   const float *cB, const float *cC, const float *wT, float *dx, int lddx,
-                                   const float *x, int ldx, const float *in_scale, const float *in_shift,
-                                   int in_act, const float *dx_add, int ldadd, int add_div, float add_scale,
-                                   const float *x_mean, const float *x_invstd, float *dstat_partial, int M,
-                                   int K, int N, void *stream) {
-  return pwconv_bwd_data_impl(g, ldg, yraw, ldyraw, cA, cB, cC, wT, dx, lddx, x, ldx, in_scale, in_shift, in_act, dx_add, ldadd,
-                              add_div, add_scale, x_mean, x_invstd, dstat_partial, M, K, N, nullptr, 0, stream);
-}
-
-extern "C" int dl3_pwconv_bwd_data_ws(const float *g, int ldg, const float *yraw, int ldyraw, const float *cA,
-                                      const float *cB, const float *cC, const float *wT, float *dx, int lddx,
-                                      const float *x, int ldx, const float *in_scale, const float *in_shift,
-                                      int in_act, const float *dx_add, int ldadd, int add_div, float add_scale,
-                                      const float *x_mean, const float *x_invstd, float *dstat_partial, int M,
-                                      int K, int N, void *workspace, size_t workspace_bytes, void *stream) {
-  return pwconv_bwd_data_impl(g, ldg, yraw, ldyraw, cA, cB, cC, wT, dx, lddx, x, ldx, in_scale, in_shift, in_act, dx_add, ldadd,
-                              add_div, add_scale, x_mean, x_invstd, dstat_partial, M, K, N, workspace, workspace_bytes, stream);
-}
-
-// bytes of workspace with which a [M,K]x[K,N] launch (dl3_pwconv_fwd_ws: (M, K, N); dl3_pwconv_bwd_data_ws: the GEMM is
-// [M,N]x[N,K], ask with (M, N, K)) is cut along its reduction; 0: it is not (hand over NULL)
-extern "C" size_t dl3_pwconv_splitk_workspace(int M, int K, int N) {
-  if (M <= 0 || K <= 0 || N <= 0 || K % 4 || N % 4 || K > DL3_STREAM_KMAX || split_math()) return 0;
-  int ks = 1;
-  for (int two = 0; two < 2; two++)
-    for (int fwd = 0; fwd < 2; fwd++) {
-      const GemmCfg c = pick_gemm(M, K, N, two != 0, true, fwd != 0);
-      const int q = c.BM == 32 ? splitk_factor(M, K, N, c) : 1;
-      ks = q > ks ? q : ks;
-    }
-  return ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
 }
 
 extern "C" size_t dl3_pwconv_bwd_weight_workspace(int M, int K, int N) {
