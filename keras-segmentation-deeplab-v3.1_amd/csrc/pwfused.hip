@@ -37,10 +37,11 @@ constexpr int FMS = 32;  // rows per stage
 // convolutions: K <= 64, the tiles are small).  Without AUX the sums, if any, are taken against the forward input itself,
 // which is staged RAW (the input transform is applied where the fragments are read: it is two VALU operations per
 // element, and the epilogue needs the raw value for the activation mask and x_hat anyway).
-// (three workgroups per CU where the registers allow it without spilling: these launches wait for memory, not for the
-// matrix pipe; the five-block and AUX shapes keep 2 — at 3 they spill 20-150 B per lane)
+// (four workgroups per CU where the registers allow it without spilling — <= 128 VGPRs, no scratch: these launches wait
+// for memory, not for the matrix pipe; 16 -> 96 at 256x256: 2.03 ms at three, 1.81 ms at four; the five-block and AUX
+// shapes keep 2 — at 3 they spill 20-150 B per lane)
 template <int KB, int NB, bool AUX>
-__global__ __launch_bounds__(256, (KB * NB == 5 || AUX) ? 2 : 3) void pw_bwd_fused_kernel(FusedArgs P) {
+__global__ __launch_bounds__(256, (KB * NB == 5 || AUX) ? 2 : 4) void pw_bwd_fused_kernel(FusedArgs P) {
   constexpr int KP = KB * 32, NP = NB * 32;
   constexpr int LDX = KP + 4, LDD = NP + 4, LDW = KP;
   constexpr int NBLK = KB * NB;
