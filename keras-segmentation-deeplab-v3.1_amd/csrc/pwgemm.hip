@@ -470,7 +470,10 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
   // running at mfma-time + hbm-time).  48 accumulators + 48 operand registers fit two waves per SIMD next to the main
   // loop's own; 80 + 80 do not (nor 48 + 96 with a residual operand: measured, spills between the loads).
   constexpr bool PRE = (EPI == 2);
-  static_assert(!PRE || (TM == 1 && WN == 1 && (TN <= 3 || (TN == 5 && !TWO))), "prefetched epilogue: single-row-block tiles only");
+  static_assert(!PRE || (TM == 1 && WN == 1 && TN <= 3), "prefetched epilogue: narrow single-row-block tiles only");
+  // (round 4, single-tensor operand: the same at 128x160 — 80 accumulators + 80 prefetched operands — still does not fit:
+  // 200 B of scratch, 30-40 of the operands are parked there as they arrive, which puts their HBM round trip in front of
+  // the K loop again: bwd-data GEMMs 23.1 -> 25.0 ms per step, profiles/r04_ab_calls.txt call 13)
   // (EPI 3 / 4, round 4: a straight-line MASKED epilogue for the single-tensor bwd-data launches — forward input for the
   // mask and x_hat, optional residual, BatchNorm-backward sums; 0-260 B of scratch once the epilogue addresses were
   // fenced — measured no faster than the generic epilogue below: bwd-data GEMMs 25.95 ms per step with it, 25.81 without
@@ -1331,10 +1334,6 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   const bool fwd = !two && !A.ep_x && A.stat_mode != 2 && !(A.ep_add && A.add_div > 1 && A.add_div % 32 != 0);
   GemmCfg c = pick_gemm(A.M, A.K, A.N, two, stream, fwd);
   if (stream && pre_ok(A) && pre_wanted(A)) c = kGemmCfgs[4];
-  // round 4: with the single-tensor operand the 128x160 tile has the registers for its 80 prefetched mask operands too
-  // (probe: DL3_GEMM_PRE5=1): outputs made of whole 160-column tiles
-  const bool pre5 = stream && !two && pre_ok(A) && pre_wanted(A) && A.N % 160 == 0 && env_int("DL3_GEMM_PRE5") == 1;
-  if (pre5) c = kGemmCfgs[3];
   A.mtiles = dl3_cdiv(A.M, c.BM);
   DL3_T(A.dbg = g_phase_dbg;)
   dim3 grid(dl3_cdiv(A.N, c.BN), gemm_grid_y(A.M, A.N, c));
@@ -1383,10 +1382,6 @@ int run_gemm(GemmArgs A, hipStream_t st) {
     if (c.id == 4 && pre_ok(A)) {
       if (two) hipLaunchKernelGGL((pw_gemm_stream_kernel<1, 3, true, 16, 2, 1>), grid, blk, 0, st, A);
       else hipLaunchKernelGGL((pw_gemm_stream_kernel<1, 3, false, 16, 2, 1>), grid, blk, 0, st, A);
-      return (int)grid.y;
-    }
-    if (pre5) {
-      hipLaunchKernelGGL((pw_gemm_stream_kernel<1, 5, false, 16, 2, 1>), grid, blk, 0, st, A);
       return (int)grid.y;
     }
     switch (c.id) {
