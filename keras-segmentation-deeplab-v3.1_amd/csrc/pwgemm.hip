@@ -63,6 +63,9 @@ constexpr int BK = 16;
 #ifndef DL3_STREAM_KT_BWD1
 #define DL3_STREAM_KT_BWD1 16  // K-tile depth of the single-tensor bwd-data instantiation (dY materialised, round 4)
 #endif
+#ifndef DL3_STREAM_PD_SMALL
+#define DL3_STREAM_PD_SMALL 2  // 32-row (small-M) stream kernels: K-tiles of operands in flight (register ring); 1 = the plain loop
+#endif
 #ifndef DL3_WGRAD_WGS_DEFAULT
 #define DL3_WGRAD_WGS_DEFAULT 1024
 #endif
@@ -567,53 +570,58 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
     }
     f32x4 an[TM][NJ], an2[TM][NJ], ac[TM][NJ], rb[NB];
 
-    auto load_A = [&](int kt) {
+    // (the `_to` / `_from` forms name the register set: the ring loop of the 32-row kernels keeps several K-tiles in flight)
+    auto load_A_to = [&](int kt, f32x4 (&da)[TM][NJ], f32x4 (&da2)[TM][NJ]) {
 #pragma unroll
       for (int j = 0; j < NJ; j++) {
         const int kc = min(kt * KT + KH * lhi + 4 * j, P.K - 4);
 #pragma unroll
         for (int i = 0; i < TM; i++) {
-          an[i][j] = ld4(arow[i] + kc);
-          if (TWO) an2[i][j] = ld4(arow2[i] + kc);
+          da[i][j] = ld4(arow[i] + kc);
+          if (TWO) da2[i][j] = ld4(arow2[i] + kc);
         }
       }
     };
-    auto load_B = [&](int kt) {
+    auto load_B_to = [&](int kt, f32x4 (&db)[NB]) {
 #pragma unroll
       for (int i = 0; i < NB; i++) {
         const int idx = tid + 256 * i;
         if (NB * 256 == KT * BN / 4 || idx < KT * BN / 4) {
           const int kk = idx / (BN / 4), nq = idx % (BN / 4);
           const int krow = min(kt * KT + kk, P.K - 1), col = min(n0 + nq * 4, P.N - 4);
-          rb[i] = ld4(P.b + (size_t)krow * P.ldb + col);
+          db[i] = ld4(P.b + (size_t)krow * P.ldb + col);
         }
       }
     };
-    auto store_B = [&](float *Bs) {
+    auto store_B_from = [&](float *Bs, const f32x4 (&db)[NB]) {
 #pragma unroll
       for (int i = 0; i < NB; i++) {
         const int idx = tid + 256 * i;
-        if (NB * 256 == KT * BN / 4 || idx < KT * BN / 4) st4(&Bs[(idx / (BN / 4)) * LDB + (idx % (BN / 4)) * 4], rb[i]);
+        if (NB * 256 == KT * BN / 4 || idx < KT * BN / 4) st4(&Bs[(idx / (BN / 4)) * LDB + (idx % (BN / 4)) * 4], db[i]);
       }
     };
+    auto load_A = [&](int kt) { load_A_to(kt, an, an2); };
+    auto load_B = [&](int kt) { load_B_to(kt, rb); };
+    auto store_B = [&](float *Bs) { store_B_from(Bs, rb); };
     // loaded registers of K-tile kt -> MFMA operand values.  f32 path: straight into the operand registers ac, AFTER the
     // last MFMA of the running K-tile has been issued (round 3: a wave's own VALU work does not overlap its own MFMAs, so
     // there is nothing to gain from placing it earlier, and the separate copy an -> ac cost 8 v_mov per K-tile);
     // split path: in place (an <- T(an)), split3 reads it
-    auto transform = [&](int kt) {
+    auto transform_from = [&](int kt, f32x4 (&sa)[TM][NJ], const f32x4 (&sa2)[TM][NJ]) {
 #pragma unroll
       for (int j = 0; j < NJ; j++) {
         const int k = kt * KT + KH * lhi + 4 * j;
         const f32x4 fa = ld4(cf + k), fc = ld4(cf + KC + k);
 #pragma unroll
         for (int i = 0; i < TM; i++) {
-          f32x4 v = fa * an[i][j] + fc;
-          if (TWO) v += ld4(cf + 2 * KC + k) * an2[i][j];
-          if constexpr (SPL) an[i][j] = dl3_act4(v, P.a_act);
+          f32x4 v = fa * sa[i][j] + fc;
+          if (TWO) v += ld4(cf + 2 * KC + k) * sa2[i][j];
+          if constexpr (SPL) sa[i][j] = dl3_act4(v, P.a_act);
           else ac[i][j] = dl3_act4(v, P.a_act);
         }
       }
     };
+    auto transform = [&](int kt) { transform_from(kt, an, an2); };
 
     if constexpr (SPL) {
       // K-tile kt: [weights of kt+1 -> LDS by DMA] [MFMAs of k-step 0] [A of kt+1: wait, transform, split; request A of
@@ -696,6 +704,63 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
         __syncthreads();
         if (more) take_next();
       }
+    } else if constexpr (WN == 4 && DL3_STREAM_PD_SMALL > 1) {
+    // 32-row tiles (small M: a few hundred workgroups, each a long serial chain of short K-tiles — 8-16 MFMAs per wave):
+    // a ring of PD register sets keeps PD K-tiles of both operands in flight; __syncthreads only waits for the LDS
+    // (lgkmcnt) on gfx950, so the requests survive the barriers.  The loop is unrolled by PD so that the set index is a
+    // constant.  Measured (round 4, call 14, same box): B=2 478.5 / 477.7 img/s with PD = 1, 486.2 / 486.1 with 2, 480.2 /
+    // 480.3 with 3 (251-254 VGPRs: two workgroups per CU instead of three); B=4 683 / 690 / 687; B=16 unchanged.  The exposed
+    // round trip was a small part of these K-tiles after all — their 8-16 MFMAs on a 160-wide output padded to 256 columns
+    // are most of the 0.7 us each takes.
+    constexpr int PD = (TWO && DL3_STREAM_PD_SMALL > 2) ? 2 : DL3_STREAM_PD_SMALL;  // (two-tensor operand: a third set spills)
+    f32x4 ra[PD][TM][NJ], ra2[PD][TM][NJ], rbb[PD][NB];
+#pragma unroll
+    for (int d = 0; d < PD; d++)
+      if (d < ktiles) {
+        load_B_to(d, rbb[d]);
+        load_A_to(d, ra[d], ra2[d]);
+      }
+    __syncthreads();  // the previous row tile is done with the LDS
+    store_B_from(lds, rbb[0]);
+    transform_from(0, ra[0], ra2[0]);
+    __syncthreads();
+    DL3_T(tq1 = clock64();)
+    for (int kt0 = 0; kt0 < ktiles; kt0 += PD) {
+#pragma unroll
+      for (int d = 0; d < PD; d++) {
+        const int kt = kt0 + d;
+        if (kt < ktiles) {  // (the same for every wave of the workgroup: the barrier below is safe)
+          const float *Bs = lds + (kt & 1) * KT * LDB;
+          // set d (K-tile kt) went to the LDS / the operand registers at the end of the previous K-tile: refill it
+          if (kt + PD < ktiles) {
+            load_B_to(kt + PD, rbb[d]);
+            load_A_to(kt + PD, ra[d], ra2[d]);
+          }
+          float bf[2][TN];
+#pragma unroll
+          for (int j = 0; j < TN; j++) bf[0][j] = Bs[(KH * lhi) * LDB + (wn * TN + j) * 32 + l31];
+#pragma unroll
+          for (int s_ = 0; s_ < KH; ++s_) {
+            const int cur = s_ & 1, nxt = cur ^ 1;
+            if (s_ + 1 < KH) {
+#pragma unroll
+              for (int j = 0; j < TN; j++) bf[nxt][j] = Bs[(KH * lhi + s_ + 1) * LDB + (wn * TN + j) * 32 + l31];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+              for (int j = 0; j < TN; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[i][s_ >> 2][s_ & 3], bf[cur][j], acc[i][j], 0, 0, 0);
+          }
+          if (kt + 1 < ktiles) {
+            const int dn = (d + 1) % PD;  // (a constant once the loop is unrolled)
+            store_B_from(lds + ((kt + 1) & 1) * KT * LDB, rbb[dn]);
+            transform_from(kt + 1, ra[dn], ra2[dn]);
+          }
+          __syncthreads();
+        }
+      }
+    }
     } else {
     load_A(0);
     load_B(0);

@@ -268,8 +268,13 @@ def test_pwconv_every_tile_configuration(L, cfg, monkeypatch):
     monkeypatch.setenv("DL3_GEMM_CFG", str(cfg))
     test_pwconv_fwd(L, (1000, 160, 960, 0, 0, False, 2))
     test_pwconv_fwd(L, (96, 64, 384, 64, 0, True, None))
+    test_pwconv_fwd(L, (300, 24, 144, 0, 0, False, 2))     # two K-tiles, the second one ragged
+    test_pwconv_fwd(L, (200, 16, 96, 0, 0, False, None))   # a single K-tile
+    test_pwconv_fwd(L, (520, 960, 160, 0, 0, False, 2))    # sixty K-tiles
     test_pwconv_bwd_data(L, (520, 160, 960, 2, True, 1, True))
     test_pwconv_bwd_data(L, (256, 320, 256, None, True, 2, True))
+    test_pwconv_bwd_data(L, (200, 144, 24, 2, True, 1, True))
+    test_pwconv_bwd_data(L, (520, 960, 160, 2, False, 1, True))  # single-tensor operand, mask + residual gradient
 
 
 @pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 6])
