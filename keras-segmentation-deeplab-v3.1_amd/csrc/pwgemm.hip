@@ -1475,16 +1475,31 @@ struct WgCfg { int id, BKT, BNT; };
 const WgCfg kWgCfgs[] = {{0, 64, 64},  {1, 128, 128}, {2, 160, 128}, {3, 128, 160}, {4, 64, 128},
                          {5, 128, 64}, {6, 32, 128},  {7, 128, 32},  {8, 96, 128},  {9, 128, 96}};
 
-int wgrad_splits(int M, int K, int N, const WgCfg &c) {
+// M splits the tile cost model reasons with: ~1024 workgroups, capped by slab traffic and by rows per split
+int wgrad_splits_model(int M, int K, int N, const WgCfg &c, int target = DL3_WGRAD_WGS_DEFAULT) {
   const long tiles = (long)dl3_cdiv(K, c.BKT) * dl3_cdiv(N, c.BNT);
   const int wgs = env_int("DL3_WGRAD_WGS");  // tuning aid: target number of workgroups per weight-gradient launch
-  long S = (wgs > 0 ? wgs : DL3_WGRAD_WGS_DEFAULT) / tiles;
+  long S = (wgs > 0 ? wgs : target) / tiles;
   const long cap_traffic = (long)((double)M * (K + N) / (4.0 * K * N));
   const long cap_rows = M / 64;
   if (S > cap_traffic) S = cap_traffic;
   if (S > cap_rows) S = cap_rows;
   if (S < 1) S = 1;
   return (int)S;
+}
+
+// ... and the M splits a launch gets.  Every split writes a K x N slab that the fold reads back; for the 160-wide tiles
+// on a small weight matrix (<= 160 x 960) at 32k-128k rows that is a fifth of the launch's bytes, and two workgroups per CU
+// (half the slabs) are faster.  Measured in situ (round 4, calls 16 / 17, B=16: M = 65536): 160 x 960 291 -> 258 us,
+// 960 x 160 253 -> 230, 576 x 160 180 -> 156; whole step 1 055 / 1 068 / 1 071 -> 1 068 / 1 082 / 1 086 img/s.  NOT a general
+// rule: the same halving on Xception's 736 x 736 at the same M costs 24 % of the launch, on 64 x 384 5 %, and at
+// M = 16384 (B=4) the 160-wide shapes lose 12 % (profiles/r04_ab_calls.txt, call 17).
+int wgrad_splits(int M, int K, int N, const WgCfg &c) {
+  const int S = wgrad_splits_model(M, K, N, c);
+  if (env_int("DL3_WGRAD_WGS") > 0 || env_int("DL3_WGRAD_HALVE") == 0) return S;
+  const bool wide = (c.id == 2 || c.id == 3) && (long)K * N <= 160L * 960 && M >= 32768;
+  if (wide && 2.0 * (double)S * K * N > 0.1 * (double)M * (K + N)) return wgrad_splits_model(M, K, N, c, DL3_WGRAD_WGS_DEFAULT / 2);
+  return S;
 }
 
 WgCfg pick_wgrad(int M, int K, int N, bool two) {
@@ -1503,7 +1518,7 @@ WgCfg pick_wgrad(int M, int K, int N, bool two) {
   for (const WgCfg &c : kWgCfgs) {
     const double ntk = dl3_cdiv(K, c.BKT), ntn = dl3_cdiv(N, c.BNT);
     // few rows: the M split is capped (partial-slab traffic), so small tiles are what fills the chip
-    const double blocks = ntk * ntn * wgrad_splits(M, K, N, c);
+    const double blocks = ntk * ntn * wgrad_splits_model(M, K, N, c);
     const double util = blocks < 512.0 ? blocks / 512.0 : 1.0;
     const double t_mfma = 2.0 * M * ntk * c.BKT * ntn * c.BNT / 80e12 / util;
     const double t_mem = 4.0 * ((double)M * K * (1.0 + 0.25 * (ntn - 1)) +
