@@ -237,6 +237,15 @@ int fused_rows_per_wg(int M) {
   const char *e = getenv("DL3_FUSED_WGS");  // tuning aid: target number of workgroups
   long want = e && atol(e) > 0 ? atol(e) : 2048;  // (B = 128, 16 -> 96 at 256x256: 1024 -> 3.06 ms, 2048 -> 2.45 ms)
   long stages = dl3_cdiv(M, FMS);
+  // every workgroup leaves a K x N slab behind: with few rows (B <= 16) keep at least DL3_FUSED_MINROWS rows per workgroup,
+  // down to two workgroups per CU
+  if (!(e && atol(e) > 0)) {
+    const char *r = getenv("DL3_FUSED_MINROWS");
+    const long minrows = r && atol(r) > 0 ? atol(r) : 512;
+    long cap = (long)M / minrows;
+    if (cap < 512) cap = 512;
+    if (want > cap) want = cap;
+  }
   if (want > stages) want = stages;
   return (int)(dl3_cdiv((int)stages, (int)want) * FMS);
 }
