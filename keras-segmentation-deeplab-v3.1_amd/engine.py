@@ -218,7 +218,7 @@ class Engine:
         # both gradients of an HBM-bound 1x1 convolution with a small weight matrix in one pass (dl3_pwconv_bwd_fused):
         # layers with at least DL3_FUSED_ROWS pixel rows (DL3_FUSED_BWD=0 disables)
         self.fused_bwd = os.environ.get("DL3_FUSED_BWD", "1") != "0"
-        self.fused_min_rows = int(os.environ.get("DL3_FUSED_ROWS", "131072"))
+        self.fused_min_rows = int(os.environ.get("DL3_FUSED_ROWS", "32768"))
         self.dy_buf = None
         self.fork = os.environ.get("DL3_FORK", "0") in ("1", "2")
         # DL3_FORK=2 (experiment): only the weight gradient that can run next to an HBM-bound depthwise backward launch
