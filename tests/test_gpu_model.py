@@ -728,6 +728,32 @@ def test_backward_fork_is_bit_identical(monkeypatch):
         assert v[1] == ref[1] and np.array_equal(v[0], ref[0]), k
 
 
+def test_fused_both_gradient_kernel_inside_a_small_plan(monkeypatch):
+    """dl3_pwconv_bwd_fused serves layers of >= DL3_FUSED_ROWS pixel rows (32768: nothing in a 64x64 test model).  With the
+    threshold at 1 the early 1x1 convolutions of the same model go through it — with a residual addend, with BatchNorm
+    sums against another tensor, behind the stem — and the step must agree with the unfused plan to fp32 rounding."""
+    model, params = _build(input_shape=(64, 64, 3), classes=3)
+    _load(model, params)
+    rng = np.random.default_rng(13)
+    x = rng.integers(0, 256, (2, 64, 64, 3)).astype(np.float32)
+    y = rng.integers(0, 4, (2, 64 * 64)).astype(np.float32)
+    sw = (y < 3).astype(np.float32)
+    got = {}
+    for i, (rows, on) in enumerate([("1", "1"), ("1", "0")]):
+        monkeypatch.setenv("DL3_FUSED_ROWS", rows)
+        monkeypatch.setenv("DL3_FUSED_BWD", on)
+        eng = model._engine(2, True, dropout=False, use_graph=False, seed=300 + i)
+        n = sum(1 for rec in eng.ops_bwd if rec[0] == "dl3_pwconv_bwd_fused")
+        assert (n >= 5) == (on == "1"), n
+        eng.set_input(x)
+        eng.set_targets(y, sw)
+        eng.fwd_bwd()
+        torch.cuda.synchronize()
+        got[on] = (eng.grads.cpu().numpy().copy(), float(eng.loss[0].item()))
+    assert got["1"][1] == got["0"][1]
+    assert _l2(got["1"][0], got["0"][0]) < 2e-5, _l2(got["1"][0], got["0"][0])
+
+
 @pytest.mark.parametrize("backbone,shape", [("mobilenetv2", (96, 96, 3)), ("xception", (64, 64, 3))])
 def test_poisoned_scratch_changes_nothing(monkeypatch, backbone, shape):
     """DL3_POISON_SCRATCH=1 fills every scratch allocation of the engine (statistic / weight-gradient partial buffers,
