@@ -514,6 +514,12 @@ __global__ __launch_bounds__(256) void xent32_kernel(const float *__restrict__ x
   if (threadIdx.x == 0) loss_part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
+#ifndef XENT_PS
+#define XENT_PS 12  // prefetching form of the row kernel: source floats per thread and source row ...
+#endif
+#ifndef XENT_PP
+#define XENT_PP 2   // ... and output pixels per thread
+#endif
 // The training tail in one pass per output ROW: a workgroup owns output row (n, oy); phase 1 interpolates the
 // low-resolution logits, evaluates softmax / loss / dlogits for the Wo pixels of the row and leaves dlogits in LDS;
 // phase 2 folds the row onto the Wi input columns (the x half of the transposed bilinear resize, fixed summation
@@ -521,13 +527,13 @@ __global__ __launch_bounds__(256) void xent32_kernel(const float *__restrict__ x
 // x-folded rows [N,Ho,Wi,C] (8x smaller) and dl3_resize_bilinear_bwd_rows finishes with the y half.
 // The two low-resolution logit rows an output row interpolates between are staged in LDS first: the 4 x C neighbour
 // reads per pixel then come from LDS instead of the texture-address path (8 neighbouring pixels share them).
-template <int MAXC>
-__global__ __launch_bounds__(256) void xent32_fold_kernel(const float *__restrict__ x, const float *__restrict__ labels,
+template <int MAXC, bool PREF>
+__global__ __launch_bounds__(256, 2) void xent32_fold_kernel(const float *__restrict__ x, const float *__restrict__ labels,
                                                           const float *__restrict__ weights,
                                                           const float *__restrict__ nnz, float *__restrict__ xfold,
                                                           float *__restrict__ loss_part, int N, int C, int Hi, int Wi,
                                                           int Ho, int Wo, float sy, float sx) {
-  extern __shared__ float fold_tile[];  // [Wo][C] dlogits of the row, [2][Wi][C] source rows, [Wo] x lerp table
+  extern __shared__ __attribute__((aligned(16))) float fold_tile[];  // [Wo][C] dlogits of the row, [2][Wi][C] source rows, [Wo] x lerp table
   __shared__ float red[4];
   float *src = fold_tile + (size_t)Wo * C;
   float *xw = src + 2 * (size_t)Wi * C;  // fractional x weight of every output column
@@ -539,16 +545,54 @@ __global__ __launch_bounds__(256) void xent32_fold_kernel(const float *__restric
   }
   const float inv_nnz = 1.f / fmaxf(*nnz, DL3_NNZ_FLOOR);
   float lsum = 0.f;
+  // PREF (2 * Wi * C <= 2 * 256 * XENT_PS source floats, Wo <= 256 * XENT_PP pixels per row — the host checks): a row's global
+  // operands — its two source rows, its labels and weights — are requested one row AHEAD into registers and only stored
+  // to the LDS / consumed when their row starts.  Three workgroups of four waves per CU (52 KB of LDS each for a 512 x 21 row
+  // over 32 source columns) hide little of a row's dependent round trips (source rows, labels inside phase 1).  Measured
+  // (round 4, call 24, B=128: 65536 rows): 1.54 -> 1.36 ms per step; bit-identical results (tests).
+  // (named registers, not arrays: the arrays stayed in scratch — 112 B per lane — whatever the indexing)
+  static_assert(XENT_PS == 12 && XENT_PP == 2, "three float4 per thread and source row, two pixels per thread");
+  float4 plo0, plo1, plo2, phi0, phi1, phi2;
+  float plab0, plab1, pwt0, pwt1;
+  plo0 = plo1 = plo2 = phi0 = phi1 = phi2 = make_float4(0.f, 0.f, 0.f, 0.f);
+  plab0 = plab1 = pwt0 = pwt1 = 0.f;
+  const int nq = Wi * C / 4;
+  auto prefetch = [&](int row) __attribute__((always_inline)) {
+    const int n = row / Ho, oy = row - n * Ho;
+    const Lerp ly = tf1_lerp(oy, sy, Hi);
+    const float4 *blo = reinterpret_cast<const float4 *>(x + ((size_t)n * Hi + ly.lo) * Wi * C);
+    const float4 *bhi = reinterpret_cast<const float4 *>(x + ((size_t)n * Hi + ly.hi) * Wi * C);
+    const int i0 = min((int)threadIdx.x, nq - 1), i1 = min((int)threadIdx.x + 256, nq - 1), i2 = min((int)threadIdx.x + 512, nq - 1);
+    plo0 = blo[i0]; phi0 = bhi[i0];
+    plo1 = blo[i1]; phi1 = bhi[i1];
+    plo2 = blo[i2]; phi2 = bhi[i2];
+    const size_t m0 = (size_t)row * Wo + min((int)threadIdx.x, Wo - 1), m1 = (size_t)row * Wo + min((int)threadIdx.x + 256, Wo - 1);
+    plab0 = labels[m0]; plab1 = labels[m1];
+    pwt0 = weights ? weights[m0] : 1.f; pwt1 = weights ? weights[m1] : 1.f;
+  };
+  if (PREF && (int)blockIdx.x < N * Ho) prefetch(blockIdx.x);
   for (int row = blockIdx.x; row < N * Ho; row += gridDim.x) {
     const int n = row / Ho, oy = row - n * Ho;
     const Lerp ly = tf1_lerp(oy, sy, Hi);
-    const float *b = x + (size_t)n * Hi * Wi * C;
-    for (int i = threadIdx.x; i < Wi * C; i += 256) {
-      src[i] = b[(size_t)ly.lo * Wi * C + i];
-      src[Wi * C + i] = b[(size_t)ly.hi * Wi * C + i];
+    float clab0 = 0.f, clab1 = 0.f, cwt0 = 0.f, cwt1 = 0.f;
+    if constexpr (PREF) {
+      float4 *s4lo = reinterpret_cast<float4 *>(src), *s4hi = reinterpret_cast<float4 *>(src + Wi * C);
+      const int i0 = threadIdx.x, i1 = threadIdx.x + 256, i2 = threadIdx.x + 512;
+      if (i0 < nq) { s4lo[i0] = plo0; s4hi[i0] = phi0; }
+      if (i1 < nq) { s4lo[i1] = plo1; s4hi[i1] = phi1; }
+      if (i2 < nq) { s4lo[i2] = plo2; s4hi[i2] = phi2; }
+      clab0 = plab0; clab1 = plab1; cwt0 = pwt0; cwt1 = pwt1;
+    } else {
+      const float *b = x + (size_t)n * Hi * Wi * C;
+      for (int i = threadIdx.x; i < Wi * C; i += 256) {
+        src[i] = b[(size_t)ly.lo * Wi * C + i];
+        src[Wi * C + i] = b[(size_t)ly.hi * Wi * C + i];
+      }
     }
     __syncthreads();
-    for (int ox = threadIdx.x; ox < Wo; ox += 256) {
+    if (PREF && row + (int)gridDim.x < N * Ho) prefetch(row + gridDim.x);
+    // one output pixel: interpolate, softmax, loss, dlogits into the LDS row (labf / wf: its label and sample weight)
+    auto pixel = [&](int ox, float labf, float wf) __attribute__((always_inline)) {
       const Lerp lx = tf1_lerp(ox, sx, Wi);
       const float *tl = src + lx.lo * C, *tr = src + lx.hi * C;
       const float *bl = src + (Wi + lx.lo) * C, *br = src + (Wi + lx.hi) * C;
@@ -570,9 +614,8 @@ __global__ __launch_bounds__(256) void xent32_fold_kernel(const float *__restric
         ssum += z[c];
       }
       const float inv = 1.f / ssum;
-      const size_t m = (size_t)row * Wo + ox;
-      const int t = (int)labels[m];
-      const float w = (t >= 0 && t < C) ? (weights ? weights[m] : 1.f) : 0.f;  // void rows: zero loss and gradient
+      const int t = (int)labf;
+      const float w = (t >= 0 && t < C) ? wf : 0.f;  // void rows: zero loss and gradient
       float psum = 0.f, pt = 0.f;
 #pragma unroll
       for (int c = 0; c < MAXC; c++) {
@@ -591,6 +634,20 @@ __global__ __launch_bounds__(256) void xent32_fold_kernel(const float *__restric
 #pragma unroll
       for (int c = 0; c < MAXC; c++)
         if (c < C) fold_tile[ox * C + c] = (z[c] - (c == t ? 1.f : 0.f)) * gs;
+    };
+    if constexpr (PREF) {
+      // (a real loop: unrolled, the scheduler hoists every LDS operand of the row's pixels and spills — 256 VGPRs + scratch
+      // against 65 for the loop)
+#pragma nounroll
+      for (int j = 0; j < 2; j++) {
+        const int ox = threadIdx.x + 256 * j;
+        if (ox < Wo) pixel(ox, j == 0 ? clab0 : clab1, j == 0 ? cwt0 : cwt1);
+      }
+    } else {
+      for (int ox = threadIdx.x; ox < Wo; ox += 256) {
+        const size_t m = (size_t)row * Wo + ox;
+        pixel(ox, labels[m], weights ? weights[m] : 1.f);
+      }
     }
     __syncthreads();
     // x fold: work item = (input column, group of 3 channels); the lerp of an output column comes from the table
@@ -843,12 +900,16 @@ extern "C" int dl3_upsample_softmax_xent_fold(const float *logits_lo, const floa
   DL3_UNSUPPORTED(lds > 64 * 1024, "upsample_softmax_xent_fold: (%d + 2*%d) x %d floats exceed 64 KB of LDS", Wo, Wi, C);
   const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
   const dim3 grid(dl3_xent_fold_partials(N, Ho));
-  if (C <= 24)
-    hipLaunchKernelGGL(xent32_fold_kernel<24>, grid, dim3(256), lds, (hipStream_t)stream, logits_lo, labels, weights, nnz,
-                       dlogits_xfold, loss_partial, N, C, Hi, Wi, Ho, Wo, sy, sx);
-  else
-    hipLaunchKernelGGL(xent32_fold_kernel<32>, grid, dim3(256), lds, (hipStream_t)stream, logits_lo, labels, weights, nnz,
-                       dlogits_xfold, loss_partial, N, C, Hi, Wi, Ho, Wo, sy, sx);
+  const char *pe = getenv("DL3_XENT_PREF");  // 0 = every row requests its own operands (tuning / test aid)
+  // (float4 requests and LDS stores: source rows of whole float4s, 16-byte aligned; the source tile starts Wo * C floats in)
+  const bool pref = (long)Wi * C <= 256L * XENT_PS && Wo <= 256 * XENT_PP && (Wi * C) % 4 == 0 && ((long)Wo * C) % 4 == 0 &&
+                    (((uintptr_t)logits_lo) & 15) == 0 && !(pe && atoi(pe) == 0);
+#define DL3_XENT(MAXC_, PREF_)                                                                                         \
+  hipLaunchKernelGGL((xent32_fold_kernel<MAXC_, PREF_>), grid, dim3(256), lds, (hipStream_t)stream, logits_lo, labels, \
+                     weights, nnz, dlogits_xfold, loss_partial, N, C, Hi, Wi, Ho, Wo, sy, sx)
+  if (C <= 24) { if (pref) DL3_XENT(24, true); else DL3_XENT(24, false); }
+  else { if (pref) DL3_XENT(32, true); else DL3_XENT(32, false); }
+#undef DL3_XENT
   DL3_LAUNCH_CHECK("upsample_softmax_xent_fold");
   return DL3_OK;
 }

@@ -1020,8 +1020,12 @@ def test_fused_upsample_xent(L, void_w):
 
 
 @pytest.mark.parametrize("void_w", [False, True])
-@pytest.mark.parametrize("dims", [(2, 8, 8, 64, 64, 21), (1, 5, 7, 17, 23, 3), (3, 16, 16, 64, 64, 32), (2, 4, 4, 4, 4, 2)])
-def test_xent_fold_and_rows(L, dims, void_w):
+@pytest.mark.parametrize("dims", [(2, 8, 8, 64, 64, 21), (1, 5, 7, 17, 23, 3), (3, 16, 16, 64, 64, 32), (2, 4, 4, 4, 4, 2),
+                                  (2, 32, 32, 512, 512, 21),    # the benchmark's row (MobileNetV2: logits at 1/16): two pixels per thread
+                                  (1, 64, 64, 256, 256, 21),    # Xception-style 1/4 logits: three float4 per thread and source row
+                                  (2, 16, 32, 64, 300, 8),      # second pixel of some threads only
+                                  (1, 8, 100, 16, 200, 32)])    # source rows too long for the prefetching form
+def test_xent_fold_and_rows(L, dims, void_w, monkeypatch):
     """dl3_upsample_softmax_xent_fold + dl3_resize_bilinear_bwd_rows == the oracle's loss and the gradient it sends
     through the transposed legacy-bilinear resize, without the full-resolution dlogits"""
     N, Hi, Wi, Ho, Wo, C = dims
@@ -1053,6 +1057,12 @@ def test_xent_fold_and_rows(L, dims, void_w):
          N, Hi, Wi, Ho, Wo, C)
     call("dl3_resize_bilinear_bwd", ptr(dl), C, ptr(dlo2), C, N, Hi, Wi, Ho, Wo, C, 0, None, 0)
     assert relerr(host(dlo), host(dlo2)) < 1e-5
+    # rows that request their operands one row ahead (the default where the row fits) == rows that request their own
+    monkeypatch.setenv("DL3_XENT_PREF", "0")
+    xf2, lp3 = empty(N, Ho, Wi, C), empty(P)
+    call("dl3_upsample_softmax_xent_fold", ptr(dev(lo)), ptr(dev(labels)), ptr(dev(w)), ptr(nnz), ptr(xf2), ptr(lp3), N, Hi,
+         Wi, Ho, Wo, C)
+    assert np.array_equal(host(xf2), host(xfold)) and np.array_equal(host(lp3), host(lp))
 
 
 def test_transpose_batched(L):
