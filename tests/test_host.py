@@ -32,6 +32,23 @@ def test_sizing_queries_of_the_weight_gradient_folds():
             S = L.dl3_pwconv_bwd_weight_splits(M, K, N, two)
             assert S >= 1 and S * K * N * 4 <= L.dl3_pwconv_bwd_weight_workspace(M, K, N), (M, K, N, two, S)
     assert L.dl3_pwconv_bwd_weight_splits(0, 8, 8, 0) == 0
+    # round 4: at 32k-128k rows the 160-wide tiles on a small weight matrix get HALF the M splits (their K x N slabs are a
+    # fifth of the launch's bytes); nowhere else, and never more slabs than the workspace query promised
+    for K, N in [(160, 960), (960, 160), (576, 160)]:
+        few, many = L.dl3_pwconv_bwd_weight_splits(65536, K, N, 1), L.dl3_pwconv_bwd_weight_splits(524288, K, N, 1)
+        assert 2 * few <= many + 2 and few >= 8, (K, N, few, many)
+        for M in (8192, 16384, 32768, 65536, 131072, 262144, 524288):
+            for two in (0, 1):
+                S = L.dl3_pwconv_bwd_weight_splits(M, K, N, two)
+                assert 1 <= S and S * K * N * 4 <= L.dl3_pwconv_bwd_weight_workspace(M, K, N), (M, K, N, two, S)
+    assert L.dl3_pwconv_bwd_weight_splits(65536, 736, 736, 1) == L.dl3_pwconv_bwd_weight_splits(524288, 736, 736, 1)
+    # the fused both-gradient kernel: at most 2048 workgroups, at least 512 rows each down to 512 workgroups; slabs fit
+    for M, want in [(8388608, 2048), (1048576, 2048), (262144, 512), (131072, 512), (32768, 512), (4096, 128)]:
+        S = L.dl3_pwconv_bwd_fused_splits(M, 16, 96)
+        assert S == want, (M, S)
+        assert S * 16 * 96 * 4 <= L.dl3_pwconv_bwd_fused_workspace(M, 16, 96)
+    assert L.dl3_pwconv_bwd_fused_supported(1000, 24, 144) == 2 and L.dl3_pwconv_bwd_fused_supported(1000, 144, 24) == 1
+    assert L.dl3_pwconv_bwd_fused_supported(1000, 32, 192) == 0 and L.dl3_pwconv_bwd_fused_splits(1000, 32, 192) == 0
     for P, n, cols in [(1, 5, 64), (32, 6400, 64), (33, 100, 32), (256, 9 * 960, 32), (257, 9, 8), (1365, 153600, 8)]:
         assert L.dl3_reduce_partials_blocks(P, n) == -(-n // cols)
     assert L.dl3_reduce_partials_blocks(0, 10) == 0 and L.dl3_reduce_partials_blocks(4, 0) == 0
