@@ -100,6 +100,11 @@ int dl3_set_gemm_math(int mode);
 int dl3_get_gemm_math(void);
 /* P for the [M,K]x[K,N] GEMM's per-output-channel partials */
 int dl3_pwconv_partials(int M, int K, int N);
+/* which kernel a dl3_pwconv_fwd launch of this shape takes (16-byte aligned operands, leading dimensions multiples of 4,
+ * no addend): 0 the tiled MFMA GEMM, 1 the weight-stationary streaming kernel of the HBM-bound layers (round 5: the
+ * whole K x N matrix in LDS, every wave walks 32-row tiles on its own, 16-byte stores; deeplabv3p.py:175-198 at
+ * 16..192 channels, M >= 32768; DL3_FWD_WS=0 disables it).  Diagnostic only: results do not depend on it. */
+int dl3_pwconv_fwd_impl(int M, int K, int N);
 /* y[M,N](ldy) = T(x)[M,K](ldx) . w[K,N] (+bias[N]); stat_partial (nullable) [P][N][2] = sum(y), sum(y^2) */
 int dl3_pwconv_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
                    const float *w, const float *bias, float *y, int ldy, int M, int K, int N,
@@ -147,7 +152,7 @@ int dl3_pwconv_bwd_weight_dy(const float *x, int ldx, const float *in_scale, con
  *   dstat_partial (nullable) [S][K][2] = sum(dx), sum(dx * (stat_x - x_mean) * x_invstd) — stat_x is the forward input
  *   itself or, when the gradient reaches another BatchNorm'ed tensor unchanged through a residual Add, that tensor.
  * S = dl3_pwconv_bwd_fused_splits(M, K, N) workgroups / slabs / partial rows; workspace >= _workspace(M, K, N) bytes.
- * _supported: 0 unless K, N are multiples of 4 with ceil(K/32) * ceil(N/32) <= 5; 2: any epilogue; 1 (K > 64): without
+ * _supported: 0 unless K, N are multiples of 4 with ceil(K/32) * ceil(N/32) <= 6; 2: any epilogue; 1 (K > 64): without
  * dx_add and with stat_x == x only (-4 otherwise).  All operands 16-byte aligned, leading dimensions multiples of 4. */
 int dl3_pwconv_bwd_fused_supported(int M, int K, int N);
 int dl3_pwconv_bwd_fused_splits(int M, int K, int N);

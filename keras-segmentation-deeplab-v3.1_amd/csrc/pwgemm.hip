@@ -1263,6 +1263,206 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const long long 
     if (c0 + i < cols && r0 + tx < rows) out[(size_t)(c0 + i) * rows + r0 + tx] = tile[tx][i];
 }
 
+
+int env_int(const char *name);
+
+// ---------------------------------------------------------------------------------------
+// round 5: weight-stationary streaming forward kernel for the HBM-bound layers
+// ---------------------------------------------------------------------------------------
+// The expand / project convolutions of the first blocks (deeplabv3p.py:175-198: 16..192 channels on 256x256 .. 64x64 maps)
+// carry 5-14 FLOP per byte: they are streaming kernels, and the tiled GEMM above runs them at 2.3-4.6 TB/s (24 -> 144 at
+// 0.29 of the HBM peak) because a 128- or 256-row tile of a reduction of 16..32 is all prologue and epilogue — one or two
+// K-tiles, a weight tile re-staged per row tile, 16 four-byte stores per 32x32 sub-tile and lane, three column tiles
+// re-reading the rows.  Here the WHOLE weight matrix sits in LDS for the life of the workgroup (K x N <= 6 blocks of
+// 32 x 32), and every WAVE walks 32-row tiles on its own — no barrier in the loop:
+//   * the lane (row l & 31, half l >> 5) loads its K/2 consecutive floats of the NEXT tile (K/8 16-byte loads) while the
+//     current one is in the matrix pipe; with 3-4 workgroups per CU that keeps 12-16 tiles in flight per CU;
+//   * the producer's BatchNorm + ReLU6 is applied in registers, coefficient vectors in LDS;
+//   * K/2 x TN MFMAs (v_mfma_f32_32x32x2_f32) against B fragments read from LDS (32 consecutive floats per half-wave:
+//     conflict-free);
+//   * epilogue per 32-column block: bias, BatchNorm partial sums (per lane: its column), then the block goes through a
+//     4 KB per-wave LDS tile and leaves as 16-byte non-temporal stores — 4 instead of 16 store instructions per lane and
+//     block, 128 contiguous bytes per row and instruction (the epilogue of an HBM-bound kernel is store-ISSUE-bound).
+// Tile -> wave assignment is static (tile t belongs to wave t mod 4G): the statistic partial rows are deterministic.
+// KQ = K / 8 (16-byte loads per lane and tile), TN = ceil(N / 32).
+template <int KQ, int TN, int OC>
+__global__ __launch_bounds__(256, OC) void pw_fwd_ws_kernel(GemmArgs P) {
+  constexpr int KH = 4 * KQ, K = 8 * KQ, NP = 32 * TN;
+  // short reductions: the next tile's rows are requested one tile ahead (two register sets); long ones (>= 48 floats
+  // per lane) rely on the 12-16 waves of a CU being in different phases instead
+  constexpr bool PRE = KQ <= 4;
+  __shared__ float Ws[K * NP];        // W[k][n], zero beyond N
+  __shared__ float cf[2 * K];         // scale | shift of the input transform
+  __shared__ float bs[NP];            // bias
+  __shared__ float Cs[4 * 1024];      // per wave: one 32x32 block on its way out; at the end: the statistic fold
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const bool xform = (P.ka != nullptr);
+
+  for (int i = tid; i < K * NP; i += 256) {
+    const int k = i / NP, n = i % NP;
+    Ws[i] = n < P.N ? P.b[(size_t)k * P.ldb + n] : 0.f;
+  }
+  for (int i = tid; i < K; i += 256) {
+    cf[i] = xform ? P.ka[i] : 1.f;
+    cf[K + i] = xform ? P.kc[i] : 0.f;
+  }
+  for (int i = tid; i < NP; i += 256) bs[i] = (P.bias && i < P.N) ? P.bias[i] : 0.f;
+  float st1[TN], st2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; j++) st1[j] = st2[j] = 0.f;
+  __syncthreads();
+
+  const int ntiles = (P.M + 31) >> 5;
+  const int gw = blockIdx.x * 4 + wave, GW = gridDim.x * 4;
+  float *const cw = Cs + wave * 1024;
+  const float *const wfrag = Ws + KH * lhi * NP + l31;
+  const float *const cfs = cf + KH * lhi, *const cft = cf + K + KH * lhi;
+  const int c4 = (lane & 7) * 4, r0 = lane >> 3;
+
+  f32x4 nx[KQ];
+  auto load_tile = [&](int t) {
+    const int row = min(t * 32 + l31, P.M - 1);
+    const float *p = P.a + (size_t)row * P.lda + KH * lhi;
+#pragma unroll
+    for (int j = 0; j < KQ; j++) nx[j] = ld4(p + 4 * j);
+  };
+  if (PRE && gw < ntiles) load_tile(gw);
+  for (int t = gw; t < ntiles; t += GW) {
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+    if constexpr (PRE) {
+      // operand of this tile: transform in registers, then request the next tile into the same registers
+      float ac[KH];
+#pragma unroll
+      for (int j = 0; j < KQ; j++) {
+        const f32x4 v = dl3_act4(ld4(cfs + 4 * j) * nx[j] + ld4(cft + 4 * j), P.a_act);
+        ac[4 * j + 0] = v.x; ac[4 * j + 1] = v.y; ac[4 * j + 2] = v.z; ac[4 * j + 3] = v.w;
+      }
+      if (t + GW < ntiles) load_tile(t + GW);
+      __builtin_amdgcn_sched_barrier(0);  // (the requests stay in front of the MFMAs: the scheduler would sink them)
+#pragma unroll
+      for (int s = 0; s < KH; s++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[s], wfrag[s * NP + j * 32], acc[j], 0, 0, 0);
+    } else {
+      // all K/8 requests of the tile first (left alone the scheduler interleaves them with the MFMAs one by one to save
+      // registers — twelve exposed round trips per tile)
+      load_tile(t);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < KQ; q++) {
+        const f32x4 v = dl3_act4(ld4(cfs + 4 * q) * nx[q] + ld4(cft + 4 * q), P.a_act);
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+          for (int j = 0; j < TN; j++)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[e], wfrag[(4 * q + e) * NP + j * 32], acc[j], 0, 0, 0);
+      }
+    }
+
+    const int m0 = t * 32;
+    const bool full = m0 + 32 <= P.M;
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const float bj = bs[j * 32 + l31];
+      // BatchNorm partial sums of this lane's column; C layout (row (r & 3) + 8 (r >> 2) + 4 lhi, column l31) -> rows of
+      // 32 floats in LDS -> 16 bytes per lane
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float v = acc[j][r] + bj;
+        const bool ok = full || (m0 + (r & 3) + 8 * (r >> 2) + 4 * lhi < P.M);
+        st1[j] += ok ? v : 0.f;
+        st2[j] += ok ? v * v : 0.f;
+        cw[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 32 + l31] = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+      float *const cp = P.c + (size_t)(m0 + r0) * P.ldc + j * 32 + c4;
+      f32x4 o[4];
+#pragma unroll
+      for (int p = 0; p < 4; p++) o[p] = ld4(cw + (r0 + 8 * p) * 32 + c4);
+      if (full && j * 32 + 32 <= P.N) {  // (wave-uniform: the interior blocks store without a branch per instruction)
+#pragma unroll
+        for (int p = 0; p < 4; p++) st4_nt(cp + (size_t)(8 * p) * P.ldc, o[p]);
+      } else {
+        const bool c4ok = j * 32 + c4 < P.N;
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+          if (c4ok && m0 + r0 + 8 * p < P.M) st4_nt(cp + (size_t)(8 * p) * P.ldc, o[p]);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+
+  if (P.stat_mode != 0) {
+    // half-waves, then the four waves in wave order: one partial row per workgroup
+    __syncthreads();
+    float *sred = Cs;  // [4][NP][2] (NP <= 192: 6 KB)
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const float a1 = st1[j] + __shfl_xor(st1[j], 32, 64), a2 = st2[j] + __shfl_xor(st2[j], 32, 64);
+      if (lhi == 0) {
+        sred[(wave * NP + j * 32 + l31) * 2 + 0] = a1;
+        sred[(wave * NP + j * 32 + l31) * 2 + 1] = a2;
+      }
+    }
+    __syncthreads();
+    for (int cl = tid; cl < NP; cl += 256) {
+      if (cl < P.N) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+          a1 += sred[(w * NP + cl) * 2 + 0];
+          a2 += sred[(w * NP + cl) * 2 + 1];
+        }
+        P.part[((size_t)blockIdx.x * P.N + cl) * 2 + 0] = a1;
+        P.part[((size_t)blockIdx.x * P.N + cl) * 2 + 1] = a2;
+        for (int r = blockIdx.x + (int)gridDim.x; r < P.part_rows; r += (int)gridDim.x) {
+          P.part[((size_t)r * P.N + cl) * 2 + 0] = 0.f;
+          P.part[((size_t)r * P.N + cl) * 2 + 1] = 0.f;
+        }
+      }
+    }
+  }
+}
+
+// the layer shapes the kernel is instantiated for (K, N) -> (KQ, TN); 0: not served
+struct WsShape { int K, TN; };
+inline int ws_tn(int K, int N) {
+  if (K % 8 != 0 || N % 4 != 0) return 0;
+  const int tn = dl3_cdiv(N, 32);
+  // MobileNetV2's HBM-bound 1x1 convolutions (alpha = 1): 32->16, 16->96, 96->24, 24->144, 144->24, 144->32, 32->192, 192->32
+  switch (K) {
+    case 16: return tn == 3 ? tn : 0;
+    case 24: return tn == 5 ? tn : 0;
+    case 32: return (tn == 1 || tn == 6) ? tn : 0;
+    case 96: return tn == 1 ? tn : 0;
+    case 144: return tn == 1 ? tn : 0;
+    case 192: return tn == 1 ? tn : 0;
+    default: return 0;
+  }
+}
+int ws_grid(int M) {
+  // persistent: three workgroups per CU, never more waves than 32-row tiles
+  const int tiles = dl3_cdiv(M, 32);
+  const int g = dl3_cdiv(tiles, 4);
+  return g < 768 ? g : 768;
+}
+// forward launch served by the weight-stationary kernel?  (DL3_FWD_WS=0 disables; the tiled kernel serves everything)
+bool ws_wanted(const GemmArgs &A, bool fwd, bool vec) {
+  static const int env = env_int("DL3_FWD_WS");
+  static const int minrows = env_int("DL3_FWD_WS_ROWS");
+  if (env == 0 || !fwd || !vec || A.ep_add || A.a2) return false;
+  if (A.ldc % 4 != 0 || (((uintptr_t)A.c) & 15) != 0) return false;  // 16-byte stores
+  if (A.M < (minrows > 0 ? minrows : 32768)) return false;
+  return ws_tn(A.K, A.N) != 0;
+}
+
 // ---- configuration choice -------------------------------------------------------------
 struct GemmCfg { int id, BM, BN; };
 const GemmCfg kGemmCfgs[] = {{0, 128, 128}, {1, 256, 64}, {2, 256, 32}, {3, 128, 160}, {4, 128, 96},
@@ -1397,6 +1597,20 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   // (a per-image addend stays on the forward instantiation when its straight-line epilogue can take it: 32-row blocks
   // inside one image)
   const bool fwd = !two && !A.ep_x && A.stat_mode != 2 && !(A.ep_add && A.add_div > 1 && A.add_div % 32 != 0);
+  if (ws_wanted(A, fwd, vec) && !split_math()) {
+    const dim3 grid(ws_grid(A.M)), blk(256);
+#define DL3_WS(KQ_, TN_, OC_) hipLaunchKernelGGL((pw_fwd_ws_kernel<KQ_, TN_, OC_>), grid, blk, 0, st, A)
+    const int tn = ws_tn(A.K, A.N);
+    if (A.K == 16) DL3_WS(2, 3, 4);
+    else if (A.K == 24) DL3_WS(3, 5, 3);
+    else if (A.K == 32 && tn == 1) DL3_WS(4, 1, 4);
+    else if (A.K == 32) DL3_WS(4, 6, 2);  // (96 accumulators: three workgroups per CU spill)
+    else if (A.K == 96) DL3_WS(12, 1, 4);
+    else if (A.K == 144) DL3_WS(18, 1, 3);
+    else DL3_WS(24, 1, 3);
+#undef DL3_WS
+    return (int)grid.x;
+  }
   GemmCfg c = pick_gemm(A.M, A.K, A.N, two, stream, fwd);
   if (stream && pre_ok(A) && pre_wanted(A)) c = kGemmCfgs[4];
   A.mtiles = dl3_cdiv(A.M, c.BM);
@@ -1573,11 +1787,22 @@ extern "C" int dl3_pwconv_partials(int M, int K, int N) {
         const int q = gemm_grid_y(M, N, pick_gemm(M, K, N, two != 0, small != 0, fwd != 0));
         p = q > p ? q : p;
       }
+  if (ws_tn(K, N)) {  // the weight-stationary forward kernel writes one row per workgroup
+    const int q = ws_grid(M);
+    p = q > p ? q : p;
+  }
   if (N % 96 == 0) {  // the prefetching bwd-data variant overrides the choice with the 128x96 tile (run_gemm)
     const int q = gemm_grid_y(M, N, kGemmCfgs[4]);
     p = q > p ? q : p;
   }
   return p;
+}
+
+extern "C" int dl3_pwconv_fwd_impl(int M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0) return 0;
+  GemmArgs A{};
+  A.M = M; A.K = K; A.N = N; A.ldc = N;
+  return (ws_wanted(A, true, true) && !split_math()) ? 1 : 0;
 }
 
 static int gemm_common_check(const char *name, int M, int K, int N) {

@@ -6,7 +6,7 @@ import torch
 
 from oracle import dl3_oracle as O
 from tests.gpu_util import (call, dev, dropout_keep_mask, empty, fold_partials, host, np_act, np_mask, ptr, relerr,
-                            stream)
+                            release, stream)
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-4
@@ -567,10 +567,161 @@ def test_pwconv_bwd_fused(L, case):
     dw2 = empty(K, N)
     call("dl3_reduce_partials", ptr(ws2), S, K * N, ptr(dw2))
     assert np.array_equal(host(dw2), host(dw)) and np.array_equal(host(dx2), host(dx))
-    assert L.dl3_pwconv_bwd_fused_supported(M, 192, 32) == 0 and L.dl3_pwconv_bwd_fused_supported(M, 30, 32) == 0
+    assert L.dl3_pwconv_bwd_fused_supported(M, 192, 64) == 0 and L.dl3_pwconv_bwd_fused_supported(M, 30, 32) == 0
     if K > 64:   # a residual addend next to a wide input is refused, not mishandled
         assert L.dl3_pwconv_bwd_fused(*args(ptr(dw), ptr(dx), None, ptr(ws))[:16], ptr(dx2), K,
                                       *args(ptr(dw), ptr(dx), None, ptr(ws))[18:], stream()) == -4
+
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 5: the weight-stationary streaming forward kernel of the HBM-bound layers (csrc/pwgemm.hip pw_fwd_ws_kernel)
+WS_CASES = [
+    # M, K, N, ldx_extra, ldy_extra, bias, act, stats — every (K, N) the kernel is instantiated for, ragged last tiles
+    (32768 + 77, 16, 96, 0, 0, False, 2, True),
+    (40000, 32, 16, 0, 0, False, 2, True),
+    (32768 + 5, 96, 24, 0, 0, False, 2, True),
+    (33000, 24, 144, 0, 0, False, None, True),
+    (32800, 144, 24, 8, 0, False, 2, True),      # reads a channel slice
+    (36000, 144, 32, 0, 8, True, 2, True),       # writes a channel slice, bias (the centred frozen BatchNorm's -mean)
+    (32768 + 31, 32, 192, 0, 0, False, None, False),
+    (50000, 192, 32, 0, 0, False, 2, True),
+    (32768, 24, 144, 0, 0, False, 2, False),     # whole tiles only, no statistics
+]
+
+
+def _pw_fwd_chunked(L, M, K, N, lxe, lye, bias, act, stats, seed=21, chunk=1 << 16):
+    """dl3_pwconv_fwd against float64, the reference evaluated chunk by chunk (M up to millions of rows)"""
+    rng = np.random.default_rng(seed)
+    ldx, ldy = K + lxe, N + lye
+    xfull = rng.normal(0, 1, (M, ldx)).astype(np.float32)
+    w = rng.normal(0, 0.2, (K, N)).astype(np.float32)
+    b = rng.normal(0, 1, N).astype(np.float32) if bias else None
+    s, t, a = _xform(rng, K, act)
+    P = L.dl3_pwconv_partials(M, K, N)
+    yfull = torch.zeros(M, ldy, dtype=torch.float32, device="cuda")
+    part = empty(P, N, 2) if stats else None
+    xd = dev(xfull)
+    call("dl3_pwconv_fwd", ptr(xd, lxe), ldx, ptr(dev(s)) if s is not None else None,
+         ptr(dev(t)) if t is not None else None, a, ptr(dev(w)), ptr(dev(b)) if bias else None, ptr(yfull, lye), ldy,
+         M, K, N, ptr(part) if stats else None)
+    y = host(yfull)
+    w64 = w.astype(np.float64)
+    s1r, s2r, worst, scale = np.zeros(N), np.zeros(N), 0.0, 0.0
+    for m0 in range(0, M, chunk):
+        x = xfull[m0:m0 + chunk, lxe:lxe + K].astype(np.float64)
+        xin = x if s is None else np_act(s * x + t, a)
+        ref = xin @ w64 + (b if bias else 0)
+        worst = max(worst, float(np.abs(y[m0:m0 + chunk, lye:] - ref).max()))
+        scale = max(scale, float(np.abs(ref).max()))
+        s1r += ref.sum(0)
+        s2r += (ref ** 2).sum(0)
+    assert worst / scale < TOL
+    if lye:
+        assert np.all(y[:, :lye] == 0)
+    if stats:
+        s1, s2 = fold_partials(part, P, N)
+        assert relerr(s1, s1r) < 1e-3 and relerr(s2, s2r) < 1e-3
+    return yfull, part
+
+
+@pytest.mark.parametrize("case", WS_CASES)
+def test_pwconv_fwd_weight_stationary(L, case):
+    M, K, N = case[:3]
+    assert L.dl3_pwconv_fwd_impl(M, K, N) == 1 and L.dl3_pwconv_fwd_impl(M // 4, K, N) == 0
+    assert L.dl3_pwconv_fwd_impl(M, K + 8, N) == 0   # only the instantiated layer shapes
+    _pw_fwd_chunked(L, *case)
+    release()
+
+
+@pytest.mark.parametrize("M,K,N", [(2097152 + 40, 24, 144), (8388608 + 9, 16, 96)])
+def test_pwconv_fwd_weight_stationary_full_size(L, M, K, N):
+    """the layer sizes of the benchmarked plan (B = 128: 128x128 and 256x256 maps): every row of millions, the statistic
+    partial rows bit-identical from launch to launch (static tile -> wave assignment)"""
+    assert L.dl3_pwconv_fwd_impl(M, K, N) == 1
+    y0, p0 = _pw_fwd_chunked(L, M, K, N, 0, 0, False, 2, True, seed=22)
+    y0, p0 = host(y0).copy(), host(p0).copy()
+    release()
+    y1, p1 = _pw_fwd_chunked(L, M, K, N, 0, 0, False, 2, True, seed=22)
+    assert np.array_equal(host(y1), y0) and np.array_equal(host(p1), p0)
+    release()
+
+
+# six-block shapes (round 5) and a six-block expand convolution with addend + foreign sums
+FUSED6_CASES = [
+    (3000, 32, 192, None, True, True, 2),
+    (2100, 32, 192, 2, True, False, 1),
+    (4000, 192, 32, 2, True, False, 1),
+    (1500, 64, 96, 1, True, True, 2),
+    (1500, 96, 64, 2, True, False, 1),
+    (36000, 24, 144, None, True, True, 2),       # more stages than workgroups
+]
+
+
+@pytest.mark.parametrize("case", FUSED6_CASES)
+def test_pwconv_bwd_fused_six_blocks(L, case):
+    test_pwconv_bwd_fused(L, case)
+
+
+@pytest.mark.parametrize("case", [FUSED_CASES[2], FUSED_CASES[3], FUSED6_CASES[0], FUSED6_CASES[2], FUSED6_CASES[3]])
+def test_pwconv_bwd_fused_three_workgroups_per_cu(L, case, monkeypatch):
+    """the five / six-block instantiations budgeted for three workgroups per CU (DL3_FUSED_OCC=3: small spills) compute the
+    same thing"""
+    monkeypatch.setenv("DL3_FUSED_OCC", "3")
+    test_pwconv_bwd_fused(L, case)
+
+
+@pytest.mark.parametrize("case", FUSED_CASES[:5])
+def test_pwconv_bwd_fused_round4_kernel(L, case, monkeypatch):
+    """DL3_FUSED_V=1: the round-4 kernel, kept for same-call A/B measurements"""
+    monkeypatch.setenv("DL3_FUSED_V", "1")
+    test_pwconv_bwd_fused(L, case)
+
+
+def test_pwconv_bwd_fused_full_size(L):
+    """24 -> 144 at the benchmarked plan's 2 097 152 rows: dX of every row, dW, the BatchNorm-backward sums; twice, bit
+    for bit"""
+    M, K, N = 2097152 + 50, 24, 144
+    rng = np.random.default_rng(23)
+    g = rng.normal(0, 1, (M, N)).astype(np.float32)
+    yraw = rng.normal(0, 1, (M, N)).astype(np.float32)
+    cA, cB, cC = [rng.normal(0, 1, N).astype(np.float32) for _ in range(3)]
+    w = rng.normal(0, 0.2, (K, N)).astype(np.float32)
+    x = rng.normal(0, 1, (M, K)).astype(np.float32)
+    add = rng.normal(0, 1, (M, K)).astype(np.float32)
+    mean = rng.normal(0, 1, K).astype(np.float32)
+    invstd = rng.uniform(0.5, 2, K).astype(np.float32)
+    wT = empty(N, K)
+    call("dl3_transpose", ptr(dev(w)), ptr(wT), K, N)
+    S = L.dl3_pwconv_bwd_fused_splits(M, K, N)
+    nbytes = L.dl3_pwconv_bwd_fused_workspace(M, K, N)
+    xd, gd, yd, ad = dev(x), dev(g), dev(yraw), dev(add)
+    cAd, cBd, cCd, md, isd = dev(cA), dev(cB), dev(cC), dev(mean), dev(invstd)
+    outs = []
+    for rep in range(2):
+        ws, dw, dx, part = empty(S, K, N), empty(K, N), empty(M, K), empty(S, K, 2)
+        call("dl3_pwconv_bwd_fused", ptr(xd), K, None, None, 0, ptr(gd), N, ptr(yd), N, ptr(cAd), ptr(cBd), ptr(cCd), ptr(wT),
+             ptr(dw), ptr(dx), K, ptr(ad), K, ptr(xd), K, ptr(md), ptr(isd), ptr(part), M, K, N, ptr(ws), nbytes)
+        outs.append((host(dx).copy(), host(dw).copy(), host(part).copy()))
+    assert all(np.array_equal(a, b) for a, b in zip(outs[0], outs[1]))
+    dxg, dwg, partg = outs[0]
+    w64 = w.astype(np.float64)
+    dw_ref, s1r, s2r, worst, scale = np.zeros((K, N)), np.zeros(K), np.zeros(K), 0.0, 0.0
+    for m0 in range(0, M, 1 << 16):
+        sl = slice(m0, m0 + (1 << 16))
+        dY = cA * g[sl].astype(np.float64) + cB * yraw[sl] + cC
+        x64 = x[sl].astype(np.float64)
+        dw_ref += x64.T @ dY
+        dxr = dY @ w64.T + add[sl]
+        worst = max(worst, float(np.abs(dxg[sl] - dxr).max()))
+        scale = max(scale, float(np.abs(dxr).max()))
+        s1r += dxr.sum(0)
+        s2r += (dxr * (x64 - mean) * invstd).sum(0)
+    assert worst / scale < TOL
+    assert relerr(dwg, dw_ref) < TOL
+    p = partg.reshape(S, K, 2).astype(np.float64)
+    assert relerr(p[:, :, 0].sum(0), s1r) < 1e-3 and relerr(p[:, :, 1].sum(0), s2r) < 1e-3
+    release()
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 32, 3, 32, 2), (1, 17, 19, 3, 32, 2), (1, 16, 16, 32, 64, 1)])

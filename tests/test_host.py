@@ -48,7 +48,12 @@ def test_sizing_queries_of_the_weight_gradient_folds():
         assert S == want, (M, S)
         assert S * 16 * 96 * 4 <= L.dl3_pwconv_bwd_fused_workspace(M, 16, 96)
     assert L.dl3_pwconv_bwd_fused_supported(1000, 24, 144) == 2 and L.dl3_pwconv_bwd_fused_supported(1000, 144, 24) == 1
-    assert L.dl3_pwconv_bwd_fused_supported(1000, 32, 192) == 0 and L.dl3_pwconv_bwd_fused_splits(1000, 32, 192) == 0
+    # round 5: six 32x32 blocks (32 <-> 192); seven or more stay with the two-launch path
+    assert L.dl3_pwconv_bwd_fused_supported(1000, 32, 192) == 2 and L.dl3_pwconv_bwd_fused_supported(1000, 192, 32) == 1
+    assert L.dl3_pwconv_bwd_fused_supported(1000, 64, 128) == 0 and L.dl3_pwconv_bwd_fused_splits(1000, 64, 128) == 0
+    # the weight-stationary forward kernel writes one statistic partial row per workgroup: the partial-row query covers it
+    assert L.dl3_pwconv_fwd_impl(2097152, 24, 144) == 1 and L.dl3_pwconv_partials(2097152, 24, 144) >= 768
+    assert L.dl3_pwconv_fwd_impl(8192, 24, 144) == 0 and L.dl3_pwconv_fwd_impl(2097152, 64, 384) == 0
     for P, n, cols in [(1, 5, 64), (32, 6400, 64), (33, 100, 32), (256, 9 * 960, 32), (257, 9, 8), (1365, 153600, 8)]:
         assert L.dl3_reduce_partials_blocks(P, n) == -(-n // cols)
     assert L.dl3_reduce_partials_blocks(0, 10) == 0 and L.dl3_reduce_partials_blocks(4, 0) == 0
