@@ -22,6 +22,8 @@
 // order): 40 MFMAs per wave and stage instead of 96 for 24 -> 144.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -343,7 +345,13 @@ __global__ __launch_bounds__(256, OC) void pw_bwd_fused2_kernel(FusedArgs P) {
   }
 
   // ---- this wave's share of dX and its W^T operands (B fragment: lane (k = l & 31, n-pair = l >> 5))
-  int x_kbx[XB], x_lo = 0, x_n = NP / 2, x_part = 0;
+  // Columns beyond K (the last 32-column block of dX may be partial) are not predicated off: their lanes compute, mask and
+  // STORE the value of column (c mod valid columns) a second time — same operands, same address, same bits — so that
+  // every lane issues every store of a whole stage.  With a fixed number of stores behind the next stage's requests the
+  // wait for those is a counted s_waitcnt vmcnt(stores); a branch around a store turns it into vmcnt(0): every wave
+  // drains its own dX stores (microseconds under load) once per stage.
+  const int klast = P.K - 32 * (KB - 1);  // valid columns of the last block (1..32)
+  int x_kbx[XB], x_col[XB], x_lo = 0, x_n = NP / 2, x_part = 0;
   if constexpr (SPLIT > 1) {
     x_kbx[0] = wave % KB;
     x_part = wave / KB;
@@ -354,14 +362,15 @@ __global__ __launch_bounds__(256, OC) void pw_bwd_fused2_kernel(FusedArgs P) {
 #pragma unroll
     for (int kx = 0; kx < XB; kx++) x_kbx[kx] = 4 * kx + (3 - wave);
   }
+#pragma unroll
+  for (int kx = 0; kx < XB; kx++) x_col[kx] = x_kbx[kx] * 32 + (x_kbx[kx] == KB - 1 ? l31 % klast : l31);
   float wb[NWB];
   if constexpr (SPLIT > 1) {
-    const int col = x_kbx[0] * 32 + l31;
 #pragma unroll
     for (int s = 0; s < NWB; s++) {
       const int n = 2 * (x_lo + s) + lhi;
-      const bool ok = s < x_n && n < P.N && col < P.K;
-      const float v = P.wT[(size_t)min(n, P.N - 1) * P.K + min(col, P.K - 1)];  // (clamped address: no branch per load)
+      const bool ok = s < x_n && n < P.N;
+      const float v = P.wT[(size_t)min(n, P.N - 1) * P.K + x_col[0]];  // (clamped address: no branch per load)
       wb[s] = ok ? v : 0.f;
     }
   } else {
@@ -428,9 +437,12 @@ __global__ __launch_bounds__(256, OC) void pw_bwd_fused2_kernel(FusedArgs P) {
     }
   };
 
-  // one value of dX: mask, addend, store, BatchNorm-backward sums (rl: row inside the stage, col < KP)
-  auto finish = [&](float v, int m0, int rl, int col, bool cok, float sc, float tc, float mu, float is, float &s1,
-                    float &s2) {
+  // one value of dX: mask, addend, store, BatchNorm-backward sums.  rl: row inside the stage; col: the column the lane
+  // computes (its own, or the valid column it doubles); own: the lane's own column exists (statistics).  FULL: every row
+  // of the stage exists — the store is unconditional.
+  auto finish = [&](auto fullc, float v, int m0, int rl, int col, bool own, float sc, float tc, float mu, float is,
+                    float &s1, float &s2) {
+    constexpr bool FULL = decltype(fullc)::value;
     const int row = m0 + rl;
     const float raw = Xr[rl * LDX + col];
     if (P.x_act != DL3_ACT_NONE) {
@@ -442,20 +454,21 @@ __global__ __launch_bounds__(256, OC) void pw_bwd_fused2_kernel(FusedArgs P) {
       if (P.add) v += Ad[rl * LDX + col];
       if (sep) xh = Sx[rl * LDX + col];
     }
-    if (cok && row < mend) {
+    if constexpr (FULL) {
       __builtin_nontemporal_store(v, &P.dx[(size_t)row * P.lddx + col]);
-      s1 += v;
-      s2 += v * ((xh - mu) * is);
+      s1 += own ? v : 0.f;
+      s2 += own ? v * ((xh - mu) * is) : 0.f;
+    } else {
+      if (own && row < mend) {
+        __builtin_nontemporal_store(v, &P.dx[(size_t)row * P.lddx + col]);
+        s1 += v;
+        s2 += v * ((xh - mu) * is);
+      }
     }
   };
 
-  __syncthreads();  // the coefficient vectors (and W^T) are in LDS
-  if (mbeg < mend) load_regs(mbeg);
-  for (int m0 = mbeg; m0 < mend; m0 += FMS) {
-    store_lds(m0);
-    __syncthreads();
-    if (m0 + FMS < mend) load_regs(m0 + FMS);  // in flight under this stage's MFMAs
-
+  // the MFMAs and the epilogue of the stage in LDS
+  auto stage = [&](auto fullc, int m0) {
     // ---- dW += T(X)^T . dY: block b of the wave = (kb, nb) = ((wave + 4 b) / NB, (wave + 4 b) % NB)
 #pragma unroll
     for (int b = 0; b < WB; b++) {
@@ -486,19 +499,18 @@ __global__ __launch_bounds__(256, OC) void pw_bwd_fused2_kernel(FusedArgs P) {
       for (int r = 0; r < 16; r++) pp[r * 64] = acc[r];
       __syncthreads();
       // the slices of block kbx, summed in slice order; this wave finishes RPW of the block's 16 row registers
-      const int kbx = x_kbx[0];
+      const int kbx = x_kbx[0], col = x_col[0];
       const float *pq = Pp + kbx * 1024 + lane;
-      const int col = kbx * 32 + l31;
-      const bool cok = col < P.K;
+      const bool own = kbx * 32 + l31 < P.K;
       const float sc = cfx[col], tc = cfx[KP + col];
-      const float mu = (P.part && cok) ? P.mean[col] : 0.f, is = (P.part && cok) ? P.invstd[col] : 0.f;
+      const float mu = P.part ? P.mean[col] : 0.f, is = P.part ? P.invstd[col] : 0.f;
 #pragma unroll
       for (int rr = 0; rr < C::RPW; rr++) {
         const int r = x_part * C::RPW + rr;
         float v = pq[r * 64];
 #pragma unroll
         for (int p = 1; p < SPLIT; p++) v += pq[p * KB * 1024 + r * 64];
-        finish(v, m0, (r & 3) + 8 * (r >> 2) + 4 * lhi, col, cok, sc, tc, mu, is, st1[0], st2[0]);
+        finish(fullc, v, m0, (r & 3) + 8 * (r >> 2) + 4 * lhi, col, own, sc, tc, mu, is, st1[0], st2[0]);
       }
     } else {
 #pragma unroll
@@ -508,23 +520,39 @@ __global__ __launch_bounds__(256, OC) void pw_bwd_fused2_kernel(FusedArgs P) {
           f32x16 acc;
 #pragma unroll
           for (int r = 0; r < 16; r++) acc[r] = 0.f;
+          const int col = x_col[kx];
 #pragma unroll 8
           for (int s = 0; s < NP / 2; s++) {
             const float a = Ds[l31 * LDD + 2 * s + lhi];
-            const float bb = Wl[(2 * s + lhi) * LDW + kbx * 32 + l31];
+            const float bb = Wl[(2 * s + lhi) * LDW + col];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc, 0, 0, 0);
           }
-          const int col = kbx * 32 + l31;
-          const bool cok = col < P.K;
+          const bool own = kbx * 32 + l31 < P.K;
           const float sc = cfx[col], tc = cfx[KP + col];
-          const float mu = (P.part && cok) ? P.mean[col] : 0.f, is = (P.part && cok) ? P.invstd[col] : 0.f;
+          const float mu = P.part ? P.mean[col] : 0.f, is = P.part ? P.invstd[col] : 0.f;
 #pragma unroll
           for (int r = 0; r < 16; r++)
-            finish(acc[r], m0, (r & 3) + 8 * (r >> 2) + 4 * lhi, col, cok, sc, tc, mu, is, st1[kx], st2[kx]);
+            finish(fullc, acc[r], m0, (r & 3) + 8 * (r >> 2) + 4 * lhi, col, own, sc, tc, mu, is, st1[kx], st2[kx]);
         }
       }
     }
+  };
+
+  __syncthreads();  // the coefficient vectors (and W^T) are in LDS
+  const int mfull = mbeg + ((mend > mbeg ? mend - mbeg : 0) / FMS) * FMS;  // end of the whole stages
+  if (mbeg < mend) load_regs(mbeg);
+  for (int m0 = mbeg; m0 < mfull; m0 += FMS) {
+    store_lds(m0);
+    __syncthreads();
+    if (m0 + FMS < mend) load_regs(m0 + FMS);  // in flight under this stage's MFMAs
+    stage(std::true_type{}, m0);
     __syncthreads();  // every wave is done with the stage before it is overwritten
+  }
+  if (mfull < mend) {  // the ragged last stage of the launch's last workgroup: every element predicated
+    store_lds(mfull);
+    __syncthreads();
+    stage(std::false_type{}, mfull);
+    __syncthreads();
   }
 
   // ---- weight-gradient slab of this workgroup (all of it: zeros where it saw no rows)
@@ -686,8 +714,8 @@ extern "C" int dl3_pwconv_bwd_fused(const float *x, int ldx, const float *in_sca
   }
   DL3_FUSED(1, 1, false, 4); DL3_FUSED(1, 2, false, 4); DL3_FUSED(1, 3, false, 3); DL3_FUSED(1, 4, false, 3);
   DL3_FUSED23(1, 5, false, 2); DL3_FUSED23(1, 6, false, 2);
-  DL3_FUSED(2, 1, false, 4); DL3_FUSED(3, 1, false, 4); DL3_FUSED(4, 1, false, 4); DL3_FUSED23(5, 1, false, 3);
-  DL3_FUSED23(6, 1, false, 3); DL3_FUSED(2, 2, false, 3); DL3_FUSED23(2, 3, false, 2); DL3_FUSED(3, 2, false, 3);
+  DL3_FUSED(2, 1, false, 4); DL3_FUSED(3, 1, false, 4); DL3_FUSED(4, 1, false, 4); DL3_FUSED23(5, 1, false, 2);
+  DL3_FUSED23(6, 1, false, 2); DL3_FUSED(2, 2, false, 3); DL3_FUSED23(2, 3, false, 2); DL3_FUSED(3, 2, false, 3);
   DL3_FUSED(1, 1, true, 3); DL3_FUSED(1, 2, true, 3); DL3_FUSED(1, 3, true, 3); DL3_FUSED(1, 4, true, 3);
   DL3_FUSED23(1, 5, true, 2); DL3_FUSED23(1, 6, true, 2); DL3_FUSED(2, 1, true, 3); DL3_FUSED(2, 2, true, 3);
   DL3_FUSED23(2, 3, true, 2);

@@ -1285,12 +1285,11 @@ int env_int(const char *name);
 //     block, 128 contiguous bytes per row and instruction (the epilogue of an HBM-bound kernel is store-ISSUE-bound).
 // Tile -> wave assignment is static (tile t belongs to wave t mod 4G): the statistic partial rows are deterministic.
 // KQ = K / 8 (16-byte loads per lane and tile), TN = ceil(N / 32).
-template <int KQ, int TN, int OC>
+// PRE: the next tile's rows are requested BEFORE this tile's MFMAs (a second register set: short reductions); otherwise
+// right behind them, into the registers they just freed — in front of this tile's stores either way.
+template <int KQ, int TN, int OC, bool PRE>
 __global__ __launch_bounds__(256, OC) void pw_fwd_ws_kernel(GemmArgs P) {
   constexpr int KH = 4 * KQ, K = 8 * KQ, NP = 32 * TN;
-  // short reductions: the next tile's rows are requested one tile ahead (two register sets); long ones (>= 48 floats
-  // per lane) rely on the 12-16 waves of a CU being in different phases instead
-  constexpr bool PRE = KQ <= 4;
   __shared__ float Ws[K * NP];        // W[k][n], zero beyond N
   __shared__ float cf[2 * K];         // scale | shift of the input transform
   __shared__ float bs[NP];            // bias
@@ -1314,12 +1313,18 @@ __global__ __launch_bounds__(256, OC) void pw_fwd_ws_kernel(GemmArgs P) {
   for (int j = 0; j < TN; j++) st1[j] = st2[j] = 0.f;
   __syncthreads();
 
-  const int ntiles = (P.M + 31) >> 5;
+  const int nfull = P.M >> 5;  // whole 32-row tiles: the loop below; a ragged last tile is handled behind it
   const int gw = blockIdx.x * 4 + wave, GW = gridDim.x * 4;
   float *const cw = Cs + wave * 1024;
   const float *const wfrag = Ws + KH * lhi * NP + l31;
   const float *const cfs = cf + KH * lhi, *const cft = cf + K + KH * lhi;
+  // 16-byte stores: lane -> (row r0 + 8 p, columns c4 .. c4 + 3) of a 32x32 block.  In the last block only N - 32 (TN - 1)
+  // columns exist: the lanes beyond them repeat a valid column group (same address, same data) instead of being
+  // predicated off, so that EVERY lane issues every store: with a fixed number of stores per tile the wait for the next
+  // tile's rows is a counted s_waitcnt vmcnt(stores) — a branch around a store makes it vmcnt(0), i.e. every wave
+  // drains its own stores (microseconds under load) once per tile.
   const int c4 = (lane & 7) * 4, r0 = lane >> 3;
+  const int c4l = c4 % (P.N - 32 * (TN - 1));
 
   f32x4 nx[KQ];
   auto load_tile = [&](int t) {
@@ -1328,22 +1333,17 @@ __global__ __launch_bounds__(256, OC) void pw_fwd_ws_kernel(GemmArgs P) {
 #pragma unroll
     for (int j = 0; j < KQ; j++) nx[j] = ld4(p + 4 * j);
   };
-  if (PRE && gw < ntiles) load_tile(gw);
-  for (int t = gw; t < ntiles; t += GW) {
-    f32x16 acc[TN];
-#pragma unroll
-    for (int j = 0; j < TN; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+  // MFMAs of the tile whose rows are in nx; `next` >= 0: that tile's rows are requested as early as the registers allow
+  auto mfma_tile = [&](f32x16 (&acc)[TN], int next) {
     if constexpr (PRE) {
-      // operand of this tile: transform in registers, then request the next tile into the same registers
+      // transform in registers, then request the next tile into the same registers
       float ac[KH];
 #pragma unroll
       for (int j = 0; j < KQ; j++) {
         const f32x4 v = dl3_act4(ld4(cfs + 4 * j) * nx[j] + ld4(cft + 4 * j), P.a_act);
         ac[4 * j + 0] = v.x; ac[4 * j + 1] = v.y; ac[4 * j + 2] = v.z; ac[4 * j + 3] = v.w;
       }
-      if (t + GW < ntiles) load_tile(t + GW);
+      if (next >= 0) load_tile(next);
       __builtin_amdgcn_sched_barrier(0);  // (the requests stay in front of the MFMAs: the scheduler would sink them)
 #pragma unroll
       for (int s = 0; s < KH; s++)
@@ -1351,10 +1351,6 @@ __global__ __launch_bounds__(256, OC) void pw_fwd_ws_kernel(GemmArgs P) {
         for (int j = 0; j < TN; j++)
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[s], wfrag[s * NP + j * 32], acc[j], 0, 0, 0);
     } else {
-      // all K/8 requests of the tile first (left alone the scheduler interleaves them with the MFMAs one by one to save
-      // registers — twelve exposed round trips per tile)
-      load_tile(t);
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < KQ; q++) {
         const f32x4 v = dl3_act4(ld4(cfs + 4 * q) * nx[q] + ld4(cft + 4 * q), P.a_act);
@@ -1364,10 +1360,26 @@ __global__ __launch_bounds__(256, OC) void pw_fwd_ws_kernel(GemmArgs P) {
           for (int j = 0; j < TN; j++)
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[e], wfrag[(4 * q + e) * NP + j * 32], acc[j], 0, 0, 0);
       }
+      // the registers are free again: all K/8 requests of the next tile, in front of this tile's stores (left alone the
+      // scheduler interleaves them with the MFMAs one by one to save registers — twelve exposed round trips per tile)
+      __builtin_amdgcn_sched_barrier(0);
+      if (next >= 0) load_tile(next);
+      __builtin_amdgcn_sched_barrier(0);
     }
+  };
 
-    const int m0 = t * 32;
-    const bool full = m0 + 32 <= P.M;
+  if (gw < nfull) load_tile(gw);
+  // (the first tile's rows are waited for HERE: entering the loop with requests in flight and no stores behind them, the
+  // compiler has to merge that state with the back edge's — requests followed by 4 TN stores — and settles for vmcnt(0))
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  for (int t = gw; t < nfull; t += GW) {
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+    mfma_tile(acc, t + GW < nfull ? t + GW : -1);
+    float *const cp = P.c + (size_t)(t * 32 + r0) * P.ldc;
 #pragma unroll
     for (int j = 0; j < TN; j++) {
       const float bj = bs[j * 32 + l31];
@@ -1376,26 +1388,44 @@ __global__ __launch_bounds__(256, OC) void pw_fwd_ws_kernel(GemmArgs P) {
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const float v = acc[j][r] + bj;
-        const bool ok = full || (m0 + (r & 3) + 8 * (r >> 2) + 4 * lhi < P.M);
-        st1[j] += ok ? v : 0.f;
-        st2[j] += ok ? v * v : 0.f;
+        st1[j] += v;
+        st2[j] += v * v;
         cw[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 32 + l31] = v;
       }
       __builtin_amdgcn_wave_barrier();
-      float *const cp = P.c + (size_t)(m0 + r0) * P.ldc + j * 32 + c4;
+      const int cc = (j == TN - 1) ? c4l : c4;
       f32x4 o[4];
 #pragma unroll
-      for (int p = 0; p < 4; p++) o[p] = ld4(cw + (r0 + 8 * p) * 32 + c4);
-      if (full && j * 32 + 32 <= P.N) {  // (wave-uniform: the interior blocks store without a branch per instruction)
+      for (int p = 0; p < 4; p++) o[p] = ld4(cw + (r0 + 8 * p) * 32 + cc);
 #pragma unroll
-        for (int p = 0; p < 4; p++) st4_nt(cp + (size_t)(8 * p) * P.ldc, o[p]);
-      } else {
-        const bool c4ok = j * 32 + c4 < P.N;
-#pragma unroll
-        for (int p = 0; p < 4; p++)
-          if (c4ok && m0 + r0 + 8 * p < P.M) st4_nt(cp + (size_t)(8 * p) * P.ldc, o[p]);
-      }
+      for (int p = 0; p < 4; p++) st4_nt(cp + (size_t)(8 * p) * P.ldc + j * 32 + cc, o[p]);
       __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if ((P.M & 31) != 0 && gw == nfull % GW) {
+    // the one ragged tile of the launch: every element predicated
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+    load_tile(nfull);
+    mfma_tile(acc, -1);
+    const int m0 = nfull * 32;
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const int col = j * 32 + l31;
+      const float bj = bs[col];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const float v = acc[j][r] + bj;
+        if (row < P.M && col < P.N) {
+          st1[j] += v;
+          st2[j] += v * v;
+          P.c[(size_t)row * P.ldc + col] = v;
+        }
+      }
     }
   }
 
@@ -1599,15 +1629,18 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   const bool fwd = !two && !A.ep_x && A.stat_mode != 2 && !(A.ep_add && A.add_div > 1 && A.add_div % 32 != 0);
   if (ws_wanted(A, fwd, vec) && !split_math()) {
     const dim3 grid(ws_grid(A.M)), blk(256);
-#define DL3_WS(KQ_, TN_, OC_) hipLaunchKernelGGL((pw_fwd_ws_kernel<KQ_, TN_, OC_>), grid, blk, 0, st, A)
+#define DL3_WS(KQ_, TN_, OC_, PRE_) hipLaunchKernelGGL((pw_fwd_ws_kernel<KQ_, TN_, OC_, PRE_>), grid, blk, 0, st, A)
     const int tn = ws_tn(A.K, A.N);
-    if (A.K == 16) DL3_WS(2, 3, 4);
-    else if (A.K == 24) DL3_WS(3, 5, 3);
-    else if (A.K == 32 && tn == 1) DL3_WS(4, 1, 4);
-    else if (A.K == 32) DL3_WS(4, 6, 2);  // (96 accumulators: three workgroups per CU spill)
-    else if (A.K == 96) DL3_WS(12, 1, 4);
-    else if (A.K == 144) DL3_WS(18, 1, 3);
-    else DL3_WS(24, 1, 3);
+    // per shape: the spill-free instantiation with the most workgroups per CU; DL3_WS_VAR=1: the alternative (A/B aid: more
+    // registers, the next tile requested a whole tile ahead)
+    const bool alt = env_int("DL3_WS_VAR") == 1;
+    if (A.K == 16) { if (alt) DL3_WS(2, 3, 3, true); else DL3_WS(2, 3, 4, false); }
+    else if (A.K == 24) { if (alt) DL3_WS(3, 5, 2, true); else DL3_WS(3, 5, 3, false); }
+    else if (A.K == 32 && tn == 1) { if (alt) DL3_WS(4, 1, 4, true); else DL3_WS(4, 1, 4, false); }
+    else if (A.K == 32) { if (alt) DL3_WS(4, 6, 2, true); else DL3_WS(4, 6, 3, false); }
+    else if (A.K == 96) DL3_WS(12, 1, 4, false);
+    else if (A.K == 144) DL3_WS(18, 1, 3, false);
+    else DL3_WS(24, 1, 3, false);
 #undef DL3_WS
     return (int)grid.x;
   }

@@ -171,11 +171,15 @@ class View:
 
 class Engine:
     def __init__(self, model, batch, training, bn_mode="batch", dropout=True, seed=2, device=None, use_graph=True,
-                 dw_impl=IMPL_AUTO, rank=None, bn_variance="keras224", external_nnz=False):
+                 dw_impl=IMPL_AUTO, rank=None, bn_variance="keras224", external_nnz=False, opt_trainable=None, bn_update=None):
         if not torch.cuda.is_available():
             raise capi.DL3Error("the dl3 engine needs a GPU (HIP device); there is no CPU fallback")
         self.lib = capi.lib()
         self.model, self.B, self.training = model, int(batch), bool(training)
+        # {layer name: bool}: whose weights the optimizer updates (Keras: collected at compile()) / whose update ops run
+        # (Keras: collected when the train function is built); None: the live `layer.trainable` (graph.Model._training_flags)
+        self._opt_trainable = opt_trainable or {}
+        self._bn_update = bn_update or {}
         self.bn_batch = self.training and bn_mode == "batch"
         self.dropout = bool(dropout) and self.training
         # Dropout mask = f(seed, step, element): every data-parallel rank draws its own masks, every step a new one
@@ -298,7 +302,7 @@ class Engine:
                 size = int(np.prod(dshape))
                 n = (size + 3) // 4 * 4
                 self.hshape[name] = tuple(w.shape)
-                if l.trainable and "/moving_" not in name:
+                if self._opt_trainable.get(l.name, l.trainable) and "/moving_" not in name:
                     self.slots[name] = ("p", np_, size, dshape, l)
                     np_ += n
                 else:
@@ -600,7 +604,7 @@ class Engine:
         if self.bn_batch:
             # Keras 2.2.x collects no updates from a non-trainable layer: a frozen BatchNormalization still normalises
             # with the batch statistics in the training phase, but its moving statistics stay as loaded
-            upd = l.trainable
+            upd = self._bn_update.get(l.name, l.trainable)
             if v.buf.M <= SMALL_BN_ROWS:
                 # few rows (the image-pooling branch: one row per image): two-pass statistics straight from the tensor
                 self.op(self.ops_fwd, "dl3_bn_finalize_direct", v.p(), v.ld, v.buf.M, C,
@@ -1255,7 +1259,7 @@ class Engine:
         if other is self or not (self.training and other.training):
             return
         if other.adam_m.numel() != self.adam_m.numel() or other.n_param != self.n_param:
-            raise RuntimeError("optimizer state layouts differ (trainable flags changed between engines?)")
+            raise RuntimeError("optimizer state layouts differ (engines of two different compile() calls?)")
         self.adam_m.copy_(other.adam_m)
         self.adam_v.copy_(other.adam_v)
         self.drop_step.copy_(other.drop_step)

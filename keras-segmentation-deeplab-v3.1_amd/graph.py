@@ -465,6 +465,15 @@ class Model:
         # optimizers.Adam / any Keras-style Adam exposing get_config(); anything else raises here, not at the first step
         self._compiled = dict(optimizer=as_adam_dict(optimizer), optimizer_object=optimizer, loss=loss, metrics=metrics,
                               sample_weight_mode=sample_weight_mode)
+        # Keras 2.2.4 collects the weights the optimizer updates HERE (`_collected_trainable_weights`), and the layers'
+        # update ops (BatchNormalization moving statistics) when the train function is first built — the first
+        # train_on_batch / fit after compile().  `layer.trainable` flipped in between (segmentation.ipynb: compile in
+        # cell 2, the fine-tuning loop in cell 5, no recompile) therefore changes which moving statistics move but NOT
+        # which weights train: Keras warns about the discrepancy and trains them all.  Same here.
+        self._compile_gen = getattr(self, "_compile_gen", 0) + 1
+        self._collected_trainable = {l.name: bool(l.trainable) for l in self.layers}
+        self._update_flags = None   # frozen at the first training step after this compile()
+        self._train_eng = None      # a new train function starts from fresh optimizer slots
 
     def distribute(self, dp=None):
         """Per-image data parallelism for train_on_batch / fit: this process is one of WORLD_SIZE (one per GPU, launched
@@ -478,12 +487,34 @@ class Model:
 
     MAX_ENGINES = int(os.environ.get("DL3_MAX_ENGINES", "4"))
 
+    def _training_flags(self):
+        """({layer: does the optimizer update its weights}, {layer: do its update ops run}, cache key) for a training engine.
+        Compiled model: the Keras 2.2.4 rule (see compile()).  Never compiled: the live flags, and the key carries them, so a
+        plan lowered for one set of flags is never replayed for another."""
+        live = {l.name: bool(l.trainable) for l in self.layers}
+        if getattr(self, "_collected_trainable", None) is None:
+            return live, live, ("live", tuple(sorted(n for n, t in live.items() if not t)))
+        if self._update_flags is None:
+            self._update_flags = live
+            if live != self._collected_trainable:
+                import warnings
+                warnings.warn("dl3: discrepancy between trainable weights and collected trainable weights — "
+                              "`layer.trainable` changed after compile(): as in Keras 2.2.4 the optimizer still updates the "
+                              "weights collected at compile(); only the moving statistics of now-frozen BatchNormalization "
+                              "layers stop moving.  Call compile() again after setting `trainable` to train the tail only.",
+                              UserWarning, stacklevel=4)
+        return self._collected_trainable, self._update_flags, ("compiled", self._compile_gen)
+
     def _engine(self, batch, training, **kw):
         """engine for (batch, mode); weights travel through the host master copies when the active engine changes, the
         optimizer state (Adam moments, iteration, dropout step) moves device-to-device between training engines, and
         the least recently used engines beyond MAX_ENGINES are dropped (each one owns a full activation arena)."""
         from .engine import Engine
         key = (int(batch), bool(training), tuple(sorted(kw.items())))
+        if training:
+            flags = self._training_flags()
+            kw = dict(kw, opt_trainable=flags[0], bn_update=flags[1])
+            key = key + (flags[2],)
         eng = self._engines.pop(key, None)
         active = getattr(self, "_active", None)
         if eng is not active and active is not None:

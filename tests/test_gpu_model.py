@@ -1097,3 +1097,59 @@ def test_notebook_fine_tuning_freezes_the_backbone(monkeypatch):
     # the per-image column sums are taken of that rounded tensor — one fp32 rounding apart)
     for n in g_pruned:
         assert _l2(res[1][n], res[0][n]) < 1e-5, (n, _l2(res[1][n], res[0][n]))
+
+
+def test_notebook_order_compile_then_freeze_trains_every_weight():
+    """The notebook's LITERAL order (segmentation.ipynb: `model.compile(...)` in cell 2, `l.trainable = False` up to
+    concat_projection in cell 5, no recompile): Keras 2.2.4 collected the optimizer's weights at compile(), so every
+    weight still trains (it warns about the discrepancy); what the flags do change is the update ops collected when the
+    train function is built — the moving statistics of the frozen BatchNormalization layers stay.  And compiling again
+    afterwards switches to the pruned fine-tuning plan: the engine is not reused across compile() calls."""
+    import warnings
+    from dl3_amd.optimizers import Adam
+    classes, B, shape = 3, 3, (64, 64, 3)
+    model, params = _build("mobilenetv2", shape, classes, "deeplab")
+    rng = np.random.default_rng(43)
+    kw = dict(backbone="mobilenetv2", input_shape=shape, classes=classes, OS=16, head="deeplab")
+    params = O.calibrate_bn(params, rng.integers(0, 256, (B,) + shape).astype(np.float32), **kw)
+    _load(model, params)
+    o = dict(O.ADAM_DEFAULTS, lr=1e-4)
+    model.compile(optimizer=Adam(**o))
+    flag = 0
+    for l in model.layers:
+        l.trainable = False
+        if l.name == "concat_projection":
+            flag = 1
+        if flag:
+            l.trainable = True
+    frozen_layers = {l.name for l in model.layers if not l.trainable}
+    x = rng.integers(0, 256, (B,) + shape).astype(np.float32)
+    y = rng.integers(0, classes + 1, (B, shape[0] * shape[1])).astype(np.float32)
+    sw = ((y < classes) * rng.uniform(0.5, 2.0, y.shape)).astype(np.float32)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        loss = model.train_on_batch(x, y[..., None], sw, dropout=False)
+    assert any("collected trainable weights" in str(w.message) for w in rec)
+    eng = model._active
+    assert len(eng.ops_bwd) > 100                       # the whole backward pass: nothing is pruned
+    eng.sync_all_to_host()
+    got = {}
+    for l in model.layers:
+        got.update(l.weights)
+    moved = [n for n in got if "/moving_" not in n and not np.array_equal(got[n], params[n])]
+    assert "aspp0/kernel:0" in moved and "Conv/kernel:0" in moved and "concat_projection/kernel:0" in moved
+    for l in model.layers:
+        for n in l.weights:
+            if "/moving_" in n:
+                assert np.array_equal(got[n], params[n]) == (l.name in frozen_layers), n
+    # one Adam step of the all-trainable oracle on the same batch (the moving statistics aside): the same weights
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    l64, w64, _ = O.train_steps(p64, [(x.astype(np.float64), y.astype(np.float64), sw.astype(np.float64))], opt=o, **kw)
+    assert abs(loss - l64[0]) < 1e-4 * abs(l64[0])
+    for n in ("aspp0/kernel:0", "concat_projection/kernel:0", "custom_logits_semantic/kernel:0", "expanded_conv_depthwise/depthwise_kernel:0"):
+        assert _l2(np.asarray(got[n], np.float64).reshape(w64[n].shape) - p64[n], w64[n] - p64[n]) < 0.1, n
+    # compile() again with the flags as they are now: the fine-tuning plan, a different engine
+    model.compile(optimizer=Adam(**o))
+    model.train_on_batch(x, y[..., None], sw, dropout=False)
+    lean = model._active
+    assert lean is not eng and len(lean.ops_bwd) < 30

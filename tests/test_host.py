@@ -420,3 +420,52 @@ def test_subpixel_constructor_contract():
             Subpixel(3, 3, 2, **kw)
     with pytest.raises(ValueError):
         Subpixel(3, (3, 1), 2)
+
+
+def test_trainable_flags_follow_keras_224_compile_semantics():
+    """Keras 2.2.4: the optimizer's weight list is collected at compile(), the layers' update ops when the train function
+    is first built; `layer.trainable` flipped after compile() (segmentation.ipynb: compile in cell 2, the fine-tuning loop
+    in cell 5) only stops the moving statistics of the frozen BatchNormalization layers — with a warning —, and a plan
+    lowered for one set of flags is never reused for another.  Host logic only: no engine is built."""
+    import warnings
+    import dl3_amd  # noqa: F401
+    from dl3_amd import graph as G
+    from dl3_amd.deeplabv3p import Deeplabv3
+    G.clear_session()
+    m = Deeplabv3(weights=None, input_shape=(64, 64, 3), classes=3, backbone="mobilenetv2")
+
+    def freeze():
+        flag = 0
+        for l in m.layers:
+            l.trainable = False
+            if l.name == "concat_projection":
+                flag = 1
+            if flag:
+                l.trainable = True
+
+    # never compiled: the live flags, and the key changes with them
+    opt0, upd0, key0 = m._training_flags()
+    assert all(opt0.values()) and opt0 == upd0 and key0[0] == "live"
+    freeze()
+    opt1, upd1, key1 = m._training_flags()
+    assert not opt1["aspp0"] and opt1["concat_projection"] and key1 != key0
+    for l in m.layers:
+        l.trainable = True
+    # compile, THEN freeze (the notebook's order): every weight still trains, frozen layers' updates stop, Keras' warning
+    m.compile(optimizer=None)
+    freeze()
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        opt2, upd2, key2 = m._training_flags()
+    assert any("collected trainable weights" in str(w.message) for w in rec)
+    assert all(opt2.values()) and not upd2["aspp0_BN"] and upd2["concat_projection_BN"] and key2 == ("compiled", 1)
+    for l in m.layers:   # flipping flags again without compile() changes nothing: the train function exists
+        l.trainable = True
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        assert m._training_flags() == (opt2, upd2, key2) and not rec
+    # freeze, then compile: the tail only; a new key, so the old plan is not reused
+    freeze()
+    m.compile(optimizer=None)
+    opt3, upd3, key3 = m._training_flags()
+    assert not opt3["aspp0"] and opt3["concat_projection"] and opt3 == upd3 and key3 == ("compiled", 2)
