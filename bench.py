@@ -99,8 +99,9 @@ def build_engine(args):
         model = SegModel(image_size=shape[:2]).create_seg_model(args.head, n=21, backbone=args.backbone)
     kw = {}
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        # the engine Model.train_on_batch builds under Model.distribute(): the loss is normalised by the GLOBAL
-        # count(w != 0), refreshed before every step (Engine.sync_nnz) — the N>1 number times the product path
+        # the engine Model.train_on_batch builds under Model.distribute(): ONE loss over the global batch — the shard's
+        # count(w != 0) and loss sum ride in the arena all-reduce, Adam finishes the normalisation on the device
+        # (Engine.train_step) — the N>1 number times the product path
         kw["external_nnz"] = True
     eng = model._engine(args.batch, True, bn_mode=args.bn_mode, dropout=True, use_graph=not args.no_graph, **kw)
     rng = np.random.default_rng(1000 + int(os.environ.get("RANK", "0")))
@@ -372,7 +373,7 @@ def split_math_leg(args):
             eng.adam(None, 1.0)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        loss = float(eng.loss[0].item())
+        loss = eng.loss_value()
     finally:
         capi.set_gemm_math(None)
     log("split-math leg: %.1f ms/step" % (1e3 * dt / args.steps))
@@ -383,6 +384,47 @@ def split_math_leg(args):
                         "(tests/test_gpu_ops.py::test_split_math_error); full-size parity in this mode: tests/test_gpu_fullsize.py "
                         "::test_cfg2_mnv2_512_train_step_split_math, ::test_cfg3_subpixel_mnv2_512_train_step_split_math, "
                         "::test_cfg4_xception_os8_256_train_step_split_math (same bars as the f32 tests)"}
+
+
+def fed_run(eng, steps, classes=21):
+    """The same resident step FED from the host (utils.py:360-402 + :231-241 are what it replaces): every
+    step a NEW batch — uint8 images + uint8 label maps, three distinct pinned host batches in rotation — crosses PCIe on a
+    copy stream while the previous step runs (feed.BatchFeeder: two device slots), is widened into the engine's input and
+    turned into (Y, SW) by dl3_prepare_targets on the device.  Timed like the resident loop, on the same engine."""
+    from dl3_amd.feed import BatchFeeder
+    B = eng.B
+    H, W = eng.xbuf.H, eng.xbuf.W
+    rng = np.random.default_rng(77)
+    host = []
+    for _ in range(3):
+        img = torch.from_numpy(rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)).pin_memory()
+        lab = rng.integers(0, classes + 1, (B, H * W), dtype=np.uint8)
+        lab[lab == classes] = 255                     # void as cv2 delivers it
+        host.append((img, torch.from_numpy(lab).pin_memory()))
+    fd = BatchFeeder(eng, classes, np.uint8)
+
+    def step():
+        eng.fwd_bwd()
+        eng.adam(None, 1.0)
+
+    fd.run((host[i % 3] for i in range(3)), step)      # warm-up: pinned registration, copy stream, both slots
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = fd.run((host[i % 3] for i in range(steps)), step)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert n == steps
+    # the link on its own: one image batch, H2D, alone on the copy stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(fd.copy_stream):
+        e0.record(fd.copy_stream)
+        fd.dx[0].copy_(host[0][0].reshape(-1), non_blocking=True)
+        e1.record(fd.copy_stream)
+    torch.cuda.synchronize()
+    raw = fd.nx / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    return {"value": B * steps / dt, "unit": "img/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+            "host_bytes_per_step": fd.bytes_per_batch, "pcie_gb_s_sustained_by_the_loop": fd.bytes_per_batch * steps / dt / 1e9,
+            "pcie_gb_s_one_copy_alone": raw, "final_loss": eng.loss_value()}
 
 
 def _free_engines():
@@ -399,7 +441,8 @@ def compact_leg(args, **over):
     in-situ pass for the family fractions.  The headline engine has been freed before."""
     a = argparse.Namespace(**vars(args))
     for k, v in over.items():
-        setattr(a, k, v)
+        if k != "fed":
+            setattr(a, k, v)
     _free_engines()
     model, eng = build_engine(a)
 
@@ -427,6 +470,10 @@ def compact_leg(args, **over):
     out = {"value": a.batch * steps / dt, "unit": "img/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "batch": a.batch,
            "workload": "%s %dx%d OS=%d head=%s B=%d" % (a.backbone, a.size, a.size, a.os, a.head, a.batch),
            "launches_per_step": len(eng.ops_fwd) + len(eng.ops_bwd) + 1, "device_gb": round(torch.cuda.memory_allocated() / 1e9, 2)}
+    if over.get("fed"):
+        out["fed"] = fed_run(eng, steps)
+        out["fed"]["vs_resident"] = round(out["fed"]["value"] / out["value"], 4)
+        log("   fed from the host: %.1f img/s = %.3f x resident" % (out["fed"]["value"], out["fed"]["vs_resident"]))
     rb = {} if a.no_roofline else roofline_blocks(insitu_profile(eng, passes=1), a)
     if "roofline" in rb:
         out["gemm_frac_of_fp32_mfma_peak"] = round(rb["roofline"]["frac"], 4)
@@ -469,11 +516,11 @@ def main():
     dp.broadcast(eng.state)
 
     def step():
-        if eng.external_nnz:
-            eng.sync_nnz(dp)  # device count + one-float RCCL all-reduce + scale, all on the stream (no host round trip)
+        # (N > 1: nothing in front of the replayed hipGraph, ONE all-reduce behind it — gradients, the shard's
+        # count(w != 0) and loss sum in one arena —, Adam with the normalisation finished on the device; no host sync)
         eng.fwd_bwd()
         scale = dp.allreduce_grads(eng.grads)
-        eng.adam(None, scale)
+        eng.adam(None, scale, norm=eng.external_nnz)
 
     def allreduce_ms(reps=10):
         """the gradient exchange on its own (same arena, same stream, same communicator), HIP events around `reps`
@@ -500,15 +547,33 @@ def main():
         raise SystemExit("bench.py: hipGraph capture failed — refusing to report eager-launch numbers as the headline")
     dp.barrier()
     torch.cuda.synchronize()
+    # no host round trip inside the timed loop: torch raises on any implicit device synchronisation
+    # (.item(), .cpu(), a blocking copy) while the guard is on.  Not on the gloo plane: its exchange is host-staged.
+    guard = None
+    if dp.world == 1 or dp.comm is not None:
+        try:
+            torch.cuda.set_sync_debug_mode("error")
+            guard = 0
+        except Exception:   # pragma: no cover - depends on the runtime
+            guard = None
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    try:
+        for _ in range(args.steps):
+            step()
+    finally:
+        if guard is not None:
+            torch.cuda.set_sync_debug_mode("default")
     torch.cuda.synchronize()
     dp.barrier()
     dt = dp.max_over_ranks(time.perf_counter() - t0)
-    loss = float(eng.loss[0].item())
+    loss = eng.loss_value()
     log("timed %d steps: %.1f ms/step" % (args.steps, 1e3 * dt / args.steps))
     ar_ms = allreduce_ms()
+    fed = None
+    if dp.world == 1 and not args.no_legs and not eng.external_nnz:
+        fed = fed_run(eng, args.steps)
+        fed["vs_resident"] = round(fed["value"] / (args.batch * args.steps / dt), 4)
+        log("fed from the host: %.1f img/s = %.3f x resident" % (fed["value"], fed["vs_resident"]))
 
     if dp.rank == 0:
         imgs = args.batch * dp.world * args.steps
@@ -530,10 +595,14 @@ def main():
                        "gradient_exchange": ("dl3_comm_allreduce_f32 (RCCL), %.2f MB" % (eng.n_param * 4 / 1e6))
                        if dp.comm is not None else ("gloo (host staged)" if dp.world > 1 else None),
                        "rccl_ranks": dp.rccl_ranks(), "dist_strict": os.environ.get("DL3_DIST_STRICT", "0") == "1",
-                       "backward_fork": bool(eng.fork and eng._side)},
+                       "backward_fork": bool(eng.fork and eng._side),
+                       # 0: asserted — the timed loop ran under torch.cuda.set_sync_debug_mode("error"); None: guard unavailable
+                       "host_syncs_in_timed_loop": guard},
         }
         if ar_ms is not None:
             rec["allreduce_ms"] = ar_ms  # one exchange of the %d-float arena on its own, max over ranks (part of ms_per_step)
+        if fed is not None:
+            rec["fed"] = fed   # the same steps fed from pinned host memory (never `value`: that is the resident rate)
         if not args.no_roofline:
             rows = insitu_profile(eng)
             log("in-situ profile done: %.2f ms for %d launches" % (sum(r["ms"] for r in rows), len(rows)))
@@ -557,7 +626,7 @@ def main():
             except NameError:
                 pass
             eng = model = None
-            rec["by_batch"] = {str(b): compact_leg(args, batch=b) for b in (2, 16)}
+            rec["by_batch"] = {str(b): compact_leg(args, batch=b, fed=(b != 32)) for b in (2, 16, 32)}
             rec["configs"] = {
                 "cfg3_subpixel_b128": compact_leg(args, head="subpixel"),
                 "cfg4_xception_os8_b16": compact_leg(args, backbone="xception", os=8, batch=16),

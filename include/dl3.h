@@ -348,6 +348,12 @@ int dl3_scale(float *p, float value, size_t n, void *stream);
  * g is first multiplied by grad_scale (1/world_size after the RCCL sum) */
 int dl3_adam_step(float *p, const float *g, float *m, float *v, size_t n, float lr_t, float beta1, float beta2,
                   float eps, float grad_scale, void *stream);
+/* the same with the scale finished on the device: g is multiplied by grad_scale / max(denom[0], 1e-20).  Data-parallel
+ * step without a host round trip (round 5; utils.py:209-211 merges the towers and evaluates ONE loss over the global
+ * batch): every rank differentiates sum_shard(l*w) / c0 with a FIXED c0, its count(w != 0) and loss sum ride behind the
+ * gradients in the same all-reduce, denom = the summed count, grad_scale = c0. */
+int dl3_adam_step_norm(float *p, const float *g, float *m, float *v, size_t n, float lr_t, float beta1, float beta2,
+                       float eps, float grad_scale, const float *denom, void *stream);
 
 /* ---- either side of the network: targets in, metric counts out -------------------------- */
 #define DL3_LABEL_U8 0  /* cv2.imread(path, 0) label maps (utils.py:314) */

@@ -448,6 +448,24 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
   }
 }
 
+// the same with the gradient scale finished on the device: g * gs / max(denom[0], floor) — data parallel: the arena holds
+// sum over ranks of (sum over the shard of dloss / c0), denom the global count(w != 0) that travelled in the same
+// all-reduce, gs = c0: the optimizer sees the gradient of ONE loss over the global batch with no host round trip
+__global__ __launch_bounds__(256) void adam_norm_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                        float *__restrict__ m, float *__restrict__ v, size_t n,
+                                                        float lr_t, float b1, float b2, float eps, float gs,
+                                                        const float *__restrict__ denom) {
+  const float sc = gs / fmaxf(denom[0], 1e-20f);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float gi = g[i] * sc;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
 // float4 variant: C % 4 == 0, all leading dimensions % 4 == 0, fewer than 2^31 elements
 __global__ __launch_bounds__(256) void affine_add4_kernel(const float *__restrict__ a, int lda,
                                                           const float *__restrict__ sa,
@@ -662,6 +680,15 @@ extern "C" int dl3_adam_step(float *p, const float *g, float *m, float *v, size_
   hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, beta1,
                      beta2, eps, grad_scale);
   DL3_LAUNCH_CHECK("adam_step");
+  return DL3_OK;
+}
+
+extern "C" int dl3_adam_step_norm(float *p, const float *g, float *m, float *v, size_t n, float lr_t, float beta1,
+                                  float beta2, float eps, float grad_scale, const float *denom, void *stream) {
+  DL3_CHECK_ARG(p && g && m && v && denom && n > 0, "adam_step_norm: bad argument");
+  hipLaunchKernelGGL(adam_norm_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, beta1,
+                     beta2, eps, grad_scale, denom);
+  DL3_LAUNCH_CHECK("adam_step_norm");
   return DL3_OK;
 }
 

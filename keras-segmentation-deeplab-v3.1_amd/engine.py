@@ -311,8 +311,11 @@ class Engine:
         self.n_param = np_
         self.params = self.zeros(max(np_, 4))
         self.state = self.zeros(max(ns, 4))
+        # [count(w != 0) of the shard, loss sum of the shard, 0, 0] ride behind the gradients in the arena exchange
+        # (data-parallel engines, Engine.train_step)
+        self.tail = (max(np_, 4) + 3) // 4 * 4
         if self.training:
-            self.grads = self.zeros(max(np_, 4))
+            self.grads = self.zeros(self.tail + 4)
             self.adam_m = self.zeros(max(np_, 4))
             self.adam_v = self.zeros(max(np_, 4))
             self.dummy_grad = self.zeros(4096)
@@ -849,7 +852,16 @@ class Engine:
             self.nnz = self.zeros(4)
             self.lossP = self.lib.dl3_rows_partials(M)
             self.loss_part = self.zeros(self.lossP)
-            self.loss = self.zeros(4)
+            if self.external_nnz:
+                # data parallel: the loss kernel divides by a FIXED normaliser c0 (pixels per image: the same on every
+                # rank, whatever the shard), the shard's count(w != 0) and its loss sum land in the arena's tail, the ONE
+                # all-reduce of the step sums them with the gradients, and Adam finishes the scale c0 / count_all on the
+                # device (dl3_adam_step_norm): no all-reduce in front of the step, no host round trip behind it
+                self.nnz_host = float(M // self.B)
+                self.nnz.fill_(self.nnz_host)
+                self.loss = self.grads[self.tail + 1:self.tail + 2]
+            else:
+                self.loss = self.zeros(4)
             v.buf.expected += 1
         self.views[id(l.output)] = v
 
@@ -883,8 +895,8 @@ class Engine:
         buf = v.buf
         M, C = buf.M, v.C
         # loss + dlogits (first and only contribution to the logits buffer)
-        if not self.external_nnz:
-            self.op(self.ops_fwd, "dl3_count_nonzero", ptr(self.sweights), M, ptr(self.nnz))
+        self.op(self.ops_fwd, "dl3_count_nonzero", ptr(self.sweights), M,
+                (self.grads.data_ptr() + 4 * self.tail) if self.external_nnz else ptr(self.nnz))
         if self.fused_shuffle is not None:
             su = self.fused_shuffle
             ub = su.inv.buf
@@ -1172,26 +1184,28 @@ class Engine:
                   torch.cuda.current_stream().cuda_stream)
         return float(tmp[0].item())
 
-    def sync_nnz(self, comm=None):
-        """external_nnz engines, before each step: the loss normaliser count_all(w != 0) / world of the resident sample
-        weights.  On the RCCL data plane nothing leaves the stream (device count, a one-float all-reduce, a scale — no
-        host round trip); on the gloo plane (functional tests) the count goes through the host."""
-        assert self.external_nnz
-        st = torch.cuda.current_stream().cuda_stream
-        M = self.logits_view.buf.M
-        if comm is not None and comm.comm is not None:
-            capi.call("dl3_count_nonzero", ptr(self.sweights), M, ptr(self.nnz), st)
-            capi.call("dl3_comm_allreduce_f32", comm.comm, ptr(self.nnz), ptr(self.nnz), 1, st)
-            capi.call("dl3_scale", ptr(self.nnz), 1.0 / comm.world, 1, st)
-        elif comm is not None and comm.world > 1:
-            self.set_nnz(comm.sum_over_ranks(self.count_nnz()) / comm.world)
-        else:
-            capi.call("dl3_count_nonzero", ptr(self.sweights), M, ptr(self.nnz), st)
-
     def set_nnz(self, value):
-        """external_nnz engines: the normaliser the loss kernel divides by (global count / world, see train_step)"""
+        """external_nnz engines: the FIXED normaliser the loss kernel divides by (default: pixels per image); the
+        optimizer multiplies it back and divides by the global count (train_step).  Tests use it to give engines of
+        different batch sizes one common normaliser."""
         assert self.external_nnz
+        self.nnz_host = float(value)
         capi.call("dl3_fill", ptr(self.nnz), float(value), 1, torch.cuda.current_stream().cuda_stream)
+
+    def loss_value(self):
+        """the loss of the last step as a float (one device read): sum(l*w) / count(w != 0) — over the GLOBAL batch on a
+        data-parallel engine, from the arena tail the all-reduce summed"""
+        if not self.external_nnz:
+            return float(self.loss[0].item())
+        t = self.grads[self.tail:self.tail + 2].cpu()
+        return float(t[1]) * self.nnz_host / max(float(t[0]), 1e-20)
+
+    def loss_handle(self):
+        """the same without the read: a LazyLoss that fetches when (if) somebody looks at it"""
+        if not self.external_nnz:
+            return LazyLoss(self.loss[0:1].clone(), None, 1.0)
+        t = self.grads[self.tail:self.tail + 2].clone()
+        return LazyLoss(t[1:2], t[0:1], self.nnz_host)
 
     def seg_counts(self, y):
         """after forward(): per-image, per-class pixel counts [B,3,C] of the argmax mask against labels y
@@ -1239,17 +1253,25 @@ class Engine:
         else:
             self.run_ops(self.ops_bwd)
 
-    def adam(self, opt=None, grad_scale=1.0):
-        """Keras Adam with decay (notebook cell 2): lr_t = lr/(1+decay*it) * sqrt(1-b2^t)/(1-b1^t)"""
+    def adam(self, opt=None, grad_scale=1.0, norm=False):
+        """Keras Adam with decay (notebook cell 2): lr_t = lr/(1+decay*it) * sqrt(1-b2^t)/(1-b1^t).
+        norm (data-parallel engines): the gradient scale is finished on the device, normaliser / count_all from the arena
+        tail (dl3_adam_step_norm); grad_scale is ignored."""
         o = dict(lr=7e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-8, decay=1e-6)
         o.update(opt or {})
         it = self.iteration
         t = it + 1
         lr = o["lr"] / (1.0 + o["decay"] * it)
         lr_t = lr * math.sqrt(1.0 - o["beta_2"] ** t) / (1.0 - o["beta_1"] ** t)
-        capi.call("dl3_adam_step", ptr(self.params), ptr(self.grads), ptr(self.adam_m), ptr(self.adam_v),
-                  self.n_param, lr_t, o["beta_1"], o["beta_2"], o["epsilon"], grad_scale,
-                  torch.cuda.current_stream().cuda_stream)
+        if norm:
+            assert self.external_nnz
+            capi.call("dl3_adam_step_norm", ptr(self.params), ptr(self.grads), ptr(self.adam_m), ptr(self.adam_v),
+                      self.n_param, lr_t, o["beta_1"], o["beta_2"], o["epsilon"], self.nnz_host,
+                      self.grads.data_ptr() + 4 * self.tail, torch.cuda.current_stream().cuda_stream)
+        else:
+            capi.call("dl3_adam_step", ptr(self.params), ptr(self.grads), ptr(self.adam_m), ptr(self.adam_v),
+                      self.n_param, lr_t, o["beta_1"], o["beta_2"], o["epsilon"], grad_scale,
+                      torch.cuda.current_stream().cuda_stream)
         self.iteration += 1
         self.dirty = True
 
@@ -1265,24 +1287,53 @@ class Engine:
         self.drop_step.copy_(other.drop_step)
         self.iteration = other.iteration
 
-    def train_step(self, x, y, sw=None, opt=None, comm=None):
+    def train_step(self, x, y, sw=None, opt=None, comm=None, lazy=False):
+        """one step on (x, y, sw).  Data parallel (external_nnz): ONE loss over the global batch,
+        L = sum_all(l*w) / count_all(w != 0) — every rank differentiates sum_shard(l*w) / c0, the all-reduce sums
+        gradients, counts and loss sums, Adam applies c0 / count_all on the device: nothing in front of the captured
+        step, one collective behind it, no host round trip.  lazy: the loss comes back as a LazyLoss (no device read)."""
         self.set_input(x)
         self.set_targets(y, sw)
-        if self.external_nnz:
-            # one loss over the global batch: L = sum_all(l*w) / count_all(w != 0).  Every rank divides by
-            # count_all / world; the all-reduce sums the shard gradients and Adam applies 1/world
-            self.sync_nnz(comm)
         self.fwd_bwd()
-        scale = 1.0
-        if comm is not None:
-            scale = comm.allreduce_grads(self.grads)
-        self.adam(opt, scale)
-        return float(self.loss[0].item())
+        if self.external_nnz:
+            if comm is not None:
+                comm.allreduce_grads(self.grads)
+            self.adam(opt, norm=True)
+        else:
+            scale = 1.0
+            if comm is not None:
+                scale = comm.allreduce_grads(self.grads)
+            self.adam(opt, scale)
+        return self.loss_handle() if lazy else self.loss_value()
 
     def grad_of(self, name):
         kind, off, n, shp, _ = self.slots[name]
         assert kind == "p"
         return self._unpad(name, self.grads[off:off + n].cpu().numpy().reshape(shp))
+
+
+class LazyLoss:
+    """the loss of one step, still on the device: num [* scale / den], read (one synchronising copy) only when somebody
+    converts it — Model.fit / fit_generator collect these and read them once per epoch instead of stalling every step"""
+
+    def __init__(self, num, den, scale):
+        self._num, self._den, self._scale, self._value = num, den, scale, None
+
+    def __float__(self):
+        if self._value is None:
+            n = float(self._num.cpu()[0])
+            self._value = n if self._den is None else n * self._scale / max(float(self._den.cpu()[0]), 1e-20)
+            self._num = self._den = None
+        return self._value
+
+    def __repr__(self):
+        return repr(float(self))
+
+    def __format__(self, spec):
+        return format(float(self), spec)
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(float(self), dtype=dtype)
 
 
 # ======================================================================================

@@ -601,7 +601,9 @@ class Model:
         counts = np.concatenate(counts, 0)
         return [num / den, U.Jaccard_from_counts(counts), U.accuracy_from_counts(counts)]
 
-    def train_on_batch(self, x, y, sample_weight=None, **engine_kw):
+    def train_on_batch(self, x, y, sample_weight=None, lazy_loss=False, **engine_kw):
+        """keras Model.train_on_batch; lazy_loss=True returns an engine.LazyLoss (float() reads it) instead of stalling
+        the stream for one scalar every step — fit / fit_generator use it and read once per epoch"""
         dp = self._dp
         # the data-parallel step also runs for a communicator of ONE rank (dp.comm set): every launch of the N-rank step —
         # the one-float count all-reduce in front of the hipGraph replay, the arena all-reduce behind it — on one GPU
@@ -620,14 +622,14 @@ class Model:
         eng = self._engine(x.shape[0], True, **engine_kw)
         opt = (self._compiled or {}).get("optimizer") or {}
         if not multi:
-            return eng.train_step(x, y, sample_weight, opt)
+            return eng.train_step(x, y, sample_weight, opt, lazy=lazy_loss)
         if not self._dp_synced:  # identical weights and moving statistics on every rank before the first step
             dp.broadcast(eng.params)
             dp.broadcast(eng.state)
             eng.dirty = True
             self._dp_synced = True
-        loss = eng.train_step(x, y, sample_weight, opt, comm=dp)
-        return dp.mean_over_ranks(loss)  # = sum_all(l*w) / count_all(w != 0): every rank divided by count_all / world
+        # sum_all(l*w) / count_all(w != 0), from the arena tail the one all-reduce summed: the same number on every rank
+        return eng.train_step(x, y, sample_weight, opt, comm=dp, lazy=lazy_loss)
 
     _IGNORED_FIT_KW = ("workers", "use_multiprocessing", "max_queue_size", "shuffle", "initial_epoch")
 
@@ -649,14 +651,20 @@ class Model:
         for _ in range(epochs):
             for i in range(0, n - batch_size + 1, batch_size):
                 sw = None if sample_weight is None else sample_weight[i:i + batch_size]
-                hist.append(self.train_on_batch(x[i:i + batch_size], y[i:i + batch_size], sw))
-        return hist
+                hist.append(self.train_on_batch(x[i:i + batch_size], y[i:i + batch_size], sw, lazy_loss=True))
+        return [float(l) for l in hist]
 
-    def fit_generator(self, generator, steps_per_epoch=None, epochs=1, verbose=0, **kw):
-        """Minimal Model.fit_generator (utils.py:233): generator yields (X, Y, {'pred_mask': SW}) or (X, Y, SW)."""
+    def fit_generator(self, generator, steps_per_epoch=None, epochs=1, verbose=0, device_feed=False, n_classes=None, **kw):
+        """Minimal Model.fit_generator (utils.py:233): generator yields (X, Y, {'pred_mask': SW}) or (X, Y, SW).
+        device_feed=True (not in Keras): the generator yields (uint8 images [B,H,W,3], raw label maps [B,H,W] uint8 / int32)
+        — what cv2 decodes, before SegmentationGenerator.__getitem__ turns it into float tensors (utils.py:375-402): the
+        batch crosses PCIe as bytes on a copy stream while the previous step runs, and X / Y / SW are produced on the device
+        (feed.BatchFeeder: widening copy + dl3_prepare_targets)."""
         self._check_fit_kw(kw)
         hist = []
         steps = steps_per_epoch or len(generator)
+        if device_feed:
+            return self._fit_device_feed(generator, steps, epochs, n_classes)
         for _ in range(epochs):
             for i in range(steps):
                 item = generator[i] if hasattr(generator, "__getitem__") else next(generator)
@@ -664,7 +672,48 @@ class Model:
                 SW = item[2] if len(item) > 2 else None
                 if isinstance(SW, dict):
                     SW = list(SW.values())[0]
-                hist.append(self.train_on_batch(X, Y, SW))
+                hist.append(self.train_on_batch(X, Y, SW, lazy_loss=True))
+            hist = [float(l) for l in hist]   # one read per epoch
+            if hasattr(generator, "on_epoch_end"):
+                generator.on_epoch_end()
+        return hist
+
+    def _fit_device_feed(self, generator, steps, epochs, n_classes):
+        from .feed import BatchFeeder
+        if self._dp is not None and (self._dp.world > 1 or self._dp.comm is not None):
+            raise NotImplementedError("device_feed under Model.distribute(): shard the generator per rank instead")
+        opt = (self._compiled or {}).get("optimizer") or {}
+        C = int(n_classes if n_classes is not None else self.output.shape[-1])
+        hist, feeders = [], {}
+        for _ in range(epochs):
+            def batches():
+                for i in range(steps):
+                    item = generator[i] if hasattr(generator, "__getitem__") else next(generator)
+                    yield np.asarray(item[0]), np.asarray(item[1])
+            losses = []
+            it = iter(batches())
+            first = next(it, None)
+            if first is None:
+                break
+            eng = self._engine(first[0].shape[0], True)
+            key = (id(eng), first[1].dtype.str)
+            if key not in feeders:
+                feeders[key] = BatchFeeder(eng, C, np.uint8 if first[1].dtype == np.uint8 else np.int32)
+
+            def chain():
+                yield first
+                for b in it:
+                    if b[0].shape[0] != eng.B:
+                        raise ValueError("device_feed needs batches of one size (got %d after %d)" % (b[0].shape[0], eng.B))
+                    yield b
+
+            def step():
+                eng.fwd_bwd()
+                eng.adam(opt)
+                losses.append(eng.loss_handle())
+
+            feeders[key].run(chain(), step)
+            hist += [float(l) for l in losses]   # one read per epoch
             if hasattr(generator, "on_epoch_end"):
                 generator.on_epoch_end()
         return hist

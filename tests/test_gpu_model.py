@@ -1153,3 +1153,64 @@ def test_notebook_order_compile_then_freeze_trains_every_weight():
     model.train_on_batch(x, y[..., None], sw, dropout=False)
     lean = model._active
     assert lean is not eng and len(lean.ops_bwd) < 30
+
+
+def test_batch_feeder_equals_the_host_array_path():
+    """feed.BatchFeeder (uint8 images + uint8 label maps from pinned / pageable host memory, H2D on a copy stream, widening
+    copy + dl3_prepare_targets on the device, two slots) trains exactly like train_on_batch on the float arrays the
+    reference's generator would have built on the host (utils.py:375-402): same losses, same weights, bit for bit —
+    through Model.fit_generator(device_feed=True) and through the feeder's own loop."""
+    from dl3_amd import utils as U
+    classes, B, shape, steps = 5, 2, (64, 64, 3), 5
+    rng = np.random.default_rng(51)
+    imgs = [rng.integers(0, 256, (B,) + shape, dtype=np.uint8) for _ in range(steps)]
+    labs = []
+    for _ in range(steps):
+        l = rng.integers(0, classes + 1, (B, shape[0], shape[1]), dtype=np.uint8)
+        l[l == classes] = 255
+        labs.append(l)
+
+    def fresh():
+        model, params = _build("mobilenetv2", shape, classes, "deeplab")
+        _load(model, params)
+        model.compile(optimizer=dict(lr=1e-3))
+        return model
+
+    # (a) the host-array path: float32 X, Y / SW as utils.prepare_targets' host twin builds them
+    ref = fresh()
+    want = []
+    for x8, l8 in zip(imgs, labs):
+        Y, SW = U.prepare_targets(l8, classes)
+        want.append(ref.train_on_batch(x8.astype(np.float32), Y, SW, dropout=False))
+    w_ref = ref._active.params.cpu().numpy().copy()
+
+    class Seq:
+        def __len__(self):
+            return steps
+
+        def __getitem__(self, i):
+            return imgs[i], labs[i]
+
+    # (b) the feeder's own loop on an engine with the same settings as (a) (fit_generator's engine has dropout on)
+    m2 = fresh()
+    from dl3_amd.feed import BatchFeeder
+    eng = m2._engine(B, True, dropout=False)
+    fd = BatchFeeder(eng, classes, np.uint8)
+    losses = []
+
+    def step():
+        eng.fwd_bwd()
+        eng.adam(dict(lr=1e-3))
+        losses.append(eng.loss_handle())
+
+    pinned = [(torch.from_numpy(x).pin_memory(), torch.from_numpy(l).pin_memory()) for x, l in zip(imgs[:3], labs[:3])]
+    batches = pinned + list(zip(imgs[3:], labs[3:]))    # pinned tensors (zero copy) and plain numpy arrays (slot buffers)
+    assert fd.run(iter(batches), step) == steps
+    got = [float(l) for l in losses]
+    assert got == want, (got, want)
+    assert np.array_equal(eng.params.cpu().numpy(), w_ref)
+
+    # (c) the public entry point runs (dropout on: only finiteness and the step count are checked)
+    m3 = fresh()
+    hist = m3.fit_generator(Seq(), epochs=2, device_feed=True, n_classes=classes)
+    assert len(hist) == 2 * steps and all(np.isfinite(h) for h in hist)

@@ -142,19 +142,23 @@ def _worker_global_nnz(rank, world, port, out_dir):
     params = O.init_params(O.param_shapes("mobilenetv2", 3), seed=1)
     names = sorted(n for n in params if "/moving_" not in n)
     loss, grads, _, _ = O.train_grads(params, x[lo:hi], labels[lo:hi], w[lo:hi], bn_frozen=True, **KW)
-    # what Engine.train_step does with external_nnz: the loss kernel divides by count_all / world instead of the
-    # shard's own count (the oracle normalised by the local count: rescale)
+    # what Engine.train_step does with external_nnz (round 5): every rank differentiates sum_shard(l*w) / c0 with a fixed
+    # c0 (the oracle normalised by the shard's own count: rescale), its count(w != 0) and loss sum ride behind the
+    # gradients through ONE all-reduce, and the optimizer multiplies by c0 / count_all
     local = float((w[lo:hi] != 0).sum())
-    denom = dp.sum_over_ranks(local) / dp.world
-    flat_g = torch.from_numpy(_flat(grads, names) * np.float32(local / denom))
-    scale = dp.allreduce_grads(flat_g)
-    mean_loss = dp.mean_over_ranks(loss * local / denom)
-    np.savez(os.path.join(out_dir, "n%d.npz" % rank), g=flat_g.numpy() * scale, lo=lo, hi=hi, loss=mean_loss)
+    c0 = float(x.shape[1] * x.shape[2])
+    g = _flat(grads, names)
+    arena = torch.from_numpy(np.concatenate([g * np.float32(local / c0), np.float32([local, loss * local / c0])]))
+    dp.allreduce_grads(arena)
+    a = arena.numpy()
+    n = g.size
+    np.savez(os.path.join(out_dir, "n%d.npz" % rank), g=a[:n] * np.float32(c0 / a[n]), lo=lo, hi=hi,
+             loss=float(a[n + 1]) * c0 / float(a[n]), count=float(a[n]))
     dp.close()
 
 
 def test_global_loss_normalisation_over_a_ragged_batch(tmp_path):
-    """parallel.DataParallel.shard / sum_over_ranks + the rule of Engine.train_step(external_nnz): 5 images over 2
+    """parallel.DataParallel.shard / allreduce_grads + the rule of Engine.train_step(external_nnz): 5 images over 2
     ranks (2 + 3, the remainder on the last rank like multi_gpu_model's last tower), unequal void fractions; with
     frozen BatchNorm the exchanged gradient and the reported loss equal the single-process step on all 5 images."""
     s = socket.socket()
@@ -171,4 +175,5 @@ def test_global_loss_normalisation_over_a_ragged_batch(tmp_path):
     loss, grads, _, _ = O.train_grads(params, x, labels, w, bn_frozen=True, **KW)
     want = _flat(grads, names)
     assert np.allclose(r0["g"], want, rtol=1e-4, atol=1e-6 * np.abs(want).max())
-    assert abs(float(r0["loss"]) - loss) < 1e-6 * abs(loss)
+    assert abs(float(r0["loss"]) - loss) < 1e-6 * abs(loss) and float(r0["loss"]) == float(r1["loss"])
+    assert float(r0["count"]) == float((w != 0).sum())
