@@ -88,6 +88,7 @@ class Ref:
         self.dtype = dtype
         self.batch_stats = {}  # BN layer name -> (batch mean, biased batch variance) of the last training forward
         self.bn_meta = {}      # BN layer name -> (epsilon, values per channel) of that forward
+        self.record = None     # diagnostics (tools/r5/xception_layer_distance.py): BN layer name -> its output, NHWC numpy
 
     # x is NCHW throughout
     def conv(self, x, name, k=1, stride=1, same=True, bias=False):
@@ -121,7 +122,10 @@ class Ref:
                 self.batch_stats[name] = (x.mean(dim=(0, 2, 3)).numpy(), x.var(dim=(0, 2, 3), unbiased=False).numpy())
                 self.bn_meta[name] = (eps, x.shape[0] * x.shape[2] * x.shape[3])
             return F.batch_norm(x, None, None, g, b, True, 0.0, eps)
-        return F.batch_norm(x, mm, mv, g, b, False, 0.0, eps)
+        y = F.batch_norm(x, mm, mv, g, b, False, 0.0, eps)
+        if self.record is not None:
+            self.record[name] = y.detach().permute(0, 2, 3, 1).numpy().copy()
+        return y
 
     def resize(self, x, Ho, Wo):
         """separable form out = Ry . x . Rx^T of the legacy bilinear resize (columns first, like TF's top/bottom lerp)"""
