@@ -237,6 +237,50 @@ def roofline_blocks(rows, args):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+def host_cpu_grant():
+    """what this process may actually use of the host: the affinity mask, the cgroup CPU quota
+    (cpu.max of cgroup v2, cfs_quota_us / cfs_period_us of v1), SMT siblings and the NUMA layout from sysfs"""
+    def cpulist(txt):
+        out = []
+        for part in txt.strip().split(","):
+            if not part:
+                continue
+            lo, _, hi = part.partition("-")
+            out += list(range(int(lo), int(hi or lo) + 1))
+        return out
+
+    aff = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = None if q <= 0 else q / per
+        except Exception:
+            quota = None
+    nodes = {}
+    base = "/sys/devices/system/node"
+    try:
+        for d in sorted(os.listdir(base)):
+            if d.startswith("node") and d[4:].isdigit():
+                nodes[int(d[4:])] = [c for c in cpulist(open(os.path.join(base, d, "cpulist")).read()) if c in aff]
+    except Exception:
+        nodes = {}
+    # one hardware thread per physical core of the mask (the first sibling of each core)
+    cores = []
+    for c in aff:
+        try:
+            sib = cpulist(open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read())
+        except Exception:
+            sib = [c]
+        if c == min(s for s in sib if s in aff or s == c):
+            cores.append(c)
+    return dict(affinity=aff, quota=quota, nodes={k: v for k, v in nodes.items() if v}, physical=cores)
+
+
 def cpu_baseline_leg(args):
     """CPU restatement of the same training step (oracle/torch_ref.py: torch/oneDNN on the host cores), SURVEY §8d
     protocol: thread counts swept up to os.cpu_count() (one probe step each), then the median of 10 steps after 2
@@ -244,7 +288,20 @@ def cpu_baseline_leg(args):
     Keras/TensorFlow CPU path cannot be installed here."""
     from oracle import dl3_oracle as O
     from oracle import torch_ref as T
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    grant = host_cpu_grant()
+    # the cores actually granted: physical cores of the affinity mask inside ONE NUMA node (the one with most of them: a
+    # oneDNN thread pool straddling two sockets scales negatively — that, not oneDNN, was rounds 1-4's "slower at 32 than at
+    # 16 threads"), capped by the cgroup quota; the leg pins itself there and restores the mask afterwards
+    node_cpus = max(grant["nodes"].values(), key=len) if grant["nodes"] else grant["affinity"]
+    pin = [c for c in grant["physical"] if c in node_cpus] or node_cpus
+    if grant["quota"]:
+        pin = pin[:max(1, int(grant["quota"]))]
+    avail = len(pin)
+    old_aff = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    if old_aff is not None:
+        os.sched_setaffinity(0, pin)
+    log("cpu baseline: affinity %d hw threads, cgroup quota %s, %d NUMA node(s) -> pinned to %d physical core(s) of one node" % (
+        len(grant["affinity"]), grant["quota"], len(grant["nodes"]) or 1, avail))
 
     def case(size, classes, B):
         kw = dict(backbone=args.backbone, input_shape=(size, size, 3), classes=classes, OS=args.os)
@@ -287,12 +344,19 @@ def cpu_baseline_leg(args):
         x = np.random.default_rng(0).integers(0, 256, (1, size, size, 3)).astype(np.float32)
         return lambda: T.infer_logits(params, x, **kw)
 
-    c2 = measure(case(args.size, 21, 2), 2, "cfg2 %dx%d B=2" % (args.size, args.size))
-    cpu_a = cpu_a_leg(args, avail)
-    c1 = measure(case_fwd1(128, 2), 1, "cfg1 128x128 single-image forward")
-    # cfg1's shape as a training step, B=2 (with one image the image-pooling BatchNorm sees a single value per channel)
-    c1t = measure(case(128, 2, 2), 2, "cfg1 128x128 B=2 fwd+bwd")
+    try:
+        c2 = measure(case(args.size, 21, 2), 2, "cfg2 %dx%d B=2" % (args.size, args.size))
+        cpu_a = cpu_a_leg(args, avail)
+        c1 = measure(case_fwd1(128, 2), 1, "cfg1 128x128 single-image forward")
+        # cfg1's shape as a training step, B=2 (with one image the image-pooling BatchNorm sees a single value per channel)
+        c1t = measure(case(128, 2, 2), 2, "cfg1 128x128 B=2 fwd+bwd")
+    finally:
+        if old_aff is not None:
+            os.sched_setaffinity(0, old_aff)
     return dict(value=c2["value"], unit="img/s", cores=c2["cores"], kind="port", host_cores_available=avail,
+                host={"affinity_hw_threads": len(grant["affinity"]), "cgroup_cpu_quota": grant["quota"],
+                      "numa_nodes": {str(k): len(v) for k, v in grant["nodes"].items()},
+                      "physical_cores_in_mask": len(grant["physical"]), "pinned_to": "%d physical cores of one NUMA node" % avail},
                 sample="median of 10 steps x 2 images %dx%dx21 fwd+bwd after 2 warm-up steps, torch-CPU (oneDNN) restatement "
                        "oracle/torch_ref.py; thread counts swept (4 ... all cores, stopping once a count is half as fast as "
                        "the best): oneDNN's fp32 convolutions of this graph stop scaling at `cores` threads on this host — "

@@ -10,6 +10,42 @@ read/written as `.npz` with keys "<layer>/<var>:0" plus "__layer_names__".
 import numpy as np
 
 
+# Keras 2.2.4 engine/saving.py: an attribute larger than this is stored in pieces `name0`, `name1`, ... instead of `name`
+# (save_attributes_to_hdf5_group / load_attributes_from_hdf5_group: HDF5 object headers hold at most 64 KB)
+HDF5_OBJECT_HEADER_LIMIT = 64512
+
+
+def attr_list(attrs, name):
+    """the string-array attribute `name` of a Keras file — whole, or reassembled from its pieces name0, name1, ...;
+    attrs: any mapping (h5py AttributeManager, h5lite's dict); [] if neither form exists"""
+    dec = lambda x: x.decode() if isinstance(x, bytes) else str(x)
+    if name in attrs:
+        return [dec(x) for x in np.atleast_1d(attrs[name])]
+    out, i = [], 0
+    while "%s%d" % (name, i) in attrs:
+        out += [dec(x) for x in np.atleast_1d(attrs["%s%d" % (name, i)])]
+        i += 1
+    return out
+
+
+def attr_pieces(name, strings, limit=None):
+    """[(attribute name, [bytes, ...]), ...] as Keras writes a string-array attribute: one attribute, or — if the
+    fixed-length array would exceed the object-header limit — the smallest number of equal pieces that fit"""
+    limit = HDF5_OBJECT_HEADER_LIMIT if limit is None else limit
+    data = [x if isinstance(x, bytes) else str(x).encode() for x in strings]
+    width = max([len(x) for x in data] or [1])
+    if any(len(x) > limit for x in data):
+        raise RuntimeError("a name in %r is longer than the HDF5 object header limit" % name)
+    chunks = 1
+    split = [data]
+    while any(len(c) * width > limit for c in split):
+        chunks += 1
+        split = [list(a) for a in np.array_split(np.array(data, dtype=object), chunks)]
+    if chunks == 1:
+        return [(name, data)]
+    return [("%s%d" % (name, i), c) for i, c in enumerate(split)]
+
+
 def _h5py():
     try:
         import h5py
@@ -37,13 +73,18 @@ def save_weights(model, path):
         h5lite.write_keras_weights(path, [(l.name, list(zip(l.weights.keys(), l.get_weights()))) for l in layers])
         return
     with h5py.File(path, "w", libver="earliest") as f:
-        f.attrs["layer_names"] = np.array([l.name.encode() for l in layers], dtype="S")
+        for an, piece in attr_pieces("layer_names", [l.name for l in layers]):
+            f.attrs[an] = np.array(piece, dtype="S")
         f.attrs["backend"] = b"tensorflow"
         f.attrs["keras_version"] = b"2.2.4"
         for l in layers:
             g = f.create_group(l.name)
             names = list(l.weights.keys())
-            g.attrs["weight_names"] = np.array([n.encode() for n in names], dtype="S") if names else np.zeros((0,), "S1")
+            if names:
+                for an, piece in attr_pieces("weight_names", names):
+                    g.attrs[an] = np.array(piece, dtype="S")
+            else:
+                g.attrs["weight_names"] = np.zeros((0,), "S1")
             for n, w in zip(names, l.get_weights()):
                 g.create_dataset(n, data=np.asarray(w, np.float32))
 
@@ -65,12 +106,13 @@ def _read_file(path):
         return h5lite.read_keras_weights(path)
     with h5py.File(path, "r") as f:
         root = f["model_weights"] if "model_weights" in f else f
-        dec = lambda s: s.decode() if isinstance(s, bytes) else str(s)
-        names = [dec(n) for n in root.attrs["layer_names"]]
+        names = attr_list(root.attrs, "layer_names")
+        if not names:
+            raise ValueError("%s: no layer_names attribute (whole or in pieces): not a Keras weights file" % path)
         per = {}
         for n in names:
             g = root[n]
-            per[n] = [(dec(w), np.asarray(g[dec(w)])) for w in g.attrs["weight_names"]]
+            per[n] = [(w, np.asarray(g[w])) for w in attr_list(g.attrs, "weight_names")]
         return names, per
 
 

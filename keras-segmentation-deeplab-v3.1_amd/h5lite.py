@@ -240,17 +240,15 @@ def read_keras_weights(path):
     if "model_weights" in top:  # model.save(): weights nested one level down
         root = top["model_weights"]
         top = r.children(root)
-    a = r.attrs(root)
-    if "layer_names" not in a:
+    from .h5io import attr_list   # (`layer_names` / `weight_names` whole, or in Keras' pieces name0, name1, ...)
+    names = attr_list(r.attrs(root), "layer_names")
+    if not names:
         raise H5Error("no layer_names attribute: not a Keras weights file")
-    dec = lambda s: s.decode() if isinstance(s, bytes) else str(s)
-    names = [dec(s) for s in np.atleast_1d(a["layer_names"])]
     per = {}
     for n in names:
         g = top[n]
-        wn = r.attrs(g).get("weight_names", [])
         items = []
-        for w in [dec(s) for s in np.atleast_1d(wn)] if len(np.atleast_1d(wn)) else []:
+        for w in attr_list(r.attrs(g), "weight_names"):
             node = g
             for part in w.split("/"):
                 node = r.children(node)[part]
@@ -379,8 +377,10 @@ class Writer:
         return bytes(self.buf)
 
 
-def write_keras_weights(path, layers):
-    """layers: [(layer_name, [(weight_name, array), ...]), ...] in model.layers order (Keras 2.2.x save_weights layout)"""
+def write_keras_weights(path, layers, attr_limit=None):
+    """layers: [(layer_name, [(weight_name, array), ...]), ...] in model.layers order (Keras 2.2.x save_weights layout);
+    string-array attributes beyond attr_limit bytes (default: Keras' HDF5_OBJECT_HEADER_LIMIT) are written in pieces"""
+    from .h5io import attr_pieces
     w = Writer()
     top = {}
     for lname, weights in layers:
@@ -409,10 +409,12 @@ def write_keras_weights(path, layers):
                 kids[k] = (o, True, bt, hp)
             else:
                 kids[k] = (w.dataset(v), False, 0, 0)
-        o, bt, hp = w.group(kids, [_attr_strings("weight_names", [n.encode() for n, _ in weights])])
+        o, bt, hp = w.group(kids, [_attr_strings(an, piece) for an, piece in
+                                   attr_pieces("weight_names", [n for n, _ in weights], attr_limit)] if weights else
+                            [_attr_strings("weight_names", [])])
         top[lname] = (o, True, bt, hp)
-    root = w.group(top, [_attr_strings("layer_names", [n.encode() for n, _ in layers]),
-                         _attr_scalar_string("backend", b"tensorflow"),
+    root = w.group(top, [_attr_strings(an, piece) for an, piece in attr_pieces("layer_names", [n for n, _ in layers], attr_limit)] +
+                        [_attr_scalar_string("backend", b"tensorflow"),
                          _attr_scalar_string("keras_version", b"2.2.4")])
     with open(path, "wb") as f:
         f.write(w.finish(root))

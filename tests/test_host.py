@@ -469,3 +469,44 @@ def test_trainable_flags_follow_keras_224_compile_semantics():
     m.compile(optimizer=None)
     opt3, upd3, key3 = m._training_flags()
     assert not opt3["aspp0"] and opt3["concat_projection"] and opt3 == upd3 and key3 == ("compiled", 2)
+
+
+def test_keras_split_attributes_are_read_and_written(tmp_path):
+    """Keras 2.2.4 stores a `layer_names` / `weight_names` attribute larger than 64 512 bytes in pieces `name0`, `name1`, ...
+    (engine/saving.py save_attributes_to_hdf5_group): both readers reassemble them, the writer cuts
+    them the way Keras does.  Forced here with a small limit on a real model file."""
+    import dl3_amd  # noqa: F401
+    from dl3_amd import graph as G, h5io, h5lite
+    from dl3_amd.deeplabv3p import Deeplabv3
+    # the helpers on their own: one attribute below the limit, the smallest number of equal pieces above it
+    names = ["layer_%03d" % i for i in range(100)]
+    assert h5io.attr_pieces("layer_names", names) == [("layer_names", [n.encode() for n in names])]
+    pieces = h5io.attr_pieces("layer_names", names, limit=300)
+    assert [a for a, _ in pieces] == ["layer_names%d" % i for i in range(len(pieces))] and len(pieces) == 4
+    assert all(len(p) * 9 <= 300 for _, p in pieces) and [x for _, p in pieces for x in p] == [n.encode() for n in names]
+    as_attrs = {a: np.array(p, dtype="S") for a, p in pieces}
+    assert h5io.attr_list(as_attrs, "layer_names") == names                   # what the h5py reader does with .attrs
+    assert h5io.attr_list({"layer_names": np.array(names, "S")}, "layer_names") == names
+    assert h5io.attr_list({}, "layer_names") == []
+    # a real model through the package's own HDF5 writer / reader with every string attribute in pieces
+    G.clear_session()
+    m = Deeplabv3(weights=None, input_shape=(64, 64, 3), classes=3, backbone="mobilenetv2")
+    layers = [(l.name, list(zip(l.weights.keys(), l.get_weights()))) for l in m.layers]
+    path = str(tmp_path / "split.h5")
+    h5lite.write_keras_weights(path, layers, attr_limit=400)
+    r = h5lite.Reader(path)
+    root_attrs = r.attrs(r.root["ohdr"])
+    assert "layer_names" not in root_attrs and "layer_names0" in root_attrs and "layer_names3" in root_attrs
+    got_names, per = h5lite.read_keras_weights(path)
+    assert got_names == [n for n, _ in layers]
+    for n, ws in layers:
+        assert [k for k, _ in per[n]] == [k for k, _ in ws]
+        for (_, a), (_, b) in zip(per[n], ws):
+            assert np.array_equal(a, b)
+    # and the model loads it by name
+    G.clear_session()
+    m2 = Deeplabv3(weights=None, input_shape=(64, 64, 3), classes=3, backbone="mobilenetv2")
+    m2.load_weights(path, by_name=True)
+    for la, lb in zip(m.layers, m2.layers):
+        for a, b in zip(la.get_weights(), lb.get_weights()):
+            assert np.array_equal(a, b)
