@@ -135,6 +135,7 @@ class Buf:
         self.grad = None       # tensor [M, ld]
         self.addend = None     # pending pass-through gradient (tensor [M, ld])
         self.nonneg = False
+        self.centred = set()   # channel offsets of slices stored as y - moving_mean (PwUnit.set_output_offset)
 
     def vptr(self, row, off=0):
         return self.vec.data_ptr() + 4 * (row * self.ld + off)
@@ -488,6 +489,18 @@ class Engine:
             getattr(self, "_lo_" + l.kind)(l)
         out = self.views[id(m.output)]
         self.out_view = out
+        self._check_centred_consumers()
+
+    def _check_centred_consumers(self):
+        """a slice stored as y - mean (centred frozen BatchNorm) must never be read raw: every unit input that touches it
+        has to be an affine view (the view carries the matching scale / shift)"""
+        for u in self.units:
+            for w in (getattr(u, "inv", None), getattr(u, "a", None), getattr(u, "b", None)):
+                if w is None or not w.buf.centred:
+                    continue
+                hit = any(off < w.off + w.C and w.off < off + C for _, off, C in w.buf.bns if off in w.buf.centred)
+                if hit and not w.aff:
+                    raise RuntimeError("unit %s reads the centred tensor %s raw" % (type(u).__name__, w.buf.name))
 
     def _producer_of(self, t):
         l = t.layer
@@ -635,8 +648,7 @@ class Engine:
                     self.wptr(n + "/moving_mean:0"), self.wptr(n + "/moving_variance:0"), l.cfg["eps"], C,
                     v.buf.vptr(V_SCALE, v.off), v.buf.vptr(V_SHIFT, v.off), v.buf.vptr(V_MEAN, v.off),
                     v.buf.vptr(V_INVSTD, v.off), negm)
-            assert unit.fwd_rec[0] in ("dl3_pwconv_fwd", "dl3_pwconv_fwd_add") and unit.fwd_rec[2][6] is None
-            unit.fwd_rec[2][6] = negm
+            unit.set_output_offset(negm)   # (the buffer holds y - mean from here on: Buf.centred)
         else:
             self.op(self.ops_prep, "dl3_bn_frozen", self.wptr(n + "/gamma:0"), self.wptr(n + "/beta:0"),
                     self.wptr(n + "/moving_mean:0"), self.wptr(n + "/moving_variance:0"), l.cfg["eps"], C,
@@ -964,10 +976,31 @@ class Engine:
                 self._join_before.add(id(rec))
         if self.fork_pairs:
             self._pair_wgrads_with_depthwise()
+        self._check_dy_adjacency()
         assert not self.prestat, "BatchNorm-backward sums reduced early but never folded"
         for b in self.bufs:
             if b.requires_grad and b.expected and b.done != b.expected:
                 raise RuntimeError("gradient accounting broken for buffer %s (%d/%d)" % (b.name, b.done, b.expected))
+
+    def _check_dy_adjacency(self):
+        """ONE buffer holds the materialised dY of whichever 1x1 convolution is being differentiated: between the launch
+        that writes it (dl3_pwconv_bwd_weight_dy) and the layer's bwd-data launch that reads it, no other launch may write
+        it — i.e. no second dl3_pwconv_bwd_weight_dy — and both must sit on the same stream (any future
+        reordering of ops_bwd would otherwise corrupt gradients silently)"""
+        if self.dy_buf is None:
+            return
+        dy = ptr(self.dy_buf)
+        pending = None
+        for rec in self.ops_bwd:
+            name, args = rec[0], rec[2]
+            if name == "dl3_pwconv_bwd_weight_dy":
+                assert pending is None, "two dY writers without the first one's reader in between"
+                assert args[-2] == dy and id(rec) not in self._side, "dY written off the main stream / into another buffer"
+                pending = (args[14], args[15], args[16])    # M, K, N
+            elif name == "dl3_pwconv_bwd_data" and args[0] == dy:
+                assert pending == (args[22], args[23], args[24]), ("bwd-data reads a dY another layer wrote", pending)
+                pending = None
+        assert pending is None, "a materialised dY was never read"
 
     def _pair_wgrads_with_depthwise(self):
         """DL3_FORK=2: every depthwise backward launch takes the nearest earlier 1x1 weight gradient with it (moved to just
@@ -1381,6 +1414,15 @@ class PwUnit(_ConvBase):
                                   eng.wptr(self.bias) if self.bias else None, outv.p(), outv.ld, self.M, self.K, self.N,
                                   ptr(self.stat), ptr(img_add.t), self.N, self.M // eng.B)
 
+    def set_output_offset(self, neg_offset_ptr):
+        """donate the GEMM's free bias slot (a BatchNorm'ed Conv2D has use_bias=False) to -moving_mean: the output tensor
+        then holds y - mean, and ONLY affine consumers (scale * stored + beta) may read it — the slice is recorded in
+        Buf.centred and Engine._check_centred_consumers refuses a raw view of it"""
+        rec = self.fwd_rec
+        assert rec[0] in ("dl3_pwconv_fwd", "dl3_pwconv_fwd_add") and rec[2][6] is None and self.bias is None
+        rec[2][6] = neg_offset_ptr
+        self.outv.buf.centred.add(self.outv.off)
+
     def _bwd_img_add(self, g, ldg, y, ldy, cA, cB, cC):
         """gradient of the per-image addend: S[img, n] = sum over the image's pixels of dY[m, n], dY = cA*g + cB*y + cC
         (two per-image column sums with the coefficients folded in, then their sum)"""
@@ -1399,6 +1441,12 @@ class PwUnit(_ConvBase):
                ptr(gout), N, B, N, 0.0, 0, None)
 
     def dy_mat_ok(self):
+        """(decided ONCE per unit: the buffer sizing in _lower_backward and bwd() must agree)"""
+        if getattr(self, "_dy_ok", None) is None:
+            self._dy_ok = bool(self._dy_mat_rule())
+        return self._dy_ok
+
+    def _dy_mat_rule(self):
         """does the weight-gradient launch of this convolution also write dY for its bwd-data launch?  (its output is
         BatchNorm'ed — otherwise dY is g itself —, it has a weight gradient to compute and data gradient to hand on, the
         backward fork is off — the two launches must stay ordered on one stream — and the shape rule of Engine.dy_mat holds)"""
@@ -1409,6 +1457,11 @@ class PwUnit(_ConvBase):
                 and not eng.fork and not self.bias and eng.trainable(self.wname()) and self.inv.buf.requires_grad)
 
     def fused_ok(self):
+        if getattr(self, "_fused_ok", None) is None:
+            self._fused_ok = bool(self._fused_rule())
+        return self._fused_ok
+
+    def _fused_rule(self):
         """both gradients in one pass (dl3_pwconv_bwd_fused): a small weight matrix, many pixel rows, a trainable kernel
         without bias, a data gradient to hand on, whole aligned tensors on both sides"""
         eng, inv, outv = self.eng, self.inv, self.outv

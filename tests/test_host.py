@@ -510,3 +510,57 @@ def test_keras_split_attributes_are_read_and_written(tmp_path):
     for la, lb in zip(m.layers, m2.layers):
         for a, b in zip(la.get_weights(), lb.get_weights()):
             assert np.array_equal(a, b)
+
+
+def _dry_engine(monkeypatch, backbone, B, size=512, OS=16, **kw):
+    """lower a plan WITHOUT a GPU: Engine only records launches and asks libdl3.so's host-side sizing queries while it
+    lowers; with torch.cuda.is_available patched and the buffers on the CPU (untouched virtual memory) the whole plan —
+    ops, arguments, workspace sizes, consistency checks — can be inspected here"""
+    import collections
+    import torch
+    import dl3_amd  # noqa: F401
+    from dl3_amd import capi, graph as G
+    from dl3_amd.deeplabv3p import Deeplabv3
+    from dl3_amd.engine import Engine
+    capi.lib()
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    G.clear_session()
+    m = Deeplabv3(weights=None, input_shape=(size, size, 3), classes=21, backbone=backbone, OS=OS)
+    e = Engine(m, batch=B, training=True, device="cpu", **kw)
+    return e, collections.Counter(op[0] for op in e.ops_fwd + e.ops_bwd)
+
+
+def test_benchmarked_plan_lowers_consistently_without_a_gpu(monkeypatch):
+    """the plan bench.py times (cfg2, B=128) and its small-batch / frozen / data-parallel / Xception relatives, lowered on
+    the CPU: kernel routes of round 5 (12 both-gradient launches incl. the six-block 32 <-> 192 layers, 12 forward
+    launches on the weight-stationary kernel), ONE dY buffer with writer and reader adjacent (Engine._check_dy_adjacency),
+    centred frozen BatchNorm never read raw (Engine._check_centred_consumers), and the data-parallel engine's count / loss
+    sum living in the arena tail"""
+    from dl3_amd import capi
+    L = capi.lib()
+    e, c = _dry_engine(monkeypatch, "mobilenetv2", 128)
+    assert c["dl3_pwconv_bwd_fused"] == 12 and c["dl3_pwconv_bwd_weight_dy"] == 20
+    ws = [op for op in e.ops_fwd if op[0] == "dl3_pwconv_fwd" and L.dl3_pwconv_fwd_impl(op[2][9], op[2][10], op[2][11]) == 1]
+    assert len(ws) == 12 and {(op[2][10], op[2][11]) for op in ws} == {(32, 16), (16, 96), (96, 24), (24, 144), (144, 24),
+                                                                      (144, 32), (32, 192), (192, 32)}
+    for op in ws:   # the statistic partial buffer the engine sized covers the kernel's one row per workgroup
+        assert L.dl3_pwconv_partials(op[2][9], op[2][10], op[2][11]) >= 768
+    assert e.dy_buf is not None and c["dl3_count_nonzero"] == 1
+    e2, c2 = _dry_engine(monkeypatch, "mobilenetv2", 2)
+    assert c2["dl3_pwconv_bwd_fused"] == 6            # only the 256x256 / 128x128 layers have >= 32768 rows at B=2
+    # frozen BatchNorm: statistics launches gone, every BatchNorm'ed 1x1 output centred and never read raw
+    e3, c3 = _dry_engine(monkeypatch, "mobilenetv2", 2, bn_mode="frozen")
+    assert c3["dl3_bn_finalize"] == 0 and c3["dl3_bn_frozen_centered"] == 0   # (prep ops are not in fwd / bwd)
+    assert sum(1 for op in e3.ops_prep if op[0] == "dl3_bn_frozen_centered") >= 35
+    assert any(b.centred for b in e3.bufs)
+    # data parallel: the shard's count(w != 0) and loss sum are written INTO the gradient arena's tail
+    e4, c4 = _dry_engine(monkeypatch, "mobilenetv2", 2, external_nnz=True)
+    cnt = [op for op in e4.ops_fwd if op[0] == "dl3_count_nonzero"][0]
+    assert cnt[2][2] == e4.grads.data_ptr() + 4 * e4.tail and e4.grads.numel() == e4.tail + 4
+    red = [op for op in e4.ops_fwd if op[0] == "dl3_reduce_partials"][-1]
+    assert red[2][3] == e4.grads.data_ptr() + 4 * (e4.tail + 1) == e4.loss.data_ptr()
+    assert e4.nnz_host == 512 * 512 and float(e4.nnz[0]) == 512 * 512
+    # Xception OS=8: no fused launches (no layer small enough), dY materialised for its 1x1 convolutions
+    e5, c5 = _dry_engine(monkeypatch, "xception", 1, size=256, OS=8)
+    assert c5["dl3_pwconv_bwd_fused"] == 0 and c5["dl3_pwconv_bwd_weight_dy"] > 50
