@@ -362,10 +362,14 @@ __global__ __launch_bounds__(256) void grad_finish_kernel(const float *gin, int 
 __global__ __launch_bounds__(256) void gap_kernel(const float *__restrict__ x, int ldx,
                                                   const float *__restrict__ sc, const float *__restrict__ sh,
                                                   int act, float *__restrict__ out, int HW, int C, float out_scale) {
-  __shared__ float red[256];
+  // Sums in DOUBLE (round 5): the pooled feature is ONE value per image and channel that the ASPP adds to every pixel
+  // (deeplabv3p.py:375-382) — its rounding error is coherent over the whole map, and the per-layer distance to float64
+  // of the Xception OS=8 inference (tools/r5/xception_layer_distance.py) parted from torch-fp32's exactly here.  4 096
+  // terms per (image, channel): the double adds are free next to the loads.
+  __shared__ double red[256];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl, n = blockIdx.y;
-  float s = 0.f;
+  double s = 0.0;
   if (c < C) {
     float es = 1.f, et = 0.f;
     if (sc) { es = sc[c]; et = sh[c]; }
@@ -377,24 +381,24 @@ __global__ __launch_bounds__(256) void gap_kernel(const float *__restrict__ x, i
       float v[16];
 #pragma unroll
       for (int u = 0; u < 16; u++) v[u] = p[(size_t)(i + 8 * u) * ldx];
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
       for (int u = 0; u < 16; u += 4) {
-        a0 += dl3_act(es * v[u] + et, act);
-        a1 += dl3_act(es * v[u + 1] + et, act);
-        a2 += dl3_act(es * v[u + 2] + et, act);
-        a3 += dl3_act(es * v[u + 3] + et, act);
+        a0 += (double)dl3_act(es * v[u] + et, act);
+        a1 += (double)dl3_act(es * v[u + 1] + et, act);
+        a2 += (double)dl3_act(es * v[u + 2] + et, act);
+        a3 += (double)dl3_act(es * v[u + 3] + et, act);
       }
       s += (a0 + a1) + (a2 + a3);
     }
-    for (; i < HW; i += 8) s += dl3_act(es * p[(size_t)i * ldx] + et, act);
+    for (; i < HW; i += 8) s += (double)dl3_act(es * p[(size_t)i * ldx] + et, act);
   }
   red[threadIdx.x] = s;
   __syncthreads();
   if (rl == 0 && c < C) {
-    float t = 0.f;
+    double t = 0.0;
     for (int q = 0; q < 8; q++) t += red[q * 32 + cl];
-    out[(size_t)n * C + c] = t * out_scale;
+    out[(size_t)n * C + c] = (float)(t * (double)out_scale);
   }
 }
 

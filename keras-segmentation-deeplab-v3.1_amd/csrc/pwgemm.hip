@@ -1285,9 +1285,7 @@ int env_int(const char *name);
 //     block, 128 contiguous bytes per row and instruction (the epilogue of an HBM-bound kernel is store-ISSUE-bound).
 // Tile -> wave assignment is static (tile t belongs to wave t mod 4G): the statistic partial rows are deterministic.
 // KQ = K / 8 (16-byte loads per lane and tile), TN = ceil(N / 32).
-// PRE: the next tile's rows are requested BEFORE this tile's MFMAs (a second register set: short reductions); otherwise
-// right behind them, into the registers they just freed — in front of this tile's stores either way.
-template <int KQ, int TN, int OC, bool PRE>
+template <int KQ, int TN, int OC>
 __global__ __launch_bounds__(256, OC) void pw_fwd_ws_kernel(GemmArgs P) {
   constexpr int KH = 4 * KQ, K = 8 * KQ, NP = 32 * TN;
   __shared__ float Ws[K * NP];        // W[k][n], zero beyond N
@@ -1333,39 +1331,23 @@ __global__ __launch_bounds__(256, OC) void pw_fwd_ws_kernel(GemmArgs P) {
 #pragma unroll
     for (int j = 0; j < KQ; j++) nx[j] = ld4(p + 4 * j);
   };
-  // MFMAs of the tile whose rows are in nx; `next` >= 0: that tile's rows are requested as early as the registers allow
+  // MFMAs of the tile whose rows are in nx; then, the registers being free again, ALL K/8 requests of tile `next` (>= 0) —
+  // in front of this tile's stores, so that the wait for them at the next tile's start is a counted one.  (Requested a
+  // whole tile ahead through a second register set — measured: no faster for K <= 32, spills from K = 96; left alone the
+  // scheduler sinks the requests between the MFMAs one by one to save registers — twelve exposed round trips per tile.)
   auto mfma_tile = [&](f32x16 (&acc)[TN], int next) {
-    if constexpr (PRE) {
-      // transform in registers, then request the next tile into the same registers
-      float ac[KH];
 #pragma unroll
-      for (int j = 0; j < KQ; j++) {
-        const f32x4 v = dl3_act4(ld4(cfs + 4 * j) * nx[j] + ld4(cft + 4 * j), P.a_act);
-        ac[4 * j + 0] = v.x; ac[4 * j + 1] = v.y; ac[4 * j + 2] = v.z; ac[4 * j + 3] = v.w;
-      }
-      if (next >= 0) load_tile(next);
-      __builtin_amdgcn_sched_barrier(0);  // (the requests stay in front of the MFMAs: the scheduler would sink them)
+    for (int q = 0; q < KQ; q++) {
+      const f32x4 v = dl3_act4(ld4(cfs + 4 * q) * nx[q] + ld4(cft + 4 * q), P.a_act);
 #pragma unroll
-      for (int s = 0; s < KH; s++)
+      for (int e = 0; e < 4; e++)
 #pragma unroll
         for (int j = 0; j < TN; j++)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[s], wfrag[s * NP + j * 32], acc[j], 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int q = 0; q < KQ; q++) {
-        const f32x4 v = dl3_act4(ld4(cfs + 4 * q) * nx[q] + ld4(cft + 4 * q), P.a_act);
-#pragma unroll
-        for (int e = 0; e < 4; e++)
-#pragma unroll
-          for (int j = 0; j < TN; j++)
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[e], wfrag[(4 * q + e) * NP + j * 32], acc[j], 0, 0, 0);
-      }
-      // the registers are free again: all K/8 requests of the next tile, in front of this tile's stores (left alone the
-      // scheduler interleaves them with the MFMAs one by one to save registers — twelve exposed round trips per tile)
-      __builtin_amdgcn_sched_barrier(0);
-      if (next >= 0) load_tile(next);
-      __builtin_amdgcn_sched_barrier(0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[e], wfrag[(4 * q + e) * NP + j * 32], acc[j], 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (next >= 0) load_tile(next);
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   if (gw < nfull) load_tile(gw);
@@ -1458,6 +1440,38 @@ __global__ __launch_bounds__(256, OC) void pw_fwd_ws_kernel(GemmArgs P) {
         }
       }
     }
+  }
+}
+
+// ---- a handful of rows (the ASPP image-pooling branch: ONE row per image, deeplabv3p.py:375-382, and its share of
+// concat_projection, :402-406): Y[m][n] = act(ka*x + kc)[m][:] . W[:][n] + bias + addend, accumulated in DOUBLE.  The
+// result is a per-image constant the network adds to every pixel of the 64x64 map: its rounding error does not average
+// out over pixels, and a reduction of 2 048 on the f32 MFMA was where the HIP path's distance to float64 left torch-fp32's
+// (tools/r5/xception_layer_distance.py: ratio 1.00 up to the exit flow, 1.08 behind image_pooling, 1.15 at the logits).
+// 64 columns x 4 slices of the reduction per workgroup, slices folded in slice order; M <= 256 rows: microseconds.
+__global__ __launch_bounds__(256) void pw_rows_f64_kernel(GemmArgs P) {
+  __shared__ double red[4][64];
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + cl, m = blockIdx.y;
+  const int kper = (P.K + 3) / 4, k0 = sl * kper, k1 = min(P.K, k0 + kper);
+  const float *xr = P.a + (size_t)m * P.lda;
+  const bool xform = P.ka != nullptr;
+  double acc = 0.0;
+  if (n < P.N) {
+    for (int k = k0; k < k1; k++) {
+      float v = xr[k];
+      if (xform) v = P.ka[k] * v + P.kc[k];
+      v = dl3_act(v, P.a_act);
+      acc += (double)v * (double)P.b[(size_t)k * P.ldb + n];
+    }
+  }
+  red[sl][cl] = acc;
+  __syncthreads();
+  if (sl == 0 && n < P.N) {
+    double t = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
+    if (P.bias) t += (double)P.bias[n];
+    if (P.ep_add) t += (double)(P.add_scale * P.ep_add[(size_t)(m / P.add_div) * P.ld_add + n]);
+    P.c[(size_t)m * P.ldc + n] = (float)t;
   }
 }
 
@@ -1627,20 +1641,23 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   // (a per-image addend stays on the forward instantiation when its straight-line epilogue can take it: 32-row blocks
   // inside one image)
   const bool fwd = !two && !A.ep_x && A.stat_mode != 2 && !(A.ep_add && A.add_div > 1 && A.add_div % 32 != 0);
+  // a forward launch of a handful of rows without statistics: double accumulation (pw_rows_f64_kernel)
+  if (!two && !A.ep_x && A.M <= 256 && A.stat_mode == 0 && env_int("DL3_ROWS_F64") != 0) {
+    hipLaunchKernelGGL(pw_rows_f64_kernel, dim3(dl3_cdiv(A.N, 64), A.M), dim3(256), 0, st, A);
+    return 0;
+  }
   if (ws_wanted(A, fwd, vec) && !split_math()) {
     const dim3 grid(ws_grid(A.M)), blk(256);
-#define DL3_WS(KQ_, TN_, OC_, PRE_) hipLaunchKernelGGL((pw_fwd_ws_kernel<KQ_, TN_, OC_, PRE_>), grid, blk, 0, st, A)
+#define DL3_WS(KQ_, TN_, OC_) hipLaunchKernelGGL((pw_fwd_ws_kernel<KQ_, TN_, OC_>), grid, blk, 0, st, A)
     const int tn = ws_tn(A.K, A.N);
-    // per shape: the spill-free instantiation with the most workgroups per CU; DL3_WS_VAR=1: the alternative (A/B aid: more
-    // registers, the next tile requested a whole tile ahead)
-    const bool alt = env_int("DL3_WS_VAR") == 1;
-    if (A.K == 16) { if (alt) DL3_WS(2, 3, 3, true); else DL3_WS(2, 3, 4, false); }
-    else if (A.K == 24) { if (alt) DL3_WS(3, 5, 2, true); else DL3_WS(3, 5, 3, false); }
-    else if (A.K == 32 && tn == 1) { if (alt) DL3_WS(4, 1, 4, true); else DL3_WS(4, 1, 4, false); }
-    else if (A.K == 32) { if (alt) DL3_WS(4, 6, 2, true); else DL3_WS(4, 6, 3, false); }
-    else if (A.K == 96) DL3_WS(12, 1, 4, false);
-    else if (A.K == 144) DL3_WS(18, 1, 3, false);
-    else DL3_WS(24, 1, 3, false);
+    // (workgroups per CU: the most the registers allow without spilling)
+    if (A.K == 16) DL3_WS(2, 3, 4);
+    else if (A.K == 24) DL3_WS(3, 5, 3);
+    else if (A.K == 32 && tn == 1) DL3_WS(4, 1, 4);
+    else if (A.K == 32) DL3_WS(4, 6, 3);
+    else if (A.K == 96) DL3_WS(12, 1, 4);
+    else if (A.K == 144) DL3_WS(18, 1, 3);
+    else DL3_WS(24, 1, 3);
 #undef DL3_WS
     return (int)grid.x;
   }

@@ -663,11 +663,16 @@ def test_pwconv_bwd_fused_six_blocks(L, case):
     test_pwconv_bwd_fused(L, case)
 
 
-@pytest.mark.parametrize("case", [FUSED_CASES[2], FUSED_CASES[3], FUSED6_CASES[0], FUSED6_CASES[2], FUSED6_CASES[3]])
-def test_pwconv_bwd_fused_three_workgroups_per_cu(L, case, monkeypatch):
-    """the five / six-block instantiations budgeted for three workgroups per CU (DL3_FUSED_OCC=3: small spills) compute the
-    same thing"""
-    monkeypatch.setenv("DL3_FUSED_OCC", "3")
+@pytest.mark.parametrize("case", [FUSED_CASES[3], FUSED_CASES[4], FUSED_CASES[5], FUSED_CASES[9], FUSED6_CASES[2], FUSED6_CASES[4],
+                                  (32 * 7, 144, 24, 2, True, False, 1), (50, 96, 24, 1, True, False, 1),
+                                  (4096 + 31, 100, 32, 2, True, False, 1)])
+def test_pwconv_bwd_fused_wide_dx_without_the_lds_tile(L, case, monkeypatch):
+    """the whole-block shapes (K > 64) send dX through the x tile in LDS and out as 16-byte stores (the default, covered by
+    the cases above); DL3_FUSED_TILE=0 keeps the four-byte stores from the accumulators: same results.  Also here: whole
+    stages only (no ragged tail), fewer rows than two stages, and K = 100 — a 4-block shape whose threads do not all own a
+    valid column group, which must fall back to the four-byte stores by itself."""
+    test_pwconv_bwd_fused(L, case)
+    monkeypatch.setenv("DL3_FUSED_TILE", "0")
     test_pwconv_bwd_fused(L, case)
 
 
@@ -790,6 +795,48 @@ def test_pwconv_fwd_add(L, M, K, N, div):
     assert relerr(host(y), ref) < 2e-5
     s1, s2 = fold_partials(part, P, N)
     assert relerr(s1, ref.sum(0)) < 1e-4 and relerr(s2, (ref ** 2).sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize("M,K,N,ldx_extra,ldy_extra,div", [(1, 2048, 256, 0, 0, 0), (3, 320, 256, 0, 0, 0), (128, 256, 256, 0, 0, 1),
+                                                          (256, 2048, 256, 64, 8, 0), (6, 96, 21, 0, 0, 3), (2, 2048, 256, 0, 0, 2)])
+def test_pwconv_fwd_few_rows_accumulates_in_double(L, M, K, N, ldx_extra, ldy_extra, div):
+    """a forward 1x1 convolution over a handful of rows without statistics — the ASPP image-pooling branch, one row per
+    image (deeplabv3p.py:375-382), and its per-image share of concat_projection — is accumulated in DOUBLE
+    (pw_rows_f64_kernel: its result is added to every pixel of the map, its rounding error does not average out): the
+    result is the float64 product rounded ONCE, far inside what a float32 reduction of 2 048 terms can do; with input
+    transform, bias, per-image / per-row addend, channel slices on both sides; and the global pool in front of it
+    (dl3_gap_fwd) sums in double as well"""
+    rng = np.random.default_rng(100 * M + N)
+    ldx, ldy = K + ldx_extra, N + ldy_extra
+    xf = rng.normal(0, 1, (M, ldx)).astype(np.float32)
+    w = rng.normal(0, 0.2, (K, N)).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, K).astype(np.float32), rng.normal(0, 0.3, K).astype(np.float32)
+    bias = rng.normal(0, 0.5, N).astype(np.float32)
+    x = xf[:, ldx_extra:]
+    t32 = np_act(x * sc + sh, 1)                                   # the transform itself is float32 arithmetic
+    ref = t32.astype(np.float64) @ w.astype(np.float64) + bias
+    yfull = torch.zeros(M, ldy, dtype=torch.float32, device="cuda")
+    xd = dev(xf)
+    if div:
+        add = rng.normal(0, 1, (M // div, N)).astype(np.float32)
+        ref = ref + np.repeat(add.astype(np.float64), div, axis=0)
+        call("dl3_pwconv_fwd_add", ptr(xd, ldx_extra), ldx, ptr(dev(sc)), ptr(dev(sh)), 1, ptr(dev(w)), ptr(dev(bias)),
+             ptr(yfull, ldy_extra), ldy, M, K, N, None, ptr(dev(add)), N, div)
+    else:
+        call("dl3_pwconv_fwd", ptr(xd, ldx_extra), ldx, ptr(dev(sc)), ptr(dev(sh)), 1, ptr(dev(w)), ptr(dev(bias)),
+             ptr(yfull, ldy_extra), ldy, M, K, N, None)
+    y = host(yfull)
+    err = np.abs(y[:, ldy_extra:] - ref).max() / np.abs(ref).max()
+    assert err < 1.5e-7, err                                        # one float32 rounding of the float64 result
+    if ldy_extra:
+        assert np.all(y[:, :ldy_extra] == 0)
+    # the global pool: 4 096 pixels x channels, float64 sums rounded once
+    HW, C, B = 4096, 96, 2
+    t = rng.normal(3.0, 1.0, (B, HW, C)).astype(np.float32)
+    out = empty(B, C)
+    call("dl3_gap_fwd", ptr(dev(t)), C, None, None, 0, ptr(out), B, HW, C, 1.0 / HW)
+    want = t.astype(np.float64).mean(1)
+    assert np.abs(host(out) - want).max() / np.abs(want).max() < 1.5e-7
 
 
 @pytest.mark.parametrize("M", [2, 37, 4096])

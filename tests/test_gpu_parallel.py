@@ -260,33 +260,54 @@ def test_data_parallel_step_with_a_one_rank_rccl_communicator_under_hipgraph():
         sw = ((y[..., 0] < classes) * rng.uniform(0.5, 2.0, y.shape[:2])).astype(np.float32)
         batches.append((x, y, sw))
 
-    def run(distributed):
+    def run(mode):
+        """mode 'plain': the single-process engine; 'tail': the data-parallel engine (external_nnz) without a communicator;
+        'rccl': Model.distribute() with a one-rank RCCL communicator"""
         model, params = _build("mobilenetv2", shape, classes, "deeplab")
         _load(model, params)
         dp = None
-        if distributed:
+        kw = dict(dropout=False)
+        if mode == "rccl":
             dp = DataParallel().attach_single_rank_rccl()
             assert dp.rccl_ranks() == 1
             model.distribute(dp)
-        losses = [model.train_on_batch(x, y, sw, dropout=False) for x, y, sw in batches]
+        elif mode == "tail":
+            kw["external_nnz"] = True
+        losses, g1 = [], None
+        for x, y, sw in batches:
+            losses.append(model.train_on_batch(x, y, sw, **kw))
+            if g1 is None:
+                e = model._active
+                g1 = e.grads.cpu().numpy().copy()
+                if e.external_nnz:   # what Adam applied: arena x c0 / count_all
+                    g1 = g1[:e.n_param] * np.float32(e.nnz_host / g1[e.tail])
+                else:
+                    g1 = g1[:e.n_param]
         eng = model._active
         assert eng.graph is not None, "the step was never captured"
-        assert eng.external_nnz == distributed
+        assert eng.external_nnz == (mode != "plain")
         torch.cuda.synchronize()
         w = eng.params.cpu().numpy().copy()
         st = eng.state.cpu().numpy().copy()
         if dp is not None:
             dp.close()
-        return losses, w, st
+        return losses, w, st, g1
 
-    la, wa, sa = run(False)
-    lb, wb, sb = run(True)
-    assert all(abs(a - b) < 2e-6 * abs(a) for a, b in zip(la, lb)), (la, lb)
-    dw = float(np.abs(wa - wb).max())
-    print("one-rank RCCL step vs plain step after 4 steps: max |dw| %.2e (lr 7e-4), losses %s / %s" % (dw, la, lb))
-    assert dw < 2e-5 and np.allclose(sa, sb, rtol=1e-5, atol=1e-6)
+    la, wa, sa, ga = run("plain")
+    lt, wt, st_, gt = run("tail")
+    lb, wb, sb, gb = run("rccl")
+    # the communicator and the captured all-reduce change NOTHING: a sum over one rank is the identity
+    assert lt == lb and np.array_equal(wt, wb) and np.array_equal(st_, sb) and np.array_equal(gt, gb)
+    # against the plain engine the scaling point moved (loss kernel / c0, Adam x c0 / count_all): first-step loss and
+    # gradient agree to fp32 rounding.  (Later steps part like any two fp32 evaluations do under Adam: an element whose
+    # gradient is below rounding noise moves by +-lr at random, DESIGN.md §4 — which is why rounds 1-4 could only assert
+    # this test bit for bit, and why that is no longer possible.)
+    err = float(np.linalg.norm(gb - ga) / np.linalg.norm(ga))
+    print("one-rank RCCL step vs plain step: first-step loss %.9f / %.9f, gradient rel-L2 %.2e; losses %s / %s" % (
+        la[0], lb[0], err, la, lb))
+    assert abs(la[0] - lb[0]) < 2e-6 * abs(la[0]) and err < 1e-5
+    assert all(abs(a - b) < 5e-3 * abs(a) for a, b in zip(la, lb))
     assert len(set(la)) == 4
-
 
 def test_data_parallel_step_has_no_host_round_trip():
     """the data-parallel step — captured forward/backward, ONE RCCL all-reduce of the arena (gradients +
