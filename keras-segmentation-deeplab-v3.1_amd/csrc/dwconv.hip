@@ -154,19 +154,23 @@ __global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x,
 #pragma unroll
     for (int j = 0; j < R; j++) {
       const int k = kg + j;
-      if (k > ke) break;
+      // (no `if (k > ke) break;` here: a path that leaves the group early leaves the group's remaining requests
+      // un-waited-for, the compiler then has to wait for EVERYTHING at the head of the row loop before it may reuse their
+      // registers — vmcnt(0) in front of the next group's requests, i.e. every wave drained its own stores each group
+      // and only then asked for the next rows.  Rows beyond ke are all-zero slots: predicated instead.  Round 5.)
+      const bool kv = k <= ke;
       // input row k feeds out[k+1] (tap row 0), out[k] (tap row 1), out[k-1] (tap row 2)
       f32x4 h0 = wv[0] * l[j] + wv[1] * m[j] + wv[2] * rr[j];
       f32x4 h1 = wv[3] * l[j] + wv[4] * m[j] + wv[5] * rr[j];
       f32x4 h2 = wv[6] * l[j] + wv[7] * m[j] + wv[8] * rr[j];
       f32x4 out = accA + h2;
-      if (active && k - 1 >= k0 && k - 1 < k1) {
+      if (active && kv && k - 1 >= k0 && k - 1 < k1) {
         st4_nt(ybase + ((size_t)(a + (k - 1) * r) * W + xx) * C, out);
         s1 += out;
         s2 += out * out;
       }
-      accA = accB + h1;
-      accB = h0;
+      accA = kv ? accB + h1 : accA;
+      accB = kv ? h0 : accB;
     }
   }
   if (!bot_halo && k0 < k1 && active) {  // last row of the phase: no row below contributes
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256) void dw_march2_fwd(const float *__restrict__ x
 #pragma unroll
       for (int j = 0; j < R; j++) {
         const int k = kg + j;
-        if (k > ke) break;
+        const bool kv = k <= ke;   // (predicated, not `break`: see dw_march_fwd)
         // pixel a: taps (p0, p1, p2); pixel b: taps (p1, p2, p3)
         const f32x4 a0 = wv[0] * p[j][0] + wv[1] * p[j][1] + wv[2] * p[j][2];
         const f32x4 a1 = wv[3] * p[j][0] + wv[4] * p[j][1] + wv[5] * p[j][2];
@@ -259,13 +263,13 @@ __global__ __launch_bounds__(256) void dw_march2_fwd(const float *__restrict__ x
         const f32x4 b1 = wv[3] * p[j][1] + wv[4] * p[j][2] + wv[5] * p[j][3];
         const f32x4 b2 = wv[6] * p[j][1] + wv[7] * p[j][2] + wv[8] * p[j][3];
         const f32x4 oa = aA + a2, ob = bA + b2;
-        if (k - 1 >= k0 && k - 1 < k1) {
+        if (kv && k - 1 >= k0 && k - 1 < k1) {
           float *orow = ybase + (size_t)(a + (k - 1) * r) * W * C;
           if (act_a) { st4_nt(orow + (size_t)xa * C, oa); s1 += oa; s2 += oa * oa; }
           if (act_b) { st4_nt(orow + (size_t)xb * C, ob); s1 += ob; s2 += ob * ob; }
         }
-        aA = aB + a1; aB = a0;
-        bA = bB + b1; bB = b0;
+        aA = kv ? aB + a1 : aA; aB = kv ? a0 : aB;
+        bA = kv ? bB + b1 : bA; bB = kv ? b0 : bB;
       }
     }
     if (!bot_halo && k0 < k1) {  // last row of the phase: no row below contributes
@@ -372,19 +376,23 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
     ld_e(ks, e_cur, ok_cur);
     ld_e(ks + 1, e_next, ok_next);
     for (int kg = ks; kg <= ke; kg += R) {
-      f32x4 l[R], m[R], rr[R], e_new[R], sxv[R];
+      f32x4 l[R], m[R], rr[R], e_new[R], sxv[R], addv[R];
       bool ok_new[R];
 #pragma unroll
       for (int j = 0; j < R; j++) {
         ld_dd((kg + j <= ke) ? kg + j : -1, l[j], m[j], rr[j]);
         ld_e(kg + j + 2, e_new[j], ok_new[j]);
-        // slot j of the group finishes dx row kg + j - 1: its x_hat operand (own column, clamped row: always in bounds)
-        if (sx) sxv[j] = ld4(sx + imgc + ((size_t)(a + min(max(kg + j - 1, 0), Kc) * r) * W + xc) * C);
+        // slot j of the group finishes dx row kg + j - 1: its x_hat operand and its residual addend (own column, clamped
+        // row: always in bounds) travel with the group's requests — a load inside the predicated store block below is
+        // waited for with vmcnt(0), which the in-order counter turns into "everything this wave has in flight" (round 5)
+        const size_t orow = imgc + ((size_t)(a + min(max(kg + j - 1, 0), Kc) * r) * W + xc) * C;
+        if (sx) sxv[j] = ld4(sx + orow);
+        if (dx_add) addv[j] = ld4(dx_add + orow);
       }
 #pragma unroll
       for (int j = 0; j < R; j++) {
         const int k = kg + j;
-        if (k > ke) break;
+        const bool kv = k <= ke;   // (predicated, not `break`: see dw_march_fwd)
         if (k >= k0 && k < k1) {
           // dW[i][j] += T(x)[k+i-1][x] * dY[k][x-(j-1)r] : j=0 -> right tap, j=2 -> left tap
           f32x4 ea0 = eact(e_prev, ok_prev), ea1 = eact(e_cur, ok_cur), ea2 = eact(e_next, ok_next);
@@ -397,19 +405,19 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
         f32x4 h1 = wv[3] * rr[j] + wv[4] * m[j] + wv[5] * l[j];
         f32x4 h2 = wv[6] * rr[j] + wv[7] * m[j] + wv[8] * l[j];
         f32x4 out = accA + h0;
-        if (dx && active && k - 1 >= k0 && k - 1 < k1) {
+        if (dx && active && kv && k - 1 >= k0 && k - 1 < k1) {
           const size_t off = img + ((size_t)(a + (k - 1) * r) * W + xx) * C;
           out = out * dl3_mask4(s * e_prev + t, act);
-          if (dx_add) out += ld4(dx_add + off);
+          if (dx_add) out += addv[j];
           st4_nt(dx + off, out);
           s1 += out;
           s2 += out * (((sx ? sxv[j] : e_prev) - mu) * is);
         }
-        accA = accB + h1;
-        accB = h2;
-        e_prev = e_cur; ok_prev = ok_cur;
-        e_cur = e_next; ok_cur = ok_next;
-        e_next = e_new[j]; ok_next = ok_new[j];
+        accA = kv ? accB + h1 : accA;
+        accB = kv ? h2 : accB;
+        e_prev = kv ? e_cur : e_prev; ok_prev = kv ? ok_cur : ok_prev;
+        e_cur = kv ? e_next : e_cur; ok_cur = kv ? ok_next : ok_cur;
+        e_next = kv ? e_new[j] : e_next; ok_next = kv ? ok_new[j] : ok_next;
       }
     }
     if (!bot_halo && dx && active) {  // last dx row of the phase (e_prev now holds forward input row k1-1)

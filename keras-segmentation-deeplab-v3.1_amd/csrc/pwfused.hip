@@ -313,15 +313,13 @@ struct Fused2 {
 };
 
 // OC: workgroups per CU the registers are budgeted for.
-// TILE (whole-block shapes, K > 64: dX is the WIDE side): the finished dX values of a stage are written back into the x
-// tile in LDS (every element over the raw x it was masked with) and leave at the top of the next stage as 16-byte stores
-// by all 256 threads — thread t stores exactly the LDS slots it is about to overwrite with the next stage's x, so no
-// barrier sits between the two — instead of 16 four-byte stores per lane and block (80 store instructions per stage at
-// K = 144 become 18), and with a FIXED number of stores per stage for every wave (see klast above: the counted wait).
-template <int KB, int NB, bool AUX, int OC, bool TILE = false>
+// (Round 5 also built the wide-dX shapes — K > 64 — with the finished dX values written back into the x tile in LDS and
+// stored 16 bytes per lane by all 256 threads at the top of the next stage, 18 store instructions per stage instead of
+// 80 at K = 144: one more barrier per stage, and slower — 144 -> 24 0.785 -> 0.911 ms, 192 -> 32 0.249 -> 0.284 ms,
+// whole step 1 287 -> 1 280 img/s, same call, profiles/r05_ab_calls.txt call 4.  Removed.)
+template <int KB, int NB, bool AUX, int OC>
 __global__ __launch_bounds__(256, OC) void pw_bwd_fused2_kernel(FusedArgs P) {
   using C = Fused2<KB, NB, AUX>;
-  static_assert(!TILE || (C::SPLIT == 1 && !AUX), "dX through the x tile: whole-block shapes only");
   constexpr int KP = C::KP, NP = C::NP, LDX = C::LDX, LDD = C::LDD, LDW = C::LDW, NBLK = C::NBLK;
   constexpr int SPLIT = C::SPLIT, XB = C::XB, WB = C::WB, NWB = C::NWB;
   __shared__ float smem[C::TOTAL];
@@ -461,11 +459,7 @@ __global__ __launch_bounds__(256, OC) void pw_bwd_fused2_kernel(FusedArgs P) {
       if (P.add) v += Ad[rl * LDX + col];
       if (sep) xh = Sx[rl * LDX + col];
     }
-    if constexpr (FULL && TILE) {
-      if (own) Xr[rl * LDX + col] = v;   // (own: col is the lane's own column; same wave, same instruction: read before write)
-      s1 += own ? v : 0.f;
-      s2 += own ? v * ((xh - mu) * is) : 0.f;
-    } else if constexpr (FULL) {
+    if constexpr (FULL) {
       __builtin_nontemporal_store(v, &P.dx[(size_t)row * P.lddx + col]);
       s1 += own ? v : 0.f;
       s2 += own ? v * ((xh - mu) * is) : 0.f;
@@ -496,7 +490,6 @@ __global__ __launch_bounds__(256, OC) void pw_bwd_fused2_kernel(FusedArgs P) {
       }
     }
 
-    if constexpr (TILE && decltype(fullc)::value) __syncthreads();  // no wave reads x for dW any more: finish may overwrite it
     // ---- dX = dY . W^T, finished per stage
     if constexpr (SPLIT > 1) {
       f32x16 acc;
@@ -548,41 +541,6 @@ __global__ __launch_bounds__(256, OC) void pw_bwd_fused2_kernel(FusedArgs P) {
     }
   };
 
-  // TILE: the dX tile of stage m0p (in Xr, behind the stage's last barrier) -> HBM, 16 bytes per lane.  A padding slot
-  // (columns K .. KP) stores one of the thread's OWN valid slots a second time (every thread has one for KB = 3, 5, 6 and
-  // for K = KP: checked by the launcher) — never another thread's, whose owner may already be overwriting it.
-  int t_mr[KB], t_k4[KB], t_dup = 0;
-  if constexpr (TILE) {
-#pragma unroll
-    for (int i = 0; i < KB; i++) {
-      const int idx = tid + 256 * i;
-      t_mr[i] = idx / (KP / 4);
-      t_k4[i] = (idx % (KP / 4)) * 4;
-    }
-#pragma unroll
-    for (int i = KB - 1; i >= 0; i--)
-      if (t_k4[i] < P.K) t_dup = i;
-  }
-  auto tile_store = [&](int m0p) {
-    if constexpr (TILE) {
-      f32x4 o[KB];
-#pragma unroll
-      for (int i = 0; i < KB; i++) o[i] = ld4(&Xr[t_mr[i] * LDX + t_k4[i]]);
-      f32x4 od = o[0];
-      int dmr = t_mr[0], dk4 = t_k4[0];
-#pragma unroll
-      for (int i = 1; i < KB; i++)
-        if (t_dup == i) { od = o[i]; dmr = t_mr[i]; dk4 = t_k4[i]; }
-#pragma unroll
-      for (int i = 0; i < KB; i++) {
-        const bool ok = t_k4[i] < P.K;
-        const f32x4 v = ok ? o[i] : od;
-        const int mr = ok ? t_mr[i] : dmr, k4 = ok ? t_k4[i] : dk4;
-        st4_nt(P.dx + (size_t)(m0p + mr) * P.lddx + k4, v);
-      }
-    }
-  };
-
   __syncthreads();  // the coefficient vectors (and W^T) are in LDS
   // per-column constants of this wave's dX blocks, ONCE: a global load inside the stage loop (x_mean / x_invstd used to be
   // fetched per stage) is waited for with vmcnt(0) — and the in-order counter then drains the next stage's requests, the
@@ -604,20 +562,7 @@ __global__ __launch_bounds__(256, OC) void pw_bwd_fused2_kernel(FusedArgs P) {
     stage(std::true_type{}, m0);
     __syncthreads();  // every wave is done with the stage before it is overwritten
   };
-  if constexpr (TILE) {
-    // (the first stage is peeled by hand: a loop whose first trip skips the tile stores merges two wait states at its
-    // head and the compiler falls back to vmcnt(0) for the last of the stage's requests — the store drain again)
-    if (mbeg < mfull) {
-      whole_stage(mbeg);
-      for (int m0 = mbeg + FMS; m0 < mfull; m0 += FMS) {
-        tile_store(m0 - FMS);
-        whole_stage(m0);
-      }
-      tile_store(mfull - FMS);
-    }
-  } else {
-    for (int m0 = mbeg; m0 < mfull; m0 += FMS) whole_stage(m0);
-  }
+  for (int m0 = mbeg; m0 < mfull; m0 += FMS) whole_stage(m0);
   if (mfull < mend) {  // the ragged last stage of the launch's last workgroup: every element predicated
     store_lds(mfull);
     __syncthreads();
@@ -778,16 +723,8 @@ extern "C" int dl3_pwconv_bwd_fused(const float *x, int ldx, const float *in_sca
   DL3_FUSED(1, 1, false, 4); DL3_FUSED(1, 2, false, 4); DL3_FUSED(1, 3, false, 3); DL3_FUSED(1, 4, false, 3);
   DL3_FUSED(1, 5, false, 2); DL3_FUSED(1, 6, false, 2);
   DL3_FUSED(2, 1, false, 4); DL3_FUSED(2, 2, false, 3); DL3_FUSED(2, 3, false, 2);
-  // whole-block shapes: dX through the x tile (16-byte stores) where every thread owns a valid slot and dx is aligned;
-  // DL3_FUSED_TILE=0 keeps the four-byte stores (A/B aid)
-  const bool tile = kb >= 3 && (kb != 4 || K == 128) && lddx % 4 == 0 && al16(dx) && fused_env("DL3_FUSED_TILE") != 0;
-#define DL3_FUSEDT(KB_, NB_, OC_) \
-  if (kb == KB_ && nb == NB_ && !aux) { \
-    if (tile) hipLaunchKernelGGL((pw_bwd_fused2_kernel<KB_, NB_, false, OC_, true>), dim3(S), dim3(256), 0, st, A); \
-    else hipLaunchKernelGGL((pw_bwd_fused2_kernel<KB_, NB_, false, OC_, false>), dim3(S), dim3(256), 0, st, A); \
-  }
-  DL3_FUSEDT(3, 1, 4); DL3_FUSEDT(4, 1, 4); DL3_FUSEDT(5, 1, 2); DL3_FUSEDT(6, 1, 2); DL3_FUSEDT(3, 2, 3);
-#undef DL3_FUSEDT
+  DL3_FUSED(3, 1, false, 4); DL3_FUSED(4, 1, false, 4); DL3_FUSED(5, 1, false, 2); DL3_FUSED(6, 1, false, 2);
+  DL3_FUSED(3, 2, false, 3);
   DL3_FUSED(1, 1, true, 3); DL3_FUSED(1, 2, true, 3); DL3_FUSED(1, 3, true, 3); DL3_FUSED(1, 4, true, 3);
   DL3_FUSED(1, 5, true, 2); DL3_FUSED(1, 6, true, 2); DL3_FUSED(2, 1, true, 3); DL3_FUSED(2, 2, true, 3);
   DL3_FUSED(2, 3, true, 2);

@@ -679,8 +679,10 @@ class Engine:
                 raise NotImplementedError("convolution over a slice of a Concatenate with a broadcast input")
             ib = Buf(self, self.B, 1, 1, N, l.name + "_per_image")
             self.bufs.append(ib)
-            self.units.append(PwUnit(self, l, sv, View(ib, 0, N), want_stat=False, wrow0=0, use_bias=False))
+            pu = PwUnit(self, l, sv, View(ib, 0, N), want_stat=False, wrow0=0, use_bias=False)
+            self.units.append(pu)
             u = PwUnit(self, l, v, View(buf, off, N), want_stat=self._want_stat(l, buf.M), wrow0=Cb, img_add=ib)
+            u.img_unit = pu
         else:
             u = PwUnit(self, l, v, View(buf, off, N), want_stat=self._want_stat(l, buf.M))
         self._register(u, buf, off)
@@ -1418,7 +1420,10 @@ class PwUnit(_ConvBase):
         """donate the GEMM's free bias slot (a BatchNorm'ed Conv2D has use_bias=False) to -moving_mean: the output tensor
         then holds y - mean, and ONLY affine consumers (scale * stored + beta) may read it — the slice is recorded in
         Buf.centred and Engine._check_centred_consumers refuses a raw view of it"""
-        rec = self.fwd_rec
+        # a convolution with a per-image term (concat_projection: deeplabv3p.py:402-406) subtracts the mean THERE — the
+        # few-row GEMM accumulates in double, so addend - mean is rounded once and the per-pixel epilogue adds one number
+        # instead of (acc - mean) + addend, whose first step cancels against a mean that contains the addend's average
+        rec = self.img_unit.fwd_rec if getattr(self, "img_unit", None) is not None else self.fwd_rec
         assert rec[0] in ("dl3_pwconv_fwd", "dl3_pwconv_fwd_add") and rec[2][6] is None and self.bias is None
         rec[2][6] = neg_offset_ptr
         self.outv.buf.centred.add(self.outv.off)

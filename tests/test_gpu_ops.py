@@ -663,16 +663,12 @@ def test_pwconv_bwd_fused_six_blocks(L, case):
     test_pwconv_bwd_fused(L, case)
 
 
-@pytest.mark.parametrize("case", [FUSED_CASES[3], FUSED_CASES[4], FUSED_CASES[5], FUSED_CASES[9], FUSED6_CASES[2], FUSED6_CASES[4],
-                                  (32 * 7, 144, 24, 2, True, False, 1), (50, 96, 24, 1, True, False, 1),
-                                  (4096 + 31, 100, 32, 2, True, False, 1)])
-def test_pwconv_bwd_fused_wide_dx_without_the_lds_tile(L, case, monkeypatch):
-    """the whole-block shapes (K > 64) send dX through the x tile in LDS and out as 16-byte stores (the default, covered by
-    the cases above); DL3_FUSED_TILE=0 keeps the four-byte stores from the accumulators: same results.  Also here: whole
-    stages only (no ragged tail), fewer rows than two stages, and K = 100 — a 4-block shape whose threads do not all own a
-    valid column group, which must fall back to the four-byte stores by itself."""
-    test_pwconv_bwd_fused(L, case)
-    monkeypatch.setenv("DL3_FUSED_TILE", "0")
+@pytest.mark.parametrize("case", [(32 * 7, 144, 24, 2, True, False, 1), (50, 96, 24, 1, True, False, 1),
+                                  (4096 + 31, 100, 32, 2, True, False, 1), (32 * 40, 16, 96, None, True, True, 1)])
+def test_pwconv_bwd_fused_stage_structure(L, case):
+    """whole stages only (no ragged tail: the peeled last stage never runs), fewer rows than two stages, a partial last
+    32-column block of dX (K = 100, K = 16: the lanes beyond K double a valid column — same address, same bits — so that
+    every lane issues every store of a whole stage and the wait for the next stage's rows stays a counted one)"""
     test_pwconv_bwd_fused(L, case)
 
 

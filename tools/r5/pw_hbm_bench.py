@@ -5,8 +5,7 @@ cold operands (the buffers of a shape rotate so that no launch re-reads what the
 
 forward: dl3_pwconv_fwd as the engine issues it (producer's BatchNorm + ReLU6 on load, BatchNorm partial sums out).  The
 weight-stationary route is a process-wide choice (DL3_FWD_WS=0|1): run the script once per setting.
-fused:   dl3_pwconv_bwd_fused, round-4 kernel (DL3_FUSED_V=1) against round 5 with and without the LDS tile for wide dX
-         (DL3_FUSED_TILE), in one process.
+fused:   dl3_pwconv_bwd_fused, round-4 kernel (DL3_FUSED_V=1) against round 5, in one process.
 Prints one line per (shape, variant): ms, algorithmic GB/s (the formulas of bench.py's in-situ table)."""
 import os
 import sys
@@ -89,9 +88,8 @@ def bench_fused():
         s, t = torch.rand(K, device="cuda") + 0.5, rnd(K) * 0.5
         mean, invstd = rnd(K), torch.rand(K, device="cuda") + 0.5
         act = 0 if has_add else 2
-        for label, env in (("r4", {"DL3_FUSED_V": "1"}), ("r5 no tile", {"DL3_FUSED_TILE": "0"}), ("r5 default", {})):
-            for k in ("DL3_FUSED_V", "DL3_FUSED_TILE"):
-                os.environ.pop(k, None)
+        for label, env in (("r4", {"DL3_FUSED_V": "1"}), ("r5", {})):
+            os.environ.pop("DL3_FUSED_V", None)
             os.environ.update(env)
             if not L.dl3_pwconv_bwd_fused_supported(M, K, N):
                 print("fused M=%8d K=%3d N=%3d add=%d foreign=%d %-10s  unsupported" % (M, K, N, has_add, foreign, label))
@@ -110,8 +108,7 @@ def bench_fused():
             ms = timed(fn, ns)
             print("fused M=%8d K=%3d N=%3d add=%d foreign=%d %-10s  %7.3f ms  %6.0f GB/s" % (
                 M, K, N, has_add, foreign, label, ms, by / ms / 1e6))
-        for k in ("DL3_FUSED_V", "DL3_FUSED_TILE"):
-            os.environ.pop(k, None)
+        os.environ.pop("DL3_FUSED_V", None)
         del xs, gs, ysr, dxs, adds, sxs
         torch.cuda.empty_cache()
 
