@@ -115,6 +115,14 @@ int dl3_pwconv_fwd(const float *x, int ldx, const float *in_scale, const float *
 int dl3_pwconv_fwd_add(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
                        const float *w, const float *bias, float *y, int ldy, int M, int K, int N,
                        float *stat_partial, const float *add, int ldadd, int add_div, void *stream);
+/* the same product for a FEW rows — one per image: the ASPP image-pooling branch (deeplabv3p.py:375-382) and its share of
+ * concat_projection (:402-406) — accumulated in DOUBLE and rounded once (round 5).  The result is a per-image constant the
+ * network adds to every pixel of the map: its rounding error does not average out over pixels, and a reduction of 2 048 on
+ * the f32 MFMA was where the path's distance to float64 left torch-fp32's (tools/r5/xception_layer_distance.py).  add
+ * (nullable): y[m,:] += add[(m / add_div) * ldadd + :].  No BatchNorm partial sums (few rows: dl3_bn_finalize_direct). */
+int dl3_pwconv_fwd_rows(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
+                        const float *w, const float *bias, float *y, int ldy, int M, int K, int N, const float *add,
+                        int ldadd, int add_div, void *stream);
 /* dx[M,K](lddx) = mask_{in_act}(dY[M,N] . wT[N,K]) + add_scale*dx_add ; dY = cA*g + cB*yraw + cC.
  * x/in_scale/in_shift/in_act describe the FORWARD input (needed for the mask and x_hat);
  * dx_add row address = dx_add + (m / add_div)*ldadd (add_div = H*W broadcasts a per-image vector);

@@ -1443,8 +1443,8 @@ __global__ __launch_bounds__(256, OC) void pw_fwd_ws_kernel(GemmArgs P) {
   }
 }
 
-// ---- a handful of rows (the ASPP image-pooling branch: ONE row per image, deeplabv3p.py:375-382, and its share of
-// concat_projection, :402-406): Y[m][n] = act(ka*x + kc)[m][:] . W[:][n] + bias + addend, accumulated in DOUBLE.  The
+// ---- dl3_pwconv_fwd_rows: a handful of rows (the ASPP image-pooling branch: ONE row per image, deeplabv3p.py:375-382,
+// and its share of concat_projection, :402-406): Y[m][n] = act(ka*x + kc)[m][:] . W[:][n] + bias + addend, in DOUBLE.  The
 // result is a per-image constant the network adds to every pixel of the 64x64 map: its rounding error does not average
 // out over pixels, and a reduction of 2 048 on the f32 MFMA was where the HIP path's distance to float64 left torch-fp32's
 // (tools/r5/xception_layer_distance.py: ratio 1.00 up to the exit flow, 1.08 behind image_pooling, 1.15 at the logits).
@@ -1641,11 +1641,6 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   // (a per-image addend stays on the forward instantiation when its straight-line epilogue can take it: 32-row blocks
   // inside one image)
   const bool fwd = !two && !A.ep_x && A.stat_mode != 2 && !(A.ep_add && A.add_div > 1 && A.add_div % 32 != 0);
-  // a forward launch of a handful of rows without statistics: double accumulation (pw_rows_f64_kernel)
-  if (!two && !A.ep_x && A.M <= 256 && A.stat_mode == 0 && env_int("DL3_ROWS_F64") != 0) {
-    hipLaunchKernelGGL(pw_rows_f64_kernel, dim3(dl3_cdiv(A.N, 64), A.M), dim3(256), 0, st, A);
-    return 0;
-  }
   if (ws_wanted(A, fwd, vec) && !split_math()) {
     const dim3 grid(ws_grid(A.M)), blk(256);
 #define DL3_WS(KQ_, TN_, OC_) hipLaunchKernelGGL((pw_fwd_ws_kernel<KQ_, TN_, OC_>), grid, blk, 0, st, A)
@@ -1905,6 +1900,25 @@ extern "C" int dl3_pwconv_fwd_add(const float *x, int ldx, const float *in_scale
   const int written = run_gemm(A, st);
   DL3_CHECK_ARG(written >= 0, "pwconv_fwd_add: split-math weight scratch unavailable (first launch inside a stream capture?)");
   DL3_LAUNCH_CHECK("pwconv_fwd_add");
+  return DL3_OK;
+}
+
+extern "C" int dl3_pwconv_fwd_rows(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
+                                   const float *w, const float *bias, float *y, int ldy, int M, int K, int N,
+                                   const float *add, int ldadd, int add_div, void *stream) {
+  int rc = gemm_common_check("pwconv_fwd_rows", M, K, N);
+  if (rc) return rc;
+  DL3_CHECK_ARG(x && w && y, "pwconv_fwd_rows: null pointer");
+  DL3_CHECK_ARG(ldx >= K && ldy >= N && (!add || (ldadd >= N && add_div >= 1)), "pwconv_fwd_rows: bad leading dimension / add_div");
+  DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "pwconv_fwd_rows: scale/shift must come together");
+  DL3_UNSUPPORTED(M > 65535, "pwconv_fwd_rows: a few rows (one per image), not %d", M);
+  GemmArgs A{};
+  A.a = x; A.lda = ldx; A.ka = in_scale; A.kc = in_shift; A.a_act = in_act;
+  A.b = w; A.ldb = N; A.bias = bias; A.c = y; A.ldc = ldy;
+  A.M = M; A.K = K; A.N = N;
+  A.ep_add = add; A.ld_add = ldadd; A.add_div = add_div < 1 ? 1 : add_div; A.add_scale = 1.f;
+  hipLaunchKernelGGL(pw_rows_f64_kernel, dim3(dl3_cdiv(N, 64), M), dim3(256), 0, (hipStream_t)stream, A);
+  DL3_LAUNCH_CHECK("pwconv_fwd_rows");
   return DL3_OK;
 }
 

@@ -1405,7 +1405,14 @@ class PwUnit(_ConvBase):
             self.stat = eng.empty(self.P * self.N * 2)
         s, t, a = inv.xform()
         w = eng.wptr(self.wname()) + 4 * self.wrow0 * self.N
-        if img_add is None:
+        if (img_add is None and not want_stat and inv.buf.H == 1 and inv.buf.W == 1
+                and os.environ.get("DL3_ROWS_F64", "1") != "0"):
+            # one row per image (the ASPP image-pooling branch and its share of concat_projection): accumulated in double
+            # (dl3_pwconv_fwd_rows) — the result is added to every pixel of the map, its rounding error is coherent
+            self.fwd_rec = eng.op(eng.ops_fwd, "dl3_pwconv_fwd_rows", inv.p(), inv.ld, s, t, a, w,
+                                  eng.wptr(self.bias) if self.bias else None, outv.p(), outv.ld, self.M, self.K, self.N,
+                                  None, 0, 1)
+        elif img_add is None:
             self.fwd_rec = eng.op(eng.ops_fwd, "dl3_pwconv_fwd", inv.p(), inv.ld, s, t, a, w,
                                   eng.wptr(self.bias) if self.bias else None, outv.p(), outv.ld, self.M, self.K, self.N,
                                   ptr(self.stat))
@@ -1423,8 +1430,11 @@ class PwUnit(_ConvBase):
         # a convolution with a per-image term (concat_projection: deeplabv3p.py:402-406) subtracts the mean THERE — the
         # few-row GEMM accumulates in double, so addend - mean is rounded once and the per-pixel epilogue adds one number
         # instead of (acc - mean) + addend, whose first step cancels against a mean that contains the addend's average
-        rec = self.img_unit.fwd_rec if getattr(self, "img_unit", None) is not None else self.fwd_rec
-        assert rec[0] in ("dl3_pwconv_fwd", "dl3_pwconv_fwd_add") and rec[2][6] is None and self.bias is None
+        rec = self.fwd_rec
+        iu = getattr(self, "img_unit", None)
+        if iu is not None and iu.fwd_rec[0] == "dl3_pwconv_fwd_rows":
+            rec = iu.fwd_rec
+        assert rec[0] in ("dl3_pwconv_fwd", "dl3_pwconv_fwd_add", "dl3_pwconv_fwd_rows") and rec[2][6] is None and self.bias is None
         rec[2][6] = neg_offset_ptr
         self.outv.buf.centred.add(self.outv.off)
 

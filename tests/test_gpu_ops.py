@@ -796,8 +796,8 @@ def test_pwconv_fwd_add(L, M, K, N, div):
 @pytest.mark.parametrize("M,K,N,ldx_extra,ldy_extra,div", [(1, 2048, 256, 0, 0, 0), (3, 320, 256, 0, 0, 0), (128, 256, 256, 0, 0, 1),
                                                           (256, 2048, 256, 64, 8, 0), (6, 96, 21, 0, 0, 3), (2, 2048, 256, 0, 0, 2)])
 def test_pwconv_fwd_few_rows_accumulates_in_double(L, M, K, N, ldx_extra, ldy_extra, div):
-    """a forward 1x1 convolution over a handful of rows without statistics — the ASPP image-pooling branch, one row per
-    image (deeplabv3p.py:375-382), and its per-image share of concat_projection — is accumulated in DOUBLE
+    """dl3_pwconv_fwd_rows: a forward 1x1 convolution over a handful of rows — the ASPP image-pooling branch, one row per
+    image (deeplabv3p.py:375-382), and its per-image share of concat_projection — accumulated in DOUBLE
     (pw_rows_f64_kernel: its result is added to every pixel of the map, its rounding error does not average out): the
     result is the float64 product rounded ONCE, far inside what a float32 reduction of 2 048 terms can do; with input
     transform, bias, per-image / per-row addend, channel slices on both sides; and the global pool in front of it
@@ -816,11 +816,11 @@ def test_pwconv_fwd_few_rows_accumulates_in_double(L, M, K, N, ldx_extra, ldy_ex
     if div:
         add = rng.normal(0, 1, (M // div, N)).astype(np.float32)
         ref = ref + np.repeat(add.astype(np.float64), div, axis=0)
-        call("dl3_pwconv_fwd_add", ptr(xd, ldx_extra), ldx, ptr(dev(sc)), ptr(dev(sh)), 1, ptr(dev(w)), ptr(dev(bias)),
-             ptr(yfull, ldy_extra), ldy, M, K, N, None, ptr(dev(add)), N, div)
+        call("dl3_pwconv_fwd_rows", ptr(xd, ldx_extra), ldx, ptr(dev(sc)), ptr(dev(sh)), 1, ptr(dev(w)), ptr(dev(bias)),
+             ptr(yfull, ldy_extra), ldy, M, K, N, ptr(dev(add)), N, div)
     else:
-        call("dl3_pwconv_fwd", ptr(xd, ldx_extra), ldx, ptr(dev(sc)), ptr(dev(sh)), 1, ptr(dev(w)), ptr(dev(bias)),
-             ptr(yfull, ldy_extra), ldy, M, K, N, None)
+        call("dl3_pwconv_fwd_rows", ptr(xd, ldx_extra), ldx, ptr(dev(sc)), ptr(dev(sh)), 1, ptr(dev(w)), ptr(dev(bias)),
+             ptr(yfull, ldy_extra), ldy, M, K, N, None, 0, 1)
     y = host(yfull)
     err = np.abs(y[:, ldy_extra:] - ref).max() / np.abs(ref).max()
     assert err < 1.5e-7, err                                        # one float32 rounding of the float64 result
