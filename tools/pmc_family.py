@@ -37,14 +37,15 @@ def per_step(d, march_rows):
 
 
 def gemm_family(fetch_dir, write_dir, plan):
-    """1x1-conv GEMM family by kernel name (pw_gemm_* + pw_wgrad_*): per-step sums, steps split at adam_kernel"""
+    """1x1-conv GEMM family by kernel name (pw_gemm_* + pw_fwd_ws_* + pw_wgrad_* + pw_bwd_fused*): per-step sums, steps split at
+    adam_kernel"""
     def load(d):
         tot, steps = 0.0, 0
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
                 k = r["Kernel_Name"]
                 steps += "adam_kernel" in k
-                if "pw_gemm" in k or "pw_wgrad" in k or "pw_bwd_fused" in k:
+                if any(t in k for t in ("pw_gemm", "pw_wgrad", "pw_bwd_fused", "pw_fwd_ws", "pw_rows_f64")):
                     tot += float(r["Counter_Value"])
         return tot / max(steps, 1), steps
     f, fs = load(fetch_dir)
@@ -53,7 +54,7 @@ def gemm_family(fetch_dir, write_dir, plan):
     fetch, write = 2.0 * f * 1024.0, w * 1024.0
     print(json.dumps({
         "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py --no-graph "
-                "--no-roofline --no-cpu-baseline; per-step sum over the pw_gemm_* / pw_wgrad_* / pw_bwd_fused_* dispatches; FETCH_SIZE "
+                "--no-roofline --no-cpu-baseline; per-step sum over the pw_gemm_* / pw_fwd_ws_* / pw_wgrad_* / pw_bwd_fused* dispatches; FETCH_SIZE "
                 "doubled (gfx950 correction of MI355X_MICROARCH.md; calibrated on wide coalesced reads — the GEMM A "
                 "operand is read in 16-byte pieces per lane, so treat the absolute as approximate), WRITE_SIZE as reported. "
                 "Algorithmic bytes count every operand once per launch; column tiles of a row tile re-read the activation "
