@@ -244,43 +244,85 @@ __global__ __launch_bounds__(256) void conv3x3_stem_fwd_mfma_kernel(const float 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int T = 9 * G.Cin;
   float bw[KS], fs[KS], ft[KS];
-  int dy[KS], dx_[KS], dc[KS];
+  int off[KS];                                   // tap offset from the pixel's top-left input element, in floats
+  unsigned m_top = 0u, m_bot = 0u, m_left = 0u, m_right = 0u, m_valid = 0u;  // bit s: tap s sits in row 0 / row 2 / column 0 / column 2
 #pragma unroll
   for (int s = 0; s < KS; s++) {
     const int kk = 2 * s + lhi, t = min(kk, T - 1);
     bw[s] = (kk < T) ? w[(size_t)t * COUT + l31] : 0.f;
-    dy[s] = t / (3 * G.Cin);
-    dx_[s] = (t / G.Cin) % 3;
-    dc[s] = t % G.Cin;
-    fs[s] = sc ? sc[dc[s]] : 1.f;
-    ft[s] = sc ? sh[dc[s]] : 0.f;
-    if (kk >= T) { fs[s] = 0.f; ft[s] = 0.f; }  // act(0) = 0: the padding tap contributes nothing
+    const int dy = t / (3 * G.Cin), dx = (t / G.Cin) % 3, dc = t % G.Cin;
+    off[s] = (dy * G.W + dx) * G.Cin + dc;
+    m_top |= (dy == 0) ? (1u << s) : 0u;
+    m_bot |= (dy == 2) ? (1u << s) : 0u;
+    m_left |= (dx == 0) ? (1u << s) : 0u;
+    m_right |= (dx == 2) ? (1u << s) : 0u;
+    m_valid |= (kk < T) ? (1u << s) : 0u;
+    fs[s] = sc ? sc[dc] : 1.f;
+    ft[s] = sc ? sh[dc] : 0.f;
   }
   float s1 = 0.f, s2 = 0.f;
-  const long NP = (long)G.N * G.Ho * G.Wo;
-  const long ntiles = (NP + 31) / 32;
-  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
-    const long p = min(tile * 32 + l31, NP - 1);
-    const int ox = (int)(p % G.Wo), oy = (int)((p / G.Wo) % G.Ho), n = (int)(p / ((long)G.Wo * G.Ho));
+  // Round 5: the tile loop is software-pipelined around its stores.  vmcnt retires in order and counts stores: with the
+  // next tile's 14 gathers requested BEHIND this tile's 16 stores (and the stores inside `if (row < NP)`, which makes the
+  // compiler wait with vmcnt(0)), every wave drained its own stores before it saw its next pixels.  Now: full tiles
+  // store unconditionally, the next tile's gathers are in flight before the stores are issued (always requested — the
+  // last tile asks for itself again — so that no load sits in a branch), the ragged last tile is peeled.  Pixel and
+  // element arithmetic in 32 bits (the host checks the sizes), one offset and five bit masks per lane instead of three
+  // index arrays.  Same sums in the same order: bit-identical outputs.
+  const unsigned NP = (unsigned)((long)G.N * G.Ho * G.Wo);
+  const unsigned nfull = NP / 32u, tstride = gridDim.x * 4u;
+  const unsigned HoWo = (unsigned)G.Ho * (unsigned)G.Wo;
+  float av[KS];
+  unsigned live = 0u;
+  auto gather = [&](unsigned tile) __attribute__((always_inline)) {
+    const unsigned p = min(tile * 32u + (unsigned)l31, NP - 1u);
+    const unsigned n = p / HoWo, rem = p - n * HoWo;
+    const int oy = (int)(rem / (unsigned)G.Wo), ox = (int)(rem - (unsigned)oy * (unsigned)G.Wo);
     const int iy0 = oy * G.stride - G.pad_t, ix0 = ox * G.stride - G.pad_l;
-    float av[KS];
+    // the 3x3 window hangs over at most one edge per axis (pad <= 1, H, W >= 2: the host checks)
+    const unsigned dead = (iy0 < 0 ? m_top : 0u) | (iy0 + 2 > G.H - 1 ? m_bot : 0u) | (ix0 < 0 ? m_left : 0u) |
+                          (ix0 + 2 > G.W - 1 ? m_right : 0u);
+    live = ~dead & m_valid;
+    const int base = ((int)n * G.H + iy0) * G.W * G.Cin + ix0 * G.Cin;     // top-left element of the window
+    const int safe = ((int)n * G.H + iy0 + 1) * G.W * G.Cin + (ix0 + 1) * G.Cin;  // its centre: always inside
 #pragma unroll
-    for (int s = 0; s < KS; s++) {
-      const int iy = iy0 + dy[s], ix = ix0 + dx_[s];
-      const int iyc = min(max(iy, 0), G.H - 1), ixc = min(max(ix, 0), G.W - 1);
-      const float live = (iy == iyc && ix == ixc) ? 1.f : 0.f;
-      av[s] = x[(((size_t)n * G.H + iyc) * G.W + ixc) * G.Cin + dc[s]] * live;
-      // (live scales the raw value; the shift ft is masked below)
-      av[s] = dl3_act(fs[s] * av[s] + ft[s] * live, act);
-    }
-    f32x16 acc;
+    for (int s = 0; s < KS; s++) av[s] = x[(unsigned)((dead >> s) & 1u ? safe : base + off[s])];
+  };
+  auto product = [&](f32x16 &acc) __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
 #pragma unroll
-    for (int s = 0; s < KS; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bw[s], acc, 0, 0, 0);
+    for (int s = 0; s < KS; s++) {
+      const float lv = (live >> s) & 1u ? 1.f : 0.f;
+      // (live scales the raw value and masks the shift: a padding tap contributes act(0) = 0)
+      const float a = dl3_act(fs[s] * (av[s] * lv) + ft[s] * lv, act);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[s], acc, 0, 0, 0);
+    }
+  };
+  unsigned tile = blockIdx.x * 4u + (unsigned)wave;
+  if (nfull > 0u) gather(min(tile, nfull - 1u));
+  // (the first tile's pixels are waited for HERE: entering the loop with loads but no stores outstanding, the compiler
+  // must size the loop-top wait for that state — "all but the 13 youngest", which on the back edge means every load and
+  // three of the stores)
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  for (; tile < nfull; tile += tstride) {
+    f32x16 acc;
+    product(acc);
+    gather(min(tile + tstride, nfull - 1u));
+    float *yt = y + ((size_t)tile * 32 + 4 * lhi) * COUT + l31;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      const long row = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      __builtin_nontemporal_store(acc[r], yt + (size_t)((r & 3) + 8 * (r >> 2)) * COUT);
+      s1 += acc[r];
+      s2 += acc[r] * acc[r];
+    }
+  }
+  if (tile == nfull && nfull * 32u < NP) {  // the ragged last tile (one wave of the grid)
+    f32x16 acc;
+    gather(tile);
+    product(acc);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const unsigned row = tile * 32u + (r & 3) + 8 * (r >> 2) + 4 * lhi;
       if (row < NP) {
         __builtin_nontemporal_store(acc[r], &y[(size_t)row * COUT + l31]);
         s1 += acc[r];
@@ -684,7 +726,9 @@ extern "C" int dl3_conv3x3_fwd(const float *x, const float *in_scale, const floa
   if (rc) return rc;
   DL3_CHECK_ARG(x && w && y, "conv3x3_fwd: null pointer");
   DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "conv3x3_fwd: scale/shift must come together");
-  if (9 * Cin <= 28 && Cout == 32)
+  // (the matrix-pipe stem kernel: 32-bit element indices, a window that leaves the image by at most one row / column)
+  if (9 * Cin <= 28 && Cout == 32 && (long)N * Ho * Wo < (1L << 31) && (long)N * H * W * Cin < (1L << 30) && pad_t <= 1 &&
+      pad_l <= 1 && H >= 3 && W >= 3 && (Ho - 1) * stride - pad_t + 2 <= H && (Wo - 1) * stride - pad_l + 2 <= W)
     hipLaunchKernelGGL((conv3x3_stem_fwd_mfma_kernel<32>), dim3(conv_blocks((long)N * Ho * Wo)), dim3(256), 0,
                        (hipStream_t)stream, x, in_scale, in_shift, in_act, w, y, G, stat_partial);
   else

@@ -725,7 +725,9 @@ def test_pwconv_bwd_fused_full_size(L):
     release()
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 32, 3, 32, 2), (1, 17, 19, 3, 32, 2), (1, 16, 16, 32, 64, 1)])
+# (7 x 510 x 390: 10 877 full 32-pixel tiles + a ragged one — more tiles than the stem kernel has waves, so its software-
+# pipelined tile loop runs two and three tiles per wave, with dead taps on every edge of the image)
+@pytest.mark.parametrize("shape", [(2, 32, 32, 3, 32, 2), (1, 17, 19, 3, 32, 2), (1, 16, 16, 32, 64, 1), (7, 510, 390, 3, 32, 2)])
 def test_conv3x3(L, shape):
     N, H, W, Cin, Cout, stride = shape
     rng = np.random.default_rng(6)
