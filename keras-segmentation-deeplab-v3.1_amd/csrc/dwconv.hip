@@ -15,9 +15,19 @@
 // BatchNorm + ReLU6 of the producer are applied on load ("input transform"); the BN batch
 // statistics of THIS layer's output are reduced in the epilogue into deterministic partials.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
+
+// wave-uniform base pointer + 32-bit BYTE offset per lane: the form the scalar-base global_load / global_store encodes
+// (a float index would be shifted left by two first and no longer be the zero-extension of a 32-bit register)
+__device__ __forceinline__ f32x4 ld4_su(const float *base, unsigned byte_off) {
+  return ld4(reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off));
+}
+__device__ __forceinline__ void st4_nt_su(float *base, unsigned byte_off, f32x4 v) {
+  st4_nt(reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off), v);
+}
 
 struct DwGeom {
   int N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo;
@@ -84,13 +94,19 @@ __device__ __forceinline__ bool dw_tile(int nxseg, int nslab, int ny, int N, int
   t.slab = v % nslab; v /= nslab;
   t.pc = v % ny;
   t.n = v / ny;
+  // (integer division runs on the vector ALU: pin the wave-uniform results to scalar registers, so that the row pointers
+  // built from them are scalar and the requests can use the scalar-base + 32-bit-offset address form)
+  t.xs = __builtin_amdgcn_readfirstlane(t.xs);
+  t.slab = __builtin_amdgcn_readfirstlane(t.slab);
+  t.pc = __builtin_amdgcn_readfirstlane(t.pc);
+  t.n = __builtin_amdgcn_readfirstlane(t.n);
   return true;
 }
 
 // ======================================================================================
 // march forward: 1-D grid over (x segment, channel slab, row phase/chunk, image), block 256
 // ======================================================================================
-__global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x, const float *__restrict__ sc,
+__global__ __launch_bounds__(256, 3) void dw_march_fwd(const float *__restrict__ x, const float *__restrict__ sc,
                                                     const float *__restrict__ sh, int act,
                                                     const float *__restrict__ w, float *__restrict__ y,
                                                     int H, int W, int C, int r, int nchunk, int TK, int nxseg,
@@ -113,10 +129,10 @@ __global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x,
   // a workgroup owns `ppb` consecutive row phases (large rates leave only 2-3 rows per phase: several phases per
   // workgroup amortise the prologue) or, for ppb == 1, one chunk of TK rows of one phase
   for (int pi = 0; pi < ppb; ++pi) {
-  const int a = (ppb > 1) ? pc * ppb + pi : pc / nchunk;
-  const int ch = (ppb > 1) ? 0 : pc % nchunk;
+  const int a = __builtin_amdgcn_readfirstlane((ppb > 1) ? pc * ppb + pi : pc / nchunk);
+  const int ch = __builtin_amdgcn_readfirstlane((ppb > 1) ? 0 : pc % nchunk);
   if (a >= nphase) break;
-  const int Ka = (a < H) ? (H - a + r - 1) / r : 0;
+  const int Ka = __builtin_amdgcn_readfirstlane((a < H) ? (H - a + r - 1) / r : 0);
   const int k0 = ch * TK;
   const int k1 = min(k0 + TK, Ka);
   const int Kc = max(Ka - 1, 0);
@@ -124,15 +140,18 @@ __global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x,
   // clamped coordinates: every lane always issues in-bounds loads (no branches -> the loads of a row group are
   // all in flight together); out-of-image taps and idle lanes are zeroed by a select afterwards
   const int cc = min(c, C - 4), xc = min(xx, W - 1), xlc = min(max(xx - r, 0), W - 1), xrc = min(xx + r, W - 1);
-  const float *xbase = x + ((size_t)n * H * W) * C + cc;
-  float *ybase = y + ((size_t)n * H * W) * C + c;
+  // addresses: a wave-uniform row pointer + one 32-bit byte offset per tap (shared by both bodies of the row loop below)
+  const float *xn = x + (size_t)n * H * W * C;
+  float *yn = y + (size_t)n * H * W * C;
+  const unsigned om = 4u * (unsigned)(xc * C + cc), ol = 4u * (unsigned)(xlc * C + cc), orr = 4u * (unsigned)(xrc * C + cc);
+  const unsigned oo = 4u * (unsigned)(xx * C + c);   // own position (stores; == om in an all-active workgroup)
 
   auto ldrow = [&](int k, f32x4 &l, f32x4 &m, f32x4 &rr) {
     const bool rok = active && k >= 0 && k < Ka;
-    const float *row = xbase + (size_t)(a + min(max(k, 0), Kc) * r) * W * C;
-    const f32x4 vm = dl3_act4(s * ld4(row + (size_t)xc * C) + t, act);
-    const f32x4 vl = dl3_act4(s * ld4(row + (size_t)xlc * C) + t, act);
-    const f32x4 vr = dl3_act4(s * ld4(row + (size_t)xrc * C) + t, act);
+    const float *row = xn + (size_t)(a + min(max(k, 0), Kc) * r) * W * C;
+    const f32x4 vm = dl3_act4(s * ld4_su(row, om) + t, act);
+    const f32x4 vl = dl3_act4(s * ld4_su(row, ol) + t, act);
+    const f32x4 vr = dl3_act4(s * ld4_su(row, orr) + t, act);
     // multiply by 0/1 instead of selecting: a select lets the compiler sink the loads into a branch again
     m = vm * splat4(rok ? 1.f : 0.f);
     l = vl * splat4((rok && xl_ok) ? 1.f : 0.f);
@@ -147,34 +166,72 @@ __global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x,
   // outside the phase is an all-zero row: skipped, the last output row is flushed after the loop instead)
   const bool bot_halo = k1 < Ka;
   const int ks = (k0 > 0) ? k0 - 1 : k0, ke = bot_halo ? k1 : k1 - 1;
-  for (int kg = ks; kg <= ke && k0 < k1; kg += R) {
+  // Round 5: INTERIOR groups of a workgroup whose lanes are all inside the tensor take a straight-line body: every row
+  // of the group is a live row whose output row belongs to the chunk, so its R stores are unconditional.  vmcnt retires
+  // in order and counts stores; around a store inside a branch the compiler cannot count, assumes it away and sizes the
+  // waits for the group's LAST loads as vmcnt(0) — which the hardware reads as "and every store issued so far": each group
+  // ended with the wave waiting for its own first three stores to be acknowledged.  With the stores counted that wait is
+  // vmcnt(3).  The first group (its first row only feeds the accumulators), the last one(s) and edge workgroups keep the
+  // predicated body.  Multiplying by a validity of 1.0 is exact: same values, same sums.
+  const bool allact = (slab * 32 + 32 <= C) && (xs * 32 + 32 <= W);
+  auto group = [&](int kg, auto fastc) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(fastc)::value;
     f32x4 l[R], m[R], rr[R];
 #pragma unroll
-    for (int j = 0; j < R; j++) ldrow((kg + j <= ke) ? kg + j : -1, l[j], m[j], rr[j]);
+    for (int j = 0; j < R; j++) {
+      if constexpr (FAST) {
+        // (wave-uniform row pointer + a 32-bit lane offset: one address register per tap instead of a 64-bit pair per request)
+        const float *row = xn + (size_t)(a + (kg + j) * r) * W * C;
+        m[j] = dl3_act4(s * ld4_su(row, om) + t, act);
+        l[j] = dl3_act4(s * ld4_su(row, ol) + t, act) * splat4(xl_ok ? 1.f : 0.f);
+        rr[j] = dl3_act4(s * ld4_su(row, orr) + t, act) * splat4(xr_ok ? 1.f : 0.f);
+      } else {
+        ldrow((kg + j <= ke) ? kg + j : -1, l[j], m[j], rr[j]);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < R; j++) {
       const int k = kg + j;
       // (no `if (k > ke) break;` here: a path that leaves the group early leaves the group's remaining requests
       // un-waited-for, the compiler then has to wait for EVERYTHING at the head of the row loop before it may reuse their
-      // registers — vmcnt(0) in front of the next group's requests, i.e. every wave drained its own stores each group
-      // and only then asked for the next rows.  Rows beyond ke are all-zero slots: predicated instead.  Round 5.)
-      const bool kv = k <= ke;
+      // registers.  Rows beyond ke are all-zero slots: predicated instead.  Round 5.)
+      const bool kv = FAST || k <= ke;
       // input row k feeds out[k+1] (tap row 0), out[k] (tap row 1), out[k-1] (tap row 2)
       f32x4 h0 = wv[0] * l[j] + wv[1] * m[j] + wv[2] * rr[j];
       f32x4 h1 = wv[3] * l[j] + wv[4] * m[j] + wv[5] * rr[j];
       f32x4 h2 = wv[6] * l[j] + wv[7] * m[j] + wv[8] * rr[j];
       f32x4 out = accA + h2;
-      if (active && kv && k - 1 >= k0 && k - 1 < k1) {
-        st4_nt(ybase + ((size_t)(a + (k - 1) * r) * W + xx) * C, out);
+      if constexpr (FAST) {
+        st4_nt_su(yn + (size_t)(a + (k - 1) * r) * W * C, oo, out);
         s1 += out;
         s2 += out * out;
+        accA = accB + h1;
+        accB = h0;
+      } else {
+        if (active && kv && k - 1 >= k0 && k - 1 < k1) {
+          st4_nt_su(yn + (size_t)(a + (k - 1) * r) * W * C, oo, out);
+          s1 += out;
+          s2 += out * out;
+        }
+        accA = kv ? accB + h1 : accA;
+        accB = kv ? h0 : accB;
       }
-      accA = kv ? accB + h1 : accA;
-      accB = kv ? h0 : accB;
     }
+  };
+  if (k0 < k1) {
+    int kg = ks;
+    group(kg, std::false_type{});
+    kg += R;
+    if (allact) {
+      // (enter the straight-line loop with nothing outstanding: a request of the predicated group still pending at the loop
+      // head is merged into every iteration's state and comes back as a vmcnt(0) in front of each group's requests)
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      for (; kg + R - 1 <= ke; kg += R) group(kg, std::true_type{});
+    }
+    for (; kg <= ke; kg += R) group(kg, std::false_type{});
   }
   if (!bot_halo && k0 < k1 && active) {  // last row of the phase: no row below contributes
-    st4_nt(ybase + ((size_t)(a + (k1 - 1) * r) * W + xx) * C, accA);
+    st4_nt_su(yn + (size_t)(a + (k1 - 1) * r) * W * C, oo, accA);
     s1 += accA;
     s2 += accA * accA;
   }
@@ -199,7 +256,7 @@ __global__ __launch_bounds__(256) void dw_march_fwd(const float *__restrict__ x,
 // the side-tap loads of the one-pixel kernel cost 12 % (4.70 -> 5.26 TB/s with them removed).
 // Same grid decode / row-phase walk / partial layout as dw_march_fwd with 64-pixel segments.
 // ======================================================================================
-__global__ __launch_bounds__(256) void dw_march2_fwd(const float *__restrict__ x, const float *__restrict__ sc,
+__global__ __launch_bounds__(256, 3) void dw_march2_fwd(const float *__restrict__ x, const float *__restrict__ sc,
                                                      const float *__restrict__ sh, int act,
                                                      const float *__restrict__ w, float *__restrict__ y,
                                                      int H, int W, int C, int r, int nchunk, int TK, int nxseg,
@@ -225,36 +282,53 @@ __global__ __launch_bounds__(256) void dw_march2_fwd(const float *__restrict__ x
   const int x0c = min(max(xa - r, 0), W - 1), x1c = min(xa, W - 1), x2c = min(xb, W - 1), x3c = min(xb + r, W - 1);
   const float v0 = (ca && xa - r >= 0 && xa - r < W) ? 1.f : 0.f, v1 = act_a ? 1.f : 0.f, v2 = act_b ? 1.f : 0.f,
               v3 = (ca && xb + r < W) ? 1.f : 0.f;
-  const float *xbase = x + ((size_t)n * H * W) * C + cc;
-  float *ybase = y + ((size_t)n * H * W) * C + c;
+  // addresses: a wave-uniform row pointer + one 32-bit byte offset per column position
+  const float *xn = x + (size_t)n * H * W * C;
+  float *yn = y + (size_t)n * H * W * C;
+  const unsigned o0 = 4u * (unsigned)(x0c * C + cc), o1 = 4u * (unsigned)(x1c * C + cc), o2 = 4u * (unsigned)(x2c * C + cc),
+                 o3 = 4u * (unsigned)(x3c * C + cc);
+  const unsigned osa = 4u * (unsigned)(xa * C + c), osb = 4u * (unsigned)(xb * C + c);  // own positions (stores)
   for (int pi = 0; pi < ppb; ++pi) {
-    const int a = (ppb > 1) ? pc * ppb + pi : pc / nchunk;
-    const int ch = (ppb > 1) ? 0 : pc % nchunk;
+    const int a = __builtin_amdgcn_readfirstlane((ppb > 1) ? pc * ppb + pi : pc / nchunk);
+    const int ch = __builtin_amdgcn_readfirstlane((ppb > 1) ? 0 : pc % nchunk);
     if (a >= nphase) break;
-    const int Ka = (a < H) ? (H - a + r - 1) / r : 0;
+    const int Ka = __builtin_amdgcn_readfirstlane((a < H) ? (H - a + r - 1) / r : 0);
     const int k0 = ch * TK;
     const int k1 = min(k0 + TK, Ka);
     const int Kc = max(Ka - 1, 0);
     auto ldrow = [&](int k, f32x4 (&p)[4]) {
       const float rok = (k >= 0 && k < Ka) ? 1.f : 0.f;
-      const float *row = xbase + (size_t)(a + min(max(k, 0), Kc) * r) * W * C;
-      p[0] = dl3_act4(s * ld4(row + (size_t)x0c * C) + t, act) * splat4(rok * v0);
-      p[1] = dl3_act4(s * ld4(row + (size_t)x1c * C) + t, act) * splat4(rok * v1);
-      p[2] = dl3_act4(s * ld4(row + (size_t)x2c * C) + t, act) * splat4(rok * v2);
-      p[3] = dl3_act4(s * ld4(row + (size_t)x3c * C) + t, act) * splat4(rok * v3);
+      const float *row = xn + (size_t)(a + min(max(k, 0), Kc) * r) * W * C;
+      p[0] = dl3_act4(s * ld4_su(row, o0) + t, act) * splat4(rok * v0);
+      p[1] = dl3_act4(s * ld4_su(row, o1) + t, act) * splat4(rok * v1);
+      p[2] = dl3_act4(s * ld4_su(row, o2) + t, act) * splat4(rok * v2);
+      p[3] = dl3_act4(s * ld4_su(row, o3) + t, act) * splat4(rok * v3);
     };
     f32x4 aA = splat4(0.f), aB = splat4(0.f), bA = splat4(0.f), bB = splat4(0.f);
     constexpr int R = 3;
     const bool bot_halo = k1 < Ka;
     const int ks = (k0 > 0) ? k0 - 1 : k0, ke = bot_halo ? k1 : k1 - 1;
-    for (int kg = ks; kg <= ke && k0 < k1; kg += R) {
+    // (interior groups of all-active workgroups: straight-line body with counted stores, see dw_march_fwd)
+    const bool allact = (slab * 32 + 32 <= C) && (xs * 64 + 64 <= W);
+    auto group = [&](int kg, auto fastc) __attribute__((always_inline)) {
+      constexpr bool FAST = decltype(fastc)::value;
       f32x4 p[R][4];
 #pragma unroll
-      for (int j = 0; j < R; j++) ldrow((kg + j <= ke) ? kg + j : -1, p[j]);
+      for (int j = 0; j < R; j++) {
+        if constexpr (FAST) {
+          const float *row = xn + (size_t)(a + (kg + j) * r) * W * C;   // wave-uniform + 32-bit lane offsets
+          p[j][0] = dl3_act4(s * ld4_su(row, o0) + t, act) * splat4(v0);
+          p[j][1] = dl3_act4(s * ld4_su(row, o1) + t, act) * splat4(v1);
+          p[j][2] = dl3_act4(s * ld4_su(row, o2) + t, act) * splat4(v2);
+          p[j][3] = dl3_act4(s * ld4_su(row, o3) + t, act) * splat4(v3);
+        } else {
+          ldrow((kg + j <= ke) ? kg + j : -1, p[j]);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < R; j++) {
         const int k = kg + j;
-        const bool kv = k <= ke;   // (predicated, not `break`: see dw_march_fwd)
+        const bool kv = FAST || k <= ke;   // (predicated, not `break`: see dw_march_fwd)
         // pixel a: taps (p0, p1, p2); pixel b: taps (p1, p2, p3)
         const f32x4 a0 = wv[0] * p[j][0] + wv[1] * p[j][1] + wv[2] * p[j][2];
         const f32x4 a1 = wv[3] * p[j][0] + wv[4] * p[j][1] + wv[5] * p[j][2];
@@ -263,19 +337,37 @@ __global__ __launch_bounds__(256) void dw_march2_fwd(const float *__restrict__ x
         const f32x4 b1 = wv[3] * p[j][1] + wv[4] * p[j][2] + wv[5] * p[j][3];
         const f32x4 b2 = wv[6] * p[j][1] + wv[7] * p[j][2] + wv[8] * p[j][3];
         const f32x4 oa = aA + a2, ob = bA + b2;
-        if (kv && k - 1 >= k0 && k - 1 < k1) {
-          float *orow = ybase + (size_t)(a + (k - 1) * r) * W * C;
-          if (act_a) { st4_nt(orow + (size_t)xa * C, oa); s1 += oa; s2 += oa * oa; }
-          if (act_b) { st4_nt(orow + (size_t)xb * C, ob); s1 += ob; s2 += ob * ob; }
+        if constexpr (FAST) {
+          float *orow = yn + (size_t)(a + (k - 1) * r) * W * C;
+          st4_nt_su(orow, osa, oa); s1 += oa; s2 += oa * oa;
+          st4_nt_su(orow, osb, ob); s1 += ob; s2 += ob * ob;
+          aA = aB + a1; aB = a0;
+          bA = bB + b1; bB = b0;
+        } else {
+          if (kv && k - 1 >= k0 && k - 1 < k1) {
+            float *orow = yn + (size_t)(a + (k - 1) * r) * W * C;
+            if (act_a) { st4_nt_su(orow, osa, oa); s1 += oa; s2 += oa * oa; }
+            if (act_b) { st4_nt_su(orow, osb, ob); s1 += ob; s2 += ob * ob; }
+          }
+          aA = kv ? aB + a1 : aA; aB = kv ? a0 : aB;
+          bA = kv ? bB + b1 : bA; bB = kv ? b0 : bB;
         }
-        aA = kv ? aB + a1 : aA; aB = kv ? a0 : aB;
-        bA = kv ? bB + b1 : bA; bB = kv ? b0 : bB;
       }
+    };
+    if (k0 < k1) {
+      int kg = ks;
+      group(kg, std::false_type{});
+      kg += R;
+      if (allact) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // (see dw_march_fwd)
+        for (; kg + R - 1 <= ke; kg += R) group(kg, std::true_type{});
+      }
+      for (; kg <= ke; kg += R) group(kg, std::false_type{});
     }
     if (!bot_halo && k0 < k1) {  // last row of the phase: no row below contributes
-      float *orow = ybase + (size_t)(a + (k1 - 1) * r) * W * C;
-      if (act_a) { st4_nt(orow + (size_t)xa * C, aA); s1 += aA; s2 += aA * aA; }
-      if (act_b) { st4_nt(orow + (size_t)xb * C, bA); s1 += bA; s2 += bA * bA; }
+      float *orow = yn + (size_t)(a + (k1 - 1) * r) * W * C;
+      if (act_a) { st4_nt_su(orow, osa, aA); s1 += aA; s2 += aA * aA; }
+      if (act_b) { st4_nt_su(orow, osb, bA); s1 += bA; s2 += bA * bA; }
     }
   }
   if (part) {
@@ -293,7 +385,9 @@ __global__ __launch_bounds__(256) void dw_march2_fwd(const float *__restrict__ x
 // ======================================================================================
 // march backward (fused bwd-data + bwd-weight): same decomposition as the forward
 // ======================================================================================
-__global__ __launch_bounds__(256) void dw_march_bwd(
+// SXK / ADDK: the optional operands (sx: sums against another tensor; dx_add: residual addend) are known at compile time
+template <bool SXK, bool ADDK>
+__global__ __launch_bounds__(256, 2) void dw_march_bwd(
     const float *__restrict__ g, const float *__restrict__ yraw, const float *__restrict__ cA,
     const float *__restrict__ cB, const float *__restrict__ cC, const float *__restrict__ x,
     const float *__restrict__ sc, const float *__restrict__ sh, int act, const float *__restrict__ w,
@@ -326,28 +420,32 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
   const bool two = (cA != nullptr);
   const bool xl_ok = (xx - r >= 0), xr_ok = (xx + r < W);
   const int cc = min(c, C - 4), xc = min(xx, W - 1), xlc = min(max(xx - r, 0), W - 1), xrc = min(xx + r, W - 1);
-  const size_t img = ((size_t)n * H * W) * C + c;    // own position (stores)
-  const size_t imgc = ((size_t)n * H * W) * C + cc;  // clamped (loads)
+  // addresses: wave-uniform row pointers + one 32-bit byte offset per tap (shared by both bodies of the row loop)
+  const size_t nimg = (size_t)n * H * W * C;
+  const unsigned om = 4u * (unsigned)(xc * C + cc), ol = 4u * (unsigned)(xlc * C + cc), orr = 4u * (unsigned)(xrc * C + cc);
+  const unsigned oo = 4u * (unsigned)(xx * C + c);   // own position (stores; == om in an all-active workgroup)
+  const bool allact = (slab * 32 + 32 <= C) && (xs * 32 + 32 <= W);
   f32x4 dwv[9];
 #pragma unroll
   for (int i = 0; i < 9; i++) dwv[i] = splat4(0.f);
   f32x4 s1 = splat4(0.f), s2 = splat4(0.f);
   for (int pi = 0; pi < ppb; ++pi) {  // row phases owned by this workgroup (see dw_march_fwd)
-  const int a = (ppb > 1) ? pc * ppb + pi : pc / nchunk;
-  const int ch = (ppb > 1) ? 0 : pc % nchunk;
+  const int a = __builtin_amdgcn_readfirstlane((ppb > 1) ? pc * ppb + pi : pc / nchunk);
+  const int ch = __builtin_amdgcn_readfirstlane((ppb > 1) ? 0 : pc % nchunk);
   if (a >= nphase) break;
-  const int Ka = (a < H) ? (H - a + r - 1) / r : 0;
+  const int Ka = __builtin_amdgcn_readfirstlane((a < H) ? (H - a + r - 1) / r : 0);
   const int k0 = ch * TK;
   const int k1 = min(k0 + TK, Ka);
   const int Kc = max(Ka - 1, 0);
   const float *yr = two ? yraw : g;  // when dY = g the second stream aliases the first (coefficient 0)
+  // element offset of row slot k of this phase inside the image (k clamped into the phase: always in bounds)
+  auto rowoff = [&](int k) -> size_t { return nimg + (size_t)(a + min(max(k, 0), Kc) * r) * W * C; };
 
-  auto ld_dd1 = [&](size_t off) -> f32x4 { return kA * ld4(g + off) + kB * ld4(yr + off) + kC; };
+  auto ld_dd1 = [&](size_t row, unsigned off) -> f32x4 { return kA * ld4_su(g + row, off) + kB * ld4_su(yr + row, off) + kC; };
   auto ld_dd = [&](int k, f32x4 &l, f32x4 &m, f32x4 &rr) {
     const bool rok = active && k >= 0 && k < Ka;
-    const size_t row = imgc + (size_t)(a + min(max(k, 0), Kc) * r) * W * C;
-    const f32x4 vm = ld_dd1(row + (size_t)xc * C), vl = ld_dd1(row + (size_t)xlc * C),
-                vr = ld_dd1(row + (size_t)xrc * C);
+    const size_t row = rowoff(k);
+    const f32x4 vm = ld_dd1(row, om), vl = ld_dd1(row, ol), vr = ld_dd1(row, orr);
     m = vm * splat4(rok ? 1.f : 0.f);
     l = vl * splat4((rok && xl_ok) ? 1.f : 0.f);
     rr = vr * splat4((rok && xr_ok) ? 1.f : 0.f);
@@ -355,7 +453,7 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
   // forward input row k at own column: raw value and validity
   auto ld_e = [&](int k, f32x4 &raw, bool &ok) {
     ok = active && k >= 0 && k < Ka;
-    raw = ld4(x + imgc + ((size_t)(a + min(max(k, 0), Kc) * r) * W + xc) * C);
+    raw = ld4_su(x + rowoff(k), om);
   };
   auto eact = [&](f32x4 raw, bool ok) -> f32x4 {
     const f32x4 v = dl3_act4(s * raw + t, act);
@@ -375,25 +473,41 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
     const int ks = (k0 > 0) ? k0 - 1 : k0, ke = bot_halo ? k1 : k1 - 1;
     ld_e(ks, e_cur, ok_cur);
     ld_e(ks + 1, e_next, ok_next);
-    for (int kg = ks; kg <= ke; kg += R) {
+    // FAST (round 5, see dw_march_fwd): an interior group of an all-active workgroup — both dY rows live, both dx rows
+    // inside the chunk, the forward-input rows kg-1 .. kg+R+1 inside the phase — with the optional operands known at
+    // compile time (SX: sums against another tensor, ADD: residual addend): no branch around a request or a store, so
+    // the stores are counted and the group's last operands are waited for with vmcnt(1), not vmcnt(0).
+    auto group = [&](int kg, auto fastc) __attribute__((always_inline)) {
+      constexpr bool FAST = decltype(fastc)::value, SXC = SXK, ADDC = ADDK;
       f32x4 l[R], m[R], rr[R], e_new[R], sxv[R], addv[R];
       bool ok_new[R];
 #pragma unroll
       for (int j = 0; j < R; j++) {
-        ld_dd((kg + j <= ke) ? kg + j : -1, l[j], m[j], rr[j]);
-        ld_e(kg + j + 2, e_new[j], ok_new[j]);
-        // slot j of the group finishes dx row kg + j - 1: its x_hat operand and its residual addend (own column, clamped
-        // row: always in bounds) travel with the group's requests — a load inside the predicated store block below is
-        // waited for with vmcnt(0), which the in-order counter turns into "everything this wave has in flight" (round 5)
-        const size_t orow = imgc + ((size_t)(a + min(max(kg + j - 1, 0), Kc) * r) * W + xc) * C;
-        if (sx) sxv[j] = ld4(sx + orow);
-        if (dx_add) addv[j] = ld4(dx_add + orow);
+        if constexpr (FAST) {
+          const size_t row = nimg + (size_t)(a + (kg + j) * r) * W * C;
+          m[j] = ld_dd1(row, om);
+          l[j] = ld_dd1(row, ol) * splat4(xl_ok ? 1.f : 0.f);
+          rr[j] = ld_dd1(row, orr) * splat4(xr_ok ? 1.f : 0.f);
+          ld_e(kg + j + 2, e_new[j], ok_new[j]);   // (row kg+j+2 may be the slot below the phase: clamped + flagged as ever)
+          const size_t orow = nimg + (size_t)(a + (kg + j - 1) * r) * W * C;
+          if constexpr (SXC) sxv[j] = ld4_su(sx + orow, om);
+          if constexpr (ADDC) addv[j] = ld4_su(dx_add + orow, om);
+        } else {
+          ld_dd((kg + j <= ke) ? kg + j : -1, l[j], m[j], rr[j]);
+          ld_e(kg + j + 2, e_new[j], ok_new[j]);
+          // slot j of the group finishes dx row kg + j - 1: its x_hat operand and its residual addend (own column, clamped
+          // row: always in bounds) travel with the group's requests — a load inside the predicated store block below is
+          // waited for with vmcnt(0), which the in-order counter turns into "everything this wave has in flight" (round 5)
+          const size_t orow = rowoff(kg + j - 1);
+          if constexpr (SXC) sxv[j] = ld4_su(sx + orow, om);
+          if constexpr (ADDC) addv[j] = ld4_su(dx_add + orow, om);
+        }
       }
 #pragma unroll
       for (int j = 0; j < R; j++) {
         const int k = kg + j;
-        const bool kv = k <= ke;   // (predicated, not `break`: see dw_march_fwd)
-        if (k >= k0 && k < k1) {
+        const bool kv = FAST || k <= ke;   // (predicated, not `break`: see dw_march_fwd)
+        if (FAST || (k >= k0 && k < k1)) {
           // dW[i][j] += T(x)[k+i-1][x] * dY[k][x-(j-1)r] : j=0 -> right tap, j=2 -> left tap
           f32x4 ea0 = eact(e_prev, ok_prev), ea1 = eact(e_cur, ok_cur), ea2 = eact(e_next, ok_next);
           dwv[0] += ea0 * rr[j]; dwv[1] += ea0 * m[j]; dwv[2] += ea0 * l[j];
@@ -405,28 +519,49 @@ __global__ __launch_bounds__(256) void dw_march_bwd(
         f32x4 h1 = wv[3] * rr[j] + wv[4] * m[j] + wv[5] * l[j];
         f32x4 h2 = wv[6] * rr[j] + wv[7] * m[j] + wv[8] * l[j];
         f32x4 out = accA + h0;
-        if (dx && active && kv && k - 1 >= k0 && k - 1 < k1) {
-          const size_t off = img + ((size_t)(a + (k - 1) * r) * W + xx) * C;
+        if constexpr (FAST) {
           out = out * dl3_mask4(s * e_prev + t, act);
-          if (dx_add) out += addv[j];
-          st4_nt(dx + off, out);
+          if constexpr (ADDC) out += addv[j];
+          st4_nt_su(dx + nimg + (size_t)(a + (k - 1) * r) * W * C, oo, out);
           s1 += out;
-          s2 += out * (((sx ? sxv[j] : e_prev) - mu) * is);
+          s2 += out * (((SXC ? sxv[j] : e_prev) - mu) * is);
+          accA = accB + h1;
+          accB = h2;
+          e_prev = e_cur; ok_prev = ok_cur;
+          e_cur = e_next; ok_cur = ok_next;
+          e_next = e_new[j]; ok_next = ok_new[j];
+        } else {
+          if (dx && active && kv && k - 1 >= k0 && k - 1 < k1) {
+            out = out * dl3_mask4(s * e_prev + t, act);
+            if constexpr (ADDC) out += addv[j];
+            st4_nt_su(dx + nimg + (size_t)(a + (k - 1) * r) * W * C, oo, out);
+            s1 += out;
+            s2 += out * (((SXC ? sxv[j] : e_prev) - mu) * is);
+          }
+          accA = kv ? accB + h1 : accA;
+          accB = kv ? h2 : accB;
+          e_prev = kv ? e_cur : e_prev; ok_prev = kv ? ok_cur : ok_prev;
+          e_cur = kv ? e_next : e_cur; ok_cur = kv ? ok_next : ok_cur;
+          e_next = kv ? e_new[j] : e_next; ok_next = kv ? ok_new[j] : ok_next;
         }
-        accA = kv ? accB + h1 : accA;
-        accB = kv ? h2 : accB;
-        e_prev = kv ? e_cur : e_prev; ok_prev = kv ? ok_cur : ok_prev;
-        e_cur = kv ? e_next : e_cur; ok_cur = kv ? ok_next : ok_cur;
-        e_next = kv ? e_new[j] : e_next; ok_next = kv ? ok_new[j] : ok_next;
       }
+    };
+    int kg = ks;
+    group(kg, std::false_type{});
+    kg += R;
+    if (allact && dx) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // (enter the straight-line loop with nothing outstanding: see dw_march_fwd)
+      // (dY row k1 below the chunk — the bottom halo — only finishes dx row k1-1; its dW belongs to the next chunk: not here)
+      for (; kg + R - 1 < k1; kg += R) group(kg, std::true_type{});
     }
+    for (; kg <= ke; kg += R) group(kg, std::false_type{});
     if (!bot_halo && dx && active) {  // last dx row of the phase (e_prev now holds forward input row k1-1)
-      const size_t off = img + ((size_t)(a + (k1 - 1) * r) * W + xx) * C;
+      const size_t row = nimg + (size_t)(a + (k1 - 1) * r) * W * C;
       f32x4 out = accA * dl3_mask4(s * e_prev + t, act);
-      if (dx_add) out += ld4(dx_add + off);
-      st4_nt(dx + off, out);
+      if constexpr (ADDK) out += ld4_su(dx_add + row, oo);
+      st4_nt_su(dx + row, oo, out);
       s1 += out;
-      s2 += out * (((sx ? ld4(sx + off) : e_prev) - mu) * is);
+      s2 += out * (((SXK ? ld4_su(sx + row, oo) : e_prev) - mu) * is);
     }
   }
   }  // phases of this workgroup
@@ -880,9 +1015,13 @@ static int dwconv3x3_bwd_impl(const float *g, const float *yraw, const float *cA
   const int Pmax = dl3_dwconv3x3_partials(N, H, W, C, stride, rate, Ho, Wo, im);
   if (im == DL3_IMPL_MARCH) {
     dim3 grid(march_grid(p, N));
-    hipLaunchKernelGGL(dw_march_bwd, grid, dim3(256), 0, st, g, yraw, cA, cB, cC, x, in_scale, in_shift, in_act,
-                       w, dx, dx_add, x_mean, x_invstd, dstat_partial, dw_partial, H, W, C, rate, p.nchunk, p.TK,
-                       p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), Pmax, stat_x);
+#define DL3_DW_BWD(SX_, ADD_)                                                                                              \
+  hipLaunchKernelGGL((dw_march_bwd<SX_, ADD_>), grid, dim3(256), 0, st, g, yraw, cA, cB, cC, x, in_scale, in_shift, in_act, \
+                     w, dx, dx_add, x_mean, x_invstd, dstat_partial, dw_partial, H, W, C, rate, p.nchunk, p.TK, p.nxseg,    \
+                     p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), Pmax, stat_x)
+    if (stat_x) { if (dx_add) DL3_DW_BWD(true, true); else DL3_DW_BWD(true, false); }
+    else { if (dx_add) DL3_DW_BWD(false, true); else DL3_DW_BWD(false, false); }
+#undef DL3_DW_BWD
   } else {
     DwGeom G{N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo, Pmax};
     dim3 grid(p.nslab, p.PB);
