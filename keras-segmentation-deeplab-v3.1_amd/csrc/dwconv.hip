@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, 3) void dw_march_fwd(const float *__restrict__
                                                     const float *__restrict__ w, float *__restrict__ y,
                                                     int H, int W, int C, int r, int nchunk, int TK, int nxseg,
                                                     int nphase, int ppb, int nslab, int ny, int N, int xcd,
-                                                    float *__restrict__ part, int prows) {
+                                                    float *__restrict__ part, int prows, int fast) {
   __shared__ float red[4 * 8 * 8];
   const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
   DwTile tile;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, 3) void dw_march_fwd(const float *__restrict__
   // ended with the wave waiting for its own first three stores to be acknowledged.  With the stores counted that wait is
   // vmcnt(3).  The first group (its first row only feeds the accumulators), the last one(s) and edge workgroups keep the
   // predicated body.  Multiplying by a validity of 1.0 is exact: same values, same sums.
-  const bool allact = (slab * 32 + 32 <= C) && (xs * 32 + 32 <= W);
+  const bool allact = fast && (slab * 32 + 32 <= C) && (xs * 32 + 32 <= W);
   auto group = [&](int kg, auto fastc) __attribute__((always_inline)) {
     constexpr bool FAST = decltype(fastc)::value;
     f32x4 l[R], m[R], rr[R];
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, 3) void dw_march2_fwd(const float *__restrict_
                                                      const float *__restrict__ w, float *__restrict__ y,
                                                      int H, int W, int C, int r, int nchunk, int TK, int nxseg,
                                                      int nphase, int ppb, int nslab, int ny, int N, int xcd,
-                                                     float *__restrict__ part, int prows) {
+                                                     float *__restrict__ part, int prows, int fast) {
   __shared__ float red[4 * 8 * 8];
   const int tid = threadIdx.x, cq = tid & 7, pl = tid >> 3;
   DwTile tile;
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256, 3) void dw_march2_fwd(const float *__restrict_
     const bool bot_halo = k1 < Ka;
     const int ks = (k0 > 0) ? k0 - 1 : k0, ke = bot_halo ? k1 : k1 - 1;
     // (interior groups of all-active workgroups: straight-line body with counted stores, see dw_march_fwd)
-    const bool allact = (slab * 32 + 32 <= C) && (xs * 64 + 64 <= W);
+    const bool allact = fast && (slab * 32 + 32 <= C) && (xs * 64 + 64 <= W);
     auto group = [&](int kg, auto fastc) __attribute__((always_inline)) {
       constexpr bool FAST = decltype(fastc)::value;
       f32x4 p[R][4];
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void dw_march_bwd(
     float *__restrict__ dx, const float *__restrict__ dx_add, const float *__restrict__ xmean,
     const float *__restrict__ xinvstd, float *__restrict__ dpart, float *__restrict__ wpart, int H, int W, int C,
     int r, int nchunk, int TK, int nxseg, int nphase, int ppb, int nslab, int ny, int N, int xcd, int prows,
-    const float *__restrict__ sx) {
+    const float *__restrict__ sx, int fast) {
   // sx (nullable, round 4): the BatchNorm-backward sums of dx are taken against x_hat of THIS tensor instead of the
   // forward input — the other input of the residual Add whose output gradient this launch completes (Xception's `sum`
   // shortcuts: the gradient reaches the block's last pointwise BatchNorm unchanged, Engine.alias_stats_target)
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void dw_march_bwd(
   const size_t nimg = (size_t)n * H * W * C;
   const unsigned om = 4u * (unsigned)(xc * C + cc), ol = 4u * (unsigned)(xlc * C + cc), orr = 4u * (unsigned)(xrc * C + cc);
   const unsigned oo = 4u * (unsigned)(xx * C + c);   // own position (stores; == om in an all-active workgroup)
-  const bool allact = (slab * 32 + 32 <= C) && (xs * 32 + 32 <= W);
+  const bool allact = fast && (slab * 32 + 32 <= C) && (xs * 32 + 32 <= W);
   f32x4 dwv[9];
 #pragma unroll
   for (int i = 0; i < 9; i++) dwv[i] = splat4(0.f);
@@ -879,6 +879,11 @@ unsigned march_grid(const DwPlan &p, int N) {
   const long total = (long)p.nxseg * p.nslab * p.ny * N;
   return (unsigned)((total + 7) / 8 * 8);
 }
+int march_fast() {
+  // straight-line interior row groups (round 5): bit 0 one-pixel forward, bit 1 two-pixel forward, bit 2 backward
+  static const int v = [] { const char *e = getenv("DL3_DW_FAST"); return e ? atoi(e) : 7; }();
+  return v;
+}
 int march_xcd() {
   const char *e = getenv("DL3_DW_XCD");  // 0 = plain workgroup order (tuning aid)
   return e ? atoi(e) : 1;
@@ -979,10 +984,10 @@ extern "C" int dl3_dwconv3x3_fwd(const float *x, const float *in_scale, const fl
     dim3 grid(march_grid(p, N));
     if (p.two)
       hipLaunchKernelGGL(dw_march2_fwd, grid, dim3(256), 0, st, x, in_scale, in_shift, in_act, w, y, H, W, C, rate,
-                         p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial, Pmax);
+                         p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial, Pmax, march_fast() & 2);
     else
       hipLaunchKernelGGL(dw_march_fwd, grid, dim3(256), 0, st, x, in_scale, in_shift, in_act, w, y, H, W, C, rate,
-                         p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial, Pmax);
+                         p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial, Pmax, march_fast() & 1);
   } else {
     DwGeom G{N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo, Pmax};
     dim3 grid(p.nslab, p.PB);
@@ -1018,7 +1023,7 @@ static int dwconv3x3_bwd_impl(const float *g, const float *yraw, const float *cA
 #define DL3_DW_BWD(SX_, ADD_)                                                                                              \
   hipLaunchKernelGGL((dw_march_bwd<SX_, ADD_>), grid, dim3(256), 0, st, g, yraw, cA, cB, cC, x, in_scale, in_shift, in_act, \
                      w, dx, dx_add, x_mean, x_invstd, dstat_partial, dw_partial, H, W, C, rate, p.nchunk, p.TK, p.nxseg,    \
-                     p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), Pmax, stat_x)
+                     p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), Pmax, stat_x, march_fast() & 4)
     if (stat_x) { if (dx_add) DL3_DW_BWD(true, true); else DL3_DW_BWD(true, false); }
     else { if (dx_add) DL3_DW_BWD(false, true); else DL3_DW_BWD(false, false); }
 #undef DL3_DW_BWD
