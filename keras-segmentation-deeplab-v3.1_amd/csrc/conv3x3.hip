@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void conv3x3_stem_wgrad_kernel(
     const float *__restrict__ x, const float *__restrict__ sc, const float *__restrict__ sh, int act,
     const float *__restrict__ g, const float *__restrict__ yraw, const float *__restrict__ cA,
     const float *__restrict__ cB, const float *__restrict__ cC, float *__restrict__ wpart, CGeom G) {
-  constexpr int NJ = COUT / 32, U = 4;
+  constexpr int NJ = COUT / 32, U = 8;  // (round 5: 4 -> 8 pixel pairs in flight per wave — the loop only loads, it is latency-bound)
   __shared__ float red[4][32][COUT];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int T = 9 * G.Cin;
@@ -373,17 +373,19 @@ __global__ __launch_bounds__(256) void conv3x3_stem_wgrad_kernel(
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
 
-  const long NP = (long)G.N * G.Ho * G.Wo;
-  const long per = ((NP + gridDim.x - 1) / gridDim.x + 7) & ~7l;  // pixels per workgroup, multiple of 8
-  const long pbeg = (long)blockIdx.x * per, pend = min(NP, pbeg + per);
+  // (pixel arithmetic in 32 bits: the host checks N*Ho*Wo < 2^31)
+  const unsigned NP = (unsigned)((long)G.N * G.Ho * G.Wo), HoWo = (unsigned)G.Ho * (unsigned)G.Wo;
+  const unsigned per = ((NP + gridDim.x - 1) / gridDim.x + 7u) & ~7u;  // pixels per workgroup, multiple of 8
+  const unsigned pbeg = min(NP, blockIdx.x * per), pend = min(NP, pbeg + per);
   // wave w takes pixel pairs w, w+4, w+8, ... of the range; U pairs are in flight per iteration
-  for (long q = pbeg + 2 * wave; q < pend; q += 8 * U) {
+  for (unsigned q = pbeg + 2 * wave; q < pend; q += 8 * U) {
     float av[U], gv[U][NJ], yv[U][NJ], lv[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const long p = q + 8 * u + lhi;
-      const long pc = min(p, NP - 1);
-      const int ox = (int)(pc % G.Wo), oy = (int)((pc / G.Wo) % G.Ho), n = (int)(pc / ((long)G.Wo * G.Ho));
+      const unsigned p = q + 8 * u + lhi;
+      const unsigned pc = min(p, NP - 1u);
+      const unsigned n = pc / HoWo, rem = pc - n * HoWo;
+      const int oy = (int)(rem / (unsigned)G.Wo), ox = (int)(rem - (unsigned)oy * (unsigned)G.Wo);
       const int iy = oy * G.stride - G.pad_t + ti, ix = ox * G.stride - G.pad_l + tj;
       const int iyc = min(max(iy, 0), G.H - 1), ixc = min(max(ix, 0), G.W - 1);
       lv[u] = (p < pend && iy == iyc && ix == ixc) ? tlive : 0.f;
@@ -748,7 +750,7 @@ extern "C" int dl3_conv3x3_bwd_weight(const float *x, const float *in_scale, con
   DL3_CHECK_ARG(x && g && dw_partial, "conv3x3_bwd_weight: null pointer");
   DL3_CHECK_ARG(!cA || (yraw && cB && cC), "conv3x3_bwd_weight: cA needs yraw, cB, cC");
   DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "conv3x3_bwd_weight: scale/shift must come together");
-  if (9 * Cin <= 32 && Cout == 32) {
+  if (9 * Cin <= 32 && Cout == 32 && (long)N * Ho * Wo < (1L << 31) - 64 * 2048) {
     hipLaunchKernelGGL((conv3x3_stem_wgrad_kernel<32>), dim3(conv_blocks((long)N * Ho * Wo)), dim3(256), 0,
                        (hipStream_t)stream, x, in_scale, in_shift, in_act, g, yraw, cA, cB, cC, dw_partial, G);
   } else {

@@ -880,7 +880,11 @@ unsigned march_grid(const DwPlan &p, int N) {
   return (unsigned)((total + 7) / 8 * 8);
 }
 int march_fast() {
-  // straight-line interior row groups (round 5): bit 0 one-pixel forward, bit 1 two-pixel forward, bit 2 backward
+  // straight-line interior row groups (round 5): bit 0 one-pixel forward, bit 1 two-pixel forward, bit 2 backward.
+  // Taken where a pixel's channels are whole 128-byte lines (C % 32 == 0).  Measured at B=128 (GPU call 9, cold operands,
+  // same box; ms off -> on): backward 64x64x960 r4 1.674 -> 1.577, x576 r2 1.021 -> 0.932, x384 r2 0.802 -> 0.732, x192
+  // 0.329 -> 0.293, 256x256x32 0.926 -> 0.868, but 128x128x144 (576-byte pixels: every other 128-byte store straddles two
+  // lines) 1.356 -> 1.435; forward 256x256x32 0.467 -> 0.422, 128x128x144 0.569 -> 0.603, the 64x64 maps within noise.
   static const int v = [] { const char *e = getenv("DL3_DW_FAST"); return e ? atoi(e) : 7; }();
   return v;
 }
@@ -984,10 +988,10 @@ extern "C" int dl3_dwconv3x3_fwd(const float *x, const float *in_scale, const fl
     dim3 grid(march_grid(p, N));
     if (p.two)
       hipLaunchKernelGGL(dw_march2_fwd, grid, dim3(256), 0, st, x, in_scale, in_shift, in_act, w, y, H, W, C, rate,
-                         p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial, Pmax, march_fast() & 2);
+                         p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial, Pmax, (C % 32 == 0) ? (march_fast() & 2) : 0);
     else
       hipLaunchKernelGGL(dw_march_fwd, grid, dim3(256), 0, st, x, in_scale, in_shift, in_act, w, y, H, W, C, rate,
-                         p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial, Pmax, march_fast() & 1);
+                         p.nchunk, p.TK, p.nxseg, p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), stat_partial, Pmax, (C % 32 == 0) ? (march_fast() & 1) : 0);
   } else {
     DwGeom G{N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo, Pmax};
     dim3 grid(p.nslab, p.PB);
@@ -1023,7 +1027,7 @@ static int dwconv3x3_bwd_impl(const float *g, const float *yraw, const float *cA
 #define DL3_DW_BWD(SX_, ADD_)                                                                                              \
   hipLaunchKernelGGL((dw_march_bwd<SX_, ADD_>), grid, dim3(256), 0, st, g, yraw, cA, cB, cC, x, in_scale, in_shift, in_act, \
                      w, dx, dx_add, x_mean, x_invstd, dstat_partial, dw_partial, H, W, C, rate, p.nchunk, p.TK, p.nxseg,    \
-                     p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), Pmax, stat_x, march_fast() & 4)
+                     p.nphase, p.ppb, p.nslab, p.ny, N, march_xcd(), Pmax, stat_x, (C % 32 == 0) ? (march_fast() & 4) : 0)
     if (stat_x) { if (dx_add) DL3_DW_BWD(true, true); else DL3_DW_BWD(true, false); }
     else { if (dx_add) DL3_DW_BWD(false, true); else DL3_DW_BWD(false, false); }
 #undef DL3_DW_BWD
