@@ -36,6 +36,8 @@ def timed(fn, reps=6):
 # H, W, C, rate, residual addend in the backward
 CASES = [(64, 64, 960, 4, False), (64, 64, 576, 2, False), (64, 64, 384, 2, True), (64, 64, 192, 1, False), (128, 128, 144, 1, True),
          (256, 256, 32, 1, False)]
+if B <= 16:   # Xception OS=8 (cfg4): the one-pixel forward kernel (rates that do not divide 32) and a 736-wide middle-flow layer
+    CASES += [(64, 64, 2048, 12, False), (64, 64, 2048, 36, False), (64, 64, 736, 2, True)]
 for H, W, C, r, has_add in CASES:
     rn = lambda *s: torch.randn(*s, device="cuda")
     xs, ys, gs, dxs = [rn(B, H, W, C) for _ in range(2)], [torch.empty(B, H, W, C, device="cuda") for _ in range(2)], \
