@@ -566,8 +566,13 @@ def test_odd_and_non_square_inputs(shape):
     loss, grads, logits, _ = O.train_grads(p64, x.astype(np.float64), labels.astype(np.float64), sw.astype(np.float64), **kw)
     assert relerr(eng.logits(), logits) < 1e-3
     assert abs(float(eng.loss[0].item()) - loss) < 1e-4 * abs(loss)
+    # (a 9x7 / 7x7 ASPP map and a batch of two: 126 samples per BatchNorm channel, two for image_pooling_BN — the yardstick
+    # is the fp32 run of the ORACLE itself against its float64 run, as in the Xception case above)
+    _, grads32, _, _ = O.train_grads(params, x, labels, sw, **kw)
     for name in ("concat_projection/kernel:0", "custom_logits_semantic/kernel:0", "aspp0/kernel:0"):
-        assert _l2(eng.grad_of(name), grads[name]) < 5e-3, name
+        d, yard = _l2(eng.grad_of(name), grads[name]), _l2(grads32[name], grads[name])
+        print("   %-36s gradient rel-L2 gpu %.2e, numpy-fp32 oracle %.2e" % (name, d, yard))
+        assert d < max(5e-3, 4.0 * yard), (name, d, yard)
 
 
 def test_width_multiplier_alpha():
