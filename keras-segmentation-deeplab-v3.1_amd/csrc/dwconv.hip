@@ -17,7 +17,7 @@
 #include "common.h"
 
 // Contraction by the language rule only (a * b + c inside ONE expression becomes a fused multiply-add; nothing is fused
-// across statements): several kernels below carry two bodies of the same row loop (a predicated one and a straight-line
+// across statements): the march kernels below carry two bodies of the same row loop (a predicated one and a straight-line
 // one), and under the default -ffp-contract=fast the back end is free to fuse them differently — the two bodies of one
 // kernel then rounded the same pixel differently depending on which one a batch size's row chunking sent it through
 // (round 5: the B=16 and B=2 engines of tests/test_gpu_fullsize.py::test_benchmarked_plan_cfg4_b16 parted by 8e-5).
