@@ -183,7 +183,7 @@ def _pmc_traffic(family, args):
     WRITE_SIZE, separate runs, corrected as MI355X_MICROARCH.md prescribes; tools/collect_profiles.sh +
     tools/pmc_family.py).  It is a constant read from profiles/, not a measurement of this run — the line says so in
     `traffic_source` — and only reported for the configuration it was collected on, else (None, None)."""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         rel = os.path.join("profiles", "%s_%s_b%d_pmc.json" % (rnd, family, args.batch))
         pmc = os.path.join(ROOT, rel)
         if os.path.exists(pmc) and args.head == "deeplab" and args.size == 512:
@@ -211,8 +211,9 @@ def roofline_blocks(rows, args):
         tf = g["flops"] / g["ms"] / 1e9
         out["roofline"] = {
             "bound": "mfma", "kernel": "Conv2D 1x1 GEMM family on v_mfma_f32_32x32x2_f32: pw_gemm_stream_kernel (forward, "
-            "bwd-data) + pw_wgrad_kernel (bwd-weight) + pw_bwd_fused_kernel (both gradients of the HBM-bound early "
-            "layers in one pass), %d launches/step" % g["launches"],
+            "bwd-data) + pw_fwd_ws_kernel (forward of the HBM-bound early layers, weights resident in LDS) + pw_wgrad_kernel "
+            "(bwd-weight) + pw_bwd_fused2_kernel (both gradients of the HBM-bound early layers in one pass), "
+            "%d launches/step" % g["launches"],
             "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS,
             "traffic": _pmc_traffic("gemm", args)[0], "traffic_source": _pmc_traffic("gemm", args)[1],
             "avg_ms": g["ms"] / g["launches"], "family_ms_per_step": g["ms"], "algorithmic_flops_per_step": g["flops"],
