@@ -63,3 +63,23 @@ for H, W, C, r, has_add in CASES:
         B, H, W, C, r, has_add, tf, 2 * e / tf / 1e6, d_f, tb, (4 + (1 if has_add else 0)) * e / tb / 1e6, d_b))
     del xs, ys, gs, dxs, adds
     torch.cuda.empty_cache()
+
+# the stride-2 depthwise layers (dw_gather_fwd / dw_s2_bwd)
+S2CASES = [(256, 256, 96), (128, 128, 144), (64, 64, 192)]
+for H, W, C in S2CASES:
+    Ho, Wo = H // 2, W // 2
+    rn = lambda *s: torch.randn(*s, device="cuda")
+    xs, ys = [rn(B, H, W, C) for _ in range(2)], [torch.empty(B, Ho, Wo, C, device="cuda") for _ in range(2)]
+    w = rn(9, C) * 0.3
+    v0, v1 = torch.rand(C, device="cuda") + 0.5, rn(C)
+    P = L.dl3_dwconv3x3_partials(B, H, W, C, 2, 1, Ho, Wo, 0)
+    part = torch.empty(P, C, 2, device="cuda")
+    fwd = lambda i: capi.call("dl3_dwconv3x3_fwd", ptr(xs[i]), ptr(v0), ptr(v1), 2, ptr(w), ptr(ys[i]), B, H, W, C, 2, 1, 0, 0, Ho, Wo,
+                              ptr(part), 0, ST())
+    fwd(0)
+    d_f = md5(ys[0]) + " " + md5(part)
+    tf = timed(fwd)
+    e = 4.0 * B * C * (H * W + Ho * Wo)
+    print("dw-s2 %dx%dx%dx%d fwd %.3f ms %4.0f GB/s [%s]" % (B, H, W, C, tf, e / tf / 1e6, d_f))
+    del xs, ys
+    torch.cuda.empty_cache()
