@@ -81,9 +81,12 @@ constexpr int BK = 16;
 // K-tile), MFMA operand fragments prefetched one k-step ahead.  Out-of-range rows / columns are handled by
 // clamping the ADDRESS (always in bounds, so loads are unconditional and branch-free) and zeroing the VALUE
 // when it is written to LDS.
-template <int TM, int TN, int WM, int WN, bool VEC>
+// VEC: 1 = 16-byte loads on both operands, 0 = scalar loads on both, 2 (round 5) = 16-byte loads on the activation operand
+// only — the logits layer (K = 256, N = classes = 21): the big operand is the aligned one
+template <int TM, int TN, int WM, int WN, int VEC>
 __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmArgs P) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr bool AVEC = VEC != 0, BVEC = VEC == 1;
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr int LDA = BM + 2;  // 4*LDA == 8 (mod 32): transposed 4-float stores hit distinct banks
   constexpr int LDB = BN + 4;
@@ -125,22 +128,13 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmArgs P) {
 
     auto load_tiles = [&](int kt) {
       const int k = kt * BK + akq * 4;
-      if (VEC) {
+      if (AVEC) {
         const int kc = min(k, P.K - 4);
 #pragma unroll
         for (int i = 0; i < NA; i++) {
           const int row = min(m0 + amr + 64 * i, P.M - 1);
           ra[i] = ld4(P.a + (size_t)row * P.lda + kc);
           if (two) ra2[i] = ld4(P.a2 + (size_t)row * P.lda2 + kc);
-        }
-#pragma unroll
-        for (int i = 0; i < NB; i++) {
-          const int idx = tid + 256 * i;
-          if (NB * 256 == 4 * BN || idx < 4 * BN) {
-            const int kk = idx / (BN / 4), nq = idx % (BN / 4);
-            const int krow = min(kt * BK + kk, P.K - 1), col = min(n0 + nq * 4, P.N - 4);
-            rb[i] = ld4(P.b + (size_t)krow * P.ldb + col);
-          }
         }
       } else {
 #pragma unroll
@@ -153,6 +147,18 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmArgs P) {
             if (two) ra2[i][j] = P.a2[(size_t)row * P.lda2 + kc];
           }
         }
+      }
+      if (BVEC) {
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+          const int idx = tid + 256 * i;
+          if (NB * 256 == 4 * BN || idx < 4 * BN) {
+            const int kk = idx / (BN / 4), nq = idx % (BN / 4);
+            const int krow = min(kt * BK + kk, P.K - 1), col = min(n0 + nq * 4, P.N - 4);
+            rb[i] = ld4(P.b + (size_t)krow * P.ldb + col);
+          }
+        }
+      } else {
 #pragma unroll
         for (int i = 0; i < NB; i++) {
           const int idx = tid + 256 * i;
@@ -956,8 +962,10 @@ struct WgradArgs {
 #endif
 };
 
-template <int TA, int TB, int WA, int WB, bool VEC, bool SPL = false>
+// VEC: 1 = 16-byte loads of x and of g / y, 0 = scalar loads of both, 2 (round 5) = 16-byte loads of x only (N = classes)
+template <int TA, int TB, int WA, int WB, int VEC, bool SPL = false>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
+  constexpr bool XVEC = VEC != 0, DVEC = VEC == 1;
   static_assert(WA * WB == 4, "4 waves per workgroup");
   // SPL: split math (see split3).  The reduction index is the pixel row, and a bf16 MFMA wants 8 CONSECUTIVE reduction
   // elements per lane: lane (column c, half h) gathers rows 8h..8h+7 of its column from the fp32 stage in LDS (the same
@@ -1042,7 +1050,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
       if (NX * 256 == XQ || idx < XQ) {
         const int mr = idx / (BKT / 4), kq = idx % (BKT / 4);
         const int row = min(m0 + mr, P.M - 1), k = kbase + kq * 4;
-        if (VEC) {
+        if (XVEC) {
           rx[i] = ld4(P.x + (size_t)row * P.ldx + min(k, P.K - 4));
         } else {
 #pragma unroll
@@ -1056,7 +1064,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
       if (ND * 256 == DQ || idx < DQ) {
         const int mr = idx / (BNT / 4), nq = idx % (BNT / 4);
         const int row = min(m0 + mr, P.M - 1), col = nbase + nq * 4;
-        if (VEC) {
+        if (DVEC) {
           const int cc = min(col, P.N - 4);
           rg[i] = ld4(P.g + (size_t)row * P.ldg + cc);
           if (two) ry[i] = ld4(P.y + (size_t)row * P.ldy + cc);
@@ -1097,7 +1105,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
         if (two) v += kB4[i] * ry[i];
         if (dy_owner && rok) {
           float *dp = P.dyout + (size_t)(m0 + mr) * P.lddy + nbase + nq * 4;
-          if (VEC) {
+          if (DVEC) {
             if (dok[i][0]) st4_nt(dp, v);
           } else {
 #pragma unroll
@@ -1622,11 +1630,12 @@ bool split_math() {
 }
 
 template <int TM, int TN, int WM, int WN>
-void launch_gemm(const GemmArgs &A, dim3 grid, hipStream_t st, bool vec) {
-  // two instantiations only: 16-byte loads on both operands, or scalar loads on both (tiny GEMMs
-  // with N or K = number of classes)
-  if (vec) hipLaunchKernelGGL((pw_gemm_kernel<TM, TN, WM, WN, true>), grid, dim3(256), 0, st, A);
-  else hipLaunchKernelGGL((pw_gemm_kernel<TM, TN, WM, WN, false>), grid, dim3(256), 0, st, A);
+void launch_gemm(const GemmArgs &A, dim3 grid, hipStream_t st, int vec) {
+  // 16-byte loads on both operands (1), scalar loads on both (0: tiny GEMMs with K = number of classes), or on the
+  // activation operand only (2: N = number of classes — the logits layer's forward)
+  if (vec == 1) hipLaunchKernelGGL((pw_gemm_kernel<TM, TN, WM, WN, 1>), grid, dim3(256), 0, st, A);
+  else if (vec == 2) hipLaunchKernelGGL((pw_gemm_kernel<TM, TN, WM, WN, 2>), grid, dim3(256), 0, st, A);
+  else hipLaunchKernelGGL((pw_gemm_kernel<TM, TN, WM, WN, 0>), grid, dim3(256), 0, st, A);
 }
 
 inline bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
@@ -1637,6 +1646,7 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   const bool avec = (A.K % 4 == 0) && (A.lda % 4 == 0) && al16(A.a) && (!two || ((A.lda2 % 4 == 0) && al16(A.a2)));
   const bool bvec = (A.N % 4 == 0) && (A.ldb % 4 == 0) && al16(A.b);
   const bool vec = avec && bvec;
+  const int vmode = vec ? 1 : (avec ? 2 : 0);
   const bool stream = vec && env_int("DL3_GEMM_IMPL") != 0 && A.K <= DL3_STREAM_KMAX;
   // (a per-image addend stays on the forward instantiation when its straight-line epilogue can take it: 32-row blocks
   // inside one image)
@@ -1721,11 +1731,11 @@ int run_gemm(GemmArgs A, hipStream_t st) {
     return (int)grid.y;
   }
   switch (c.id) {
-    case 0: launch_gemm<2, 2, 2, 2>(A, grid, st, vec); break;
-    case 1: launch_gemm<2, 2, 4, 1>(A, grid, st, vec); break;
-    case 2: launch_gemm<2, 1, 4, 1>(A, grid, st, vec); break;
-    case 3: launch_gemm<1, 5, 4, 1>(A, grid, st, vec); break;
-    default: launch_gemm<1, 3, 4, 1>(A, grid, st, vec); break;
+    case 0: launch_gemm<2, 2, 2, 2>(A, grid, st, vmode); break;
+    case 1: launch_gemm<2, 2, 4, 1>(A, grid, st, vmode); break;
+    case 2: launch_gemm<2, 1, 4, 1>(A, grid, st, vmode); break;
+    case 3: launch_gemm<1, 5, 4, 1>(A, grid, st, vmode); break;
+    default: launch_gemm<1, 3, 4, 1>(A, grid, st, vmode); break;
   }
   return (int)grid.y;
 }
@@ -1796,11 +1806,12 @@ int colsum_rows(int M) {
 }
 
 template <int TA, int TB, int WA, int WB>
-void launch_wgrad(const WgradArgs &A, dim3 grid, hipStream_t st, bool vec) {
-  if (vec && split_math() && env_int("DL3_WGRAD_SPLIT") != 0)
-    hipLaunchKernelGGL((pw_wgrad_kernel<TA, TB, WA, WB, true, true>), grid, dim3(256), 0, st, A);
-  else if (vec) hipLaunchKernelGGL((pw_wgrad_kernel<TA, TB, WA, WB, true>), grid, dim3(256), 0, st, A);
-  else hipLaunchKernelGGL((pw_wgrad_kernel<TA, TB, WA, WB, false>), grid, dim3(256), 0, st, A);
+void launch_wgrad(const WgradArgs &A, dim3 grid, hipStream_t st, int vec) {
+  if (vec == 1 && split_math() && env_int("DL3_WGRAD_SPLIT") != 0)
+    hipLaunchKernelGGL((pw_wgrad_kernel<TA, TB, WA, WB, 1, true>), grid, dim3(256), 0, st, A);
+  else if (vec == 1) hipLaunchKernelGGL((pw_wgrad_kernel<TA, TB, WA, WB, 1>), grid, dim3(256), 0, st, A);
+  else if (vec == 2) hipLaunchKernelGGL((pw_wgrad_kernel<TA, TB, WA, WB, 2>), grid, dim3(256), 0, st, A);
+  else hipLaunchKernelGGL((pw_wgrad_kernel<TA, TB, WA, WB, 0>), grid, dim3(256), 0, st, A);
 }
 
 }  // namespace
@@ -2007,16 +2018,16 @@ static int pwconv_bwd_weight_impl(const float *x, int ldx, const float *in_scale
   const bool xvec = (K % 4 == 0) && (ldx % 4 == 0) && al16(x);
   const bool dvec = (N % 4 == 0) && (ldg % 4 == 0) && al16(g) && (!two || ((ldyraw % 4 == 0) && al16(yraw)));
   switch (c.id) {
-    case 0: launch_wgrad<1, 1, 2, 2>(A, grid, st, xvec && dvec); break;
-    case 1: launch_wgrad<2, 2, 2, 2>(A, grid, st, xvec && dvec); break;
-    case 2: launch_wgrad<5, 1, 1, 4>(A, grid, st, xvec && dvec); break;
-    case 3: launch_wgrad<1, 5, 4, 1>(A, grid, st, xvec && dvec); break;
-    case 4: launch_wgrad<2, 1, 1, 4>(A, grid, st, xvec && dvec); break;
-    case 5: launch_wgrad<1, 2, 4, 1>(A, grid, st, xvec && dvec); break;
-    case 6: launch_wgrad<1, 1, 1, 4>(A, grid, st, xvec && dvec); break;
-    case 7: launch_wgrad<1, 1, 4, 1>(A, grid, st, xvec && dvec); break;
-    case 8: launch_wgrad<3, 1, 1, 4>(A, grid, st, xvec && dvec); break;
-    default: launch_wgrad<1, 3, 4, 1>(A, grid, st, xvec && dvec); break;
+    case 0: launch_wgrad<1, 1, 2, 2>(A, grid, st, (xvec && dvec) ? 1 : (xvec ? 2 : 0)); break;
+    case 1: launch_wgrad<2, 2, 2, 2>(A, grid, st, (xvec && dvec) ? 1 : (xvec ? 2 : 0)); break;
+    case 2: launch_wgrad<5, 1, 1, 4>(A, grid, st, (xvec && dvec) ? 1 : (xvec ? 2 : 0)); break;
+    case 3: launch_wgrad<1, 5, 4, 1>(A, grid, st, (xvec && dvec) ? 1 : (xvec ? 2 : 0)); break;
+    case 4: launch_wgrad<2, 1, 1, 4>(A, grid, st, (xvec && dvec) ? 1 : (xvec ? 2 : 0)); break;
+    case 5: launch_wgrad<1, 2, 4, 1>(A, grid, st, (xvec && dvec) ? 1 : (xvec ? 2 : 0)); break;
+    case 6: launch_wgrad<1, 1, 1, 4>(A, grid, st, (xvec && dvec) ? 1 : (xvec ? 2 : 0)); break;
+    case 7: launch_wgrad<1, 1, 4, 1>(A, grid, st, (xvec && dvec) ? 1 : (xvec ? 2 : 0)); break;
+    case 8: launch_wgrad<3, 1, 1, 4>(A, grid, st, (xvec && dvec) ? 1 : (xvec ? 2 : 0)); break;
+    default: launch_wgrad<1, 3, 4, 1>(A, grid, st, (xvec && dvec) ? 1 : (xvec ? 2 : 0)); break;
   }
   DL3_LAUNCH_CHECK("pwconv_bwd_weight");
   if (!dw) return DL3_OK;  // the caller folds the [S][K][N] slabs itself (dl3_reduce_partials / _batched)

@@ -212,7 +212,9 @@ PW_CASES = [
     # M, K, N, ldx_extra, ldy_extra, bias, act
     (256, 16, 96, 0, 0, False, 2),
     (512, 96, 24, 0, 0, False, 2),
-    (300, 32, 21, 0, 0, True, None),     # N not a multiple of 4 -> scalar path, M tail
+    (300, 32, 21, 0, 0, True, None),     # N not a multiple of 4 -> scalar weight loads (16-byte activation loads), M tail
+    (4100, 256, 21, 0, 0, True, 1),      # the logits layer (deeplabv3p.py:438): K = 256, N = classes
+    (300, 30, 21, 0, 0, True, None),     # neither operand a multiple of 4: scalar loads on both
     (1024, 160, 960, 0, 0, False, None),
     (384, 960, 160, 0, 0, False, 2),
     (130, 24, 144, 0, 0, False, 2),
