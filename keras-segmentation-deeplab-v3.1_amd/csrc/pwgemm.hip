@@ -1456,27 +1456,39 @@ __global__ __launch_bounds__(256, OC) void pw_fwd_ws_kernel(GemmArgs P) {
 // result is a per-image constant the network adds to every pixel of the 64x64 map: its rounding error does not average
 // out over pixels, and a reduction of 2 048 on the f32 MFMA was where the HIP path's distance to float64 left torch-fp32's
 // (tools/r5/xception_layer_distance.py: ratio 1.00 up to the exit flow, 1.08 behind image_pooling, 1.15 at the logits).
-// 64 columns x 4 slices of the reduction per workgroup, slices folded in slice order; M <= 256 rows: microseconds.
+// 16 columns x 16 slices of the reduction per workgroup (a lane's chain is K/16 long: at M = 2 rows the launch is eight to
+// thirty-two workgroups and its time is that chain), four independent partial sums per lane, slices folded in slice order.
+constexpr int ROWS_CL = 16, ROWS_SL = 16;
 __global__ __launch_bounds__(256) void pw_rows_f64_kernel(GemmArgs P) {
-  __shared__ double red[4][64];
-  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + cl, m = blockIdx.y;
-  const int kper = (P.K + 3) / 4, k0 = sl * kper, k1 = min(P.K, k0 + kper);
+  __shared__ double red[ROWS_SL][ROWS_CL];
+  const int cl = threadIdx.x % ROWS_CL, sl = threadIdx.x / ROWS_CL;
+  const int n = blockIdx.x * ROWS_CL + cl, m = blockIdx.y;
+  const int kper = (P.K + ROWS_SL - 1) / ROWS_SL, k0 = sl * kper, k1 = min(P.K, k0 + kper);
   const float *xr = P.a + (size_t)m * P.lda;
   const bool xform = P.ka != nullptr;
-  double acc = 0.0;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   if (n < P.N) {
-    for (int k = k0; k < k1; k++) {
+    auto term = [&](int k) -> double {
       float v = xr[k];
       if (xform) v = P.ka[k] * v + P.kc[k];
       v = dl3_act(v, P.a_act);
-      acc += (double)v * (double)P.b[(size_t)k * P.ldb + n];
+      return (double)v * (double)P.b[(size_t)k * P.ldb + n];
+    };
+    int k = k0;
+    for (; k + 4 <= k1; k += 4) {
+      a0 += term(k);
+      a1 += term(k + 1);
+      a2 += term(k + 2);
+      a3 += term(k + 3);
     }
+    for (; k < k1; k++) a0 += term(k);
   }
-  red[sl][cl] = acc;
+  red[sl][cl] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (sl == 0 && n < P.N) {
-    double t = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < ROWS_SL; i++) t += red[i][cl];
     if (P.bias) t += (double)P.bias[n];
     if (P.ep_add) t += (double)(P.add_scale * P.ep_add[(size_t)(m / P.add_div) * P.ld_add + n]);
     P.c[(size_t)m * P.ldc + n] = (float)t;
@@ -1928,7 +1940,7 @@ extern "C" int dl3_pwconv_fwd_rows(const float *x, int ldx, const float *in_scal
   A.b = w; A.ldb = N; A.bias = bias; A.c = y; A.ldc = ldy;
   A.M = M; A.K = K; A.N = N;
   A.ep_add = add; A.ld_add = ldadd; A.add_div = add_div < 1 ? 1 : add_div; A.add_scale = 1.f;
-  hipLaunchKernelGGL(pw_rows_f64_kernel, dim3(dl3_cdiv(N, 64), M), dim3(256), 0, (hipStream_t)stream, A);
+  hipLaunchKernelGGL(pw_rows_f64_kernel, dim3(dl3_cdiv(N, ROWS_CL), M), dim3(256), 0, (hipStream_t)stream, A);
   DL3_LAUNCH_CHECK("pwconv_fwd_rows");
   return DL3_OK;
 }
