@@ -358,15 +358,18 @@ __global__ __launch_bounds__(256) void grad_finish_kernel(const float *gin, int 
   }
 }
 
-// out[n][c] = out_scale * sum_hw T(x)[n,hw,c]; grid (ceil(C/32), N); 32 columns x 8 row lanes
-__global__ __launch_bounds__(256) void gap_kernel(const float *__restrict__ x, int ldx,
+// out[n][c] = out_scale * sum_hw T(x)[n,hw,c]; grid (ceil(C/32), N); 32 columns x RL row lanes (RL = 8: 256 threads; RL = 32:
+// 1 024 threads for small batches — a (column block, image) pair is ONE workgroup, at B = 2 the launch is 20 workgroups and
+// its time is the chain of dependent round trips one lane walks: 512 rows per lane at RL = 8, 128 at RL = 32)
+template <int RL>
+__global__ __launch_bounds__(32 * RL) void gap_kernel(const float *__restrict__ x, int ldx,
                                                   const float *__restrict__ sc, const float *__restrict__ sh,
                                                   int act, float *__restrict__ out, int HW, int C, float out_scale) {
   // Sums in DOUBLE (round 5): the pooled feature is ONE value per image and channel that the ASPP adds to every pixel
   // (deeplabv3p.py:375-382) — its rounding error is coherent over the whole map, and the per-layer distance to float64
   // of the Xception OS=8 inference (tools/r5/xception_layer_distance.py) parted from torch-fp32's exactly here.  4 096
   // terms per (image, channel): the double adds are free next to the loads.
-  __shared__ double red[256];
+  __shared__ double red[32 * RL];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl, n = blockIdx.y;
   double s = 0.0;
@@ -377,10 +380,10 @@ __global__ __launch_bounds__(256) void gap_kernel(const float *__restrict__ x, i
     int i = rl;
     // 16 independent loads per iteration: a (column block, image) pair is ONE workgroup (20-40 workgroups in all, the
     // kernel is pure latency: 72 us at 4 loads in flight per lane, measured on the 64x64x320 map)
-    for (; i + 120 < HW; i += 128) {
+    for (; i + 15 * RL < HW; i += 16 * RL) {
       float v[16];
 #pragma unroll
-      for (int u = 0; u < 16; u++) v[u] = p[(size_t)(i + 8 * u) * ldx];
+      for (int u = 0; u < 16; u++) v[u] = p[(size_t)(i + RL * u) * ldx];
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
       for (int u = 0; u < 16; u += 4) {
@@ -391,13 +394,13 @@ __global__ __launch_bounds__(256) void gap_kernel(const float *__restrict__ x, i
       }
       s += (a0 + a1) + (a2 + a3);
     }
-    for (; i < HW; i += 8) s += (double)dl3_act(es * p[(size_t)i * ldx] + et, act);
+    for (; i < HW; i += RL) s += (double)dl3_act(es * p[(size_t)i * ldx] + et, act);
   }
   red[threadIdx.x] = s;
   __syncthreads();
   if (rl == 0 && c < C) {
     double t = 0.0;
-    for (int q = 0; q < 8; q++) t += red[q * 32 + cl];
+    for (int q = 0; q < RL; q++) t += red[q * 32 + cl];
     out[(size_t)n * C + c] = (float)(t * (double)out_scale);
   }
 }
@@ -651,8 +654,13 @@ extern "C" int dl3_gap_fwd(const float *x, int ldx, const float *in_scale, const
   DL3_CHECK_ARG(x && out && N > 0 && HW > 0 && C > 0 && ldx >= C, "gap_fwd: bad argument");
   DL3_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "gap_fwd: scale/shift must come together");
   DL3_UNSUPPORTED(N > 65535, "gap_fwd: N too large");
-  hipLaunchKernelGGL(gap_kernel, dim3(dl3_cdiv(C, 32), N), dim3(256), 0, (hipStream_t)stream, x, ldx, in_scale,
-                     in_shift, in_act, out, HW, C, out_scale);
+  const dim3 grid(dl3_cdiv(C, 32), N);
+  if ((long)grid.x * grid.y >= 512)
+    hipLaunchKernelGGL(gap_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, x, ldx, in_scale, in_shift, in_act, out, HW,
+                       C, out_scale);
+  else
+    hipLaunchKernelGGL(gap_kernel<32>, grid, dim3(1024), 0, (hipStream_t)stream, x, ldx, in_scale, in_shift, in_act, out, HW,
+                       C, out_scale);
   DL3_LAUNCH_CHECK("gap_fwd");
   return DL3_OK;
 }

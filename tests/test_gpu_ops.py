@@ -837,6 +837,14 @@ def test_pwconv_fwd_few_rows_accumulates_in_double(L, M, K, N, ldx_extra, ldy_ex
     call("dl3_gap_fwd", ptr(dev(t)), C, None, None, 0, ptr(out), B, HW, C, 1.0 / HW)
     want = t.astype(np.float64).mean(1)
     assert np.abs(host(out) - want).max() / np.abs(want).max() < 1.5e-7
+    if M == 1:
+        # 600 (column block, image) pairs: the 256-thread form of the kernel (few pairs take 1 024 threads); ragged HW and C
+        HW, C, B = 1000, 70, 200
+        t = rng.normal(3.0, 1.0, (B, HW, C)).astype(np.float32)
+        out = empty(B, C)
+        call("dl3_gap_fwd", ptr(dev(t)), C, None, None, 0, ptr(out), B, HW, C, 1.0 / HW)
+        want = t.astype(np.float64).mean(1)
+        assert np.abs(host(out) - want).max() / np.abs(want).max() < 1.5e-7
 
 
 @pytest.mark.parametrize("M", [2, 37, 4096])
