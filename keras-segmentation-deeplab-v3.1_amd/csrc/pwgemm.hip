@@ -1451,6 +1451,168 @@ __global__ __launch_bounds__(256, OC) void pw_fwd_ws_kernel(GemmArgs P) {
   }
 }
 
+// ---- small batches (round 5): 32 rows x all N <= 160 columns per workgroup, the REDUCTION split over the four
+// waves.  At B = 2 - 4 the 64x64 maps are 8 192 - 16 384 rows: the 32-row stream kernels put their four waves side by side
+// along N (64 columns each), which pads a 160-wide output to 256 columns (1.6x the MFMAs) and a 96-wide one to 128, on a
+// launch that is one workgroup per CU walking K/16 barrier-separated K-tiles.  Here every wave owns whole 32 x (32 TN)
+// accumulators and walks every fourth K-tile on its own — weights through a wave-private double buffer in LDS, no barrier
+// in the loop —, the four partial accumulators meet in LDS once ((w0 + w1) + (w2 + w3), fixed order) and column block j is
+// finished (bias, mask, addend, store, BatchNorm sums) by wave j % 4.  One partial-sum row per workgroup (= 32-row tile).
+template <int TN, bool TWO>
+__global__ __launch_bounds__(256) void pw_ksplit32_kernel(GemmArgs P) {
+  constexpr int KT = 16, BN = 32 * TN, BQ = KT * BN;
+  constexpr int NB = (BQ / 4 + 63) / 64;             // float4 weight loads per LANE: one wave loads a whole K-tile
+  constexpr int KCS = DL3_STREAM_KMAX + KT;
+  __shared__ float cf[(TWO ? 3 : 2) * KCS];
+  __shared__ __attribute__((aligned(16))) float wbuf[4][2 * BQ];  // per wave: two weight tiles; later its TN accumulators
+  static_assert(2 * BQ == 1024 * TN, "the reduction reuses the weight buffers");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+  const int ktiles = (P.K + KT - 1) / KT;
+  const bool xform = (P.ka != nullptr);
+  for (int i = tid; i < ktiles * KT; i += 256) {
+    const bool in = i < P.K;
+    const int k = min(i, P.K - 1);
+    cf[i] = in ? (xform ? P.ka[k] : 1.f) : 0.f;
+    cf[KCS + i] = (in && xform) ? P.kc[k] : 0.f;
+    if (TWO) cf[2 * KCS + i] = in ? P.kb[k] : 0.f;
+  }
+  __syncthreads();
+  const int m0 = blockIdx.x * 32;
+  const int row = min(m0 + l31, P.M - 1);
+  const float *ar = P.a + (size_t)row * P.lda;
+  const float *ar2 = TWO ? P.a2 + (size_t)row * P.lda2 : nullptr;
+  float *wb = wbuf[wave];
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; j++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+  f32x4 an[2], an2[2], rb[NB];
+  float ac[8];
+  auto request = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int kc = min(kt * KT + 8 * lhi + 4 * j, P.K - 4);
+      an[j] = ld4(ar + kc);
+      if (TWO) an2[j] = ld4(ar2 + kc);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+      const int idx = lane + 64 * i;
+      if (NB * 64 == BQ / 4 || idx < BQ / 4) {
+        const int kk = idx / (BN / 4), nq = idx % (BN / 4);
+        const int krow = min(kt * KT + kk, P.K - 1), col = min(nq * 4, P.N - 4);
+        rb[i] = ld4(P.b + (size_t)krow * P.ldb + col);
+      }
+    }
+  };
+  auto stash = [&](int kt, float *Bs) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+      const int idx = lane + 64 * i;
+      if (NB * 64 == BQ / 4 || idx < BQ / 4) st4(&Bs[(idx / (BN / 4)) * BN + (idx % (BN / 4)) * 4], rb[i]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int k = kt * KT + 8 * lhi + 4 * j;
+      f32x4 v = ld4(cf + k) * an[j] + ld4(cf + KCS + k);
+      if (TWO) v += ld4(cf + 2 * KCS + k) * an2[j];
+      v = dl3_act4(v, P.a_act);
+      ac[4 * j + 0] = v.x; ac[4 * j + 1] = v.y; ac[4 * j + 2] = v.z; ac[4 * j + 3] = v.w;
+    }
+  };
+  int kt = wave, buf = 0;
+  if (kt < ktiles) {
+    request(kt);
+    stash(kt, wb);
+  }
+  for (; kt < ktiles; kt += 4) {
+    const bool more = kt + 4 < ktiles;
+    if (more) request(kt + 4);
+    __builtin_amdgcn_wave_barrier();   // (a wave's LDS operations complete in order: the tile it stashed is there)
+    const float *Bs = wb + buf * BQ;
+    float av[8];
+#pragma unroll
+    for (int s_ = 0; s_ < 8; s_++) av[s_] = ac[s_];
+#pragma unroll
+    for (int s_ = 0; s_ < 8; s_++) {
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s_], Bs[(8 * lhi + s_) * BN + j * 32 + l31], acc[j], 0, 0, 0);
+    }
+    if (more) stash(kt + 4, wb + (buf ^ 1) * BQ);
+    buf ^= 1;
+  }
+  // the four partial accumulators meet: wave w parks its TN blocks in its own buffer, block j is summed by wave j % 4
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < TN; j++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) wb[(j * 16 + r) * 64 + lane] = acc[j][r];
+  __syncthreads();
+  const bool mode2 = P.stat_mode == 2;
+#pragma unroll
+  for (int j = 0; j < TN; j++) {
+    if ((j & 3) != wave) continue;     // (wave-uniform)
+    float v16[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int o = (j * 16 + r) * 64 + lane;
+      v16[r] = (wbuf[0][o] + wbuf[1][o]) + (wbuf[2][o] + wbuf[3][o]);
+    }
+    const int col = j * 32 + l31;
+    const bool cok = col < P.N;
+    const int colc = min(col, P.N - 1);
+    float bias = 0.f, es = 1.f, et = 0.f, mu = 0.f, is = 0.f;
+    if (P.bias) bias = P.bias[colc];
+    if (P.ep_x && P.ep_scale) { es = P.ep_scale[colc]; et = P.ep_shift[colc]; }
+    if (mode2) { mu = P.ep_mean[colc]; is = P.ep_invstd[colc]; }
+    const int rbase = m0 + 4 * lhi;
+    float xr_[16], ad[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int rw = min(rbase + (r & 3) + 8 * (r >> 2), P.M - 1);
+      xr_[r] = P.ep_x ? P.ep_x[(size_t)rw * P.ld_epx + colc] : 0.f;
+      const int arow_ = (P.add_div > 1) ? rw / P.add_div : rw;
+      ad[r] = P.ep_add ? P.add_scale * P.ep_add[(size_t)arow_ * P.ld_add + colc] : 0.f;
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int rw = rbase + (r & 3) + 8 * (r >> 2);
+      float v = v16[r] + bias;
+      if (P.ep_x) v *= dl3_act_mask(es * xr_[r] + et, P.ep_act);
+      v += ad[r];
+      if (cok && rw < P.M) {
+        __builtin_nontemporal_store(v, &P.c[(size_t)rw * P.ldc + col]);
+        s1 += v;
+        s2 += mode2 ? v * ((xr_[r] - mu) * is) : v * v;
+      }
+    }
+    if (P.stat_mode != 0) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (lhi == 0 && cok) {
+        P.part[((size_t)blockIdx.x * P.N + col) * 2 + 0] = s1;
+        P.part[((size_t)blockIdx.x * P.N + col) * 2 + 1] = s2;
+        for (int rr = blockIdx.x + (int)gridDim.x; rr < P.part_rows; rr += (int)gridDim.x) {
+          P.part[((size_t)rr * P.N + col) * 2 + 0] = 0.f;
+          P.part[((size_t)rr * P.N + col) * 2 + 1] = 0.f;
+        }
+      }
+    }
+  }
+}
+
+// shapes and row counts the K-split kernel takes (DL3_KSPLIT=0: never; DL3_KSPLIT_ROWS: row limit, default 16 384)
+inline int ksplit_tn(int M, int K, int N) {
+  if (env_int("DL3_KSPLIT") == 0) return 0;
+  const int lim = env_int("DL3_KSPLIT_ROWS") > 0 ? env_int("DL3_KSPLIT_ROWS") : 16384;
+  if (M > lim || M < 1024 || K < 192 || K > DL3_STREAM_KMAX || K % 4 != 0 || N % 4 != 0) return 0;
+  const int tn = dl3_cdiv(N, 32);
+  return (tn == 3 || tn == 5) ? tn : 0;   // 96- and 160-wide outputs: the ones the 64-column-per-wave kernels pad
+}
+
 // ---- dl3_pwconv_fwd_rows: a handful of rows (the ASPP image-pooling branch: ONE row per image, deeplabv3p.py:375-382,
 // and its share of concat_projection, :402-406): Y[m][n] = act(ka*x + kc)[m][:] . W[:][n] + bias + addend, in DOUBLE.  The
 // result is a per-image constant the network adds to every pixel of the 64x64 map: its rounding error does not average
@@ -1678,6 +1840,20 @@ int run_gemm(GemmArgs A, hipStream_t st) {
 #undef DL3_WS
     return (int)grid.x;
   }
+  if (vec && !split_math()) {
+    const int ktn = ksplit_tn(A.M, A.K, A.N);
+    if (ktn) {
+      const dim3 grid(dl3_cdiv(A.M, 32)), blk(256);
+      if (ktn == 3) {
+        if (two) hipLaunchKernelGGL((pw_ksplit32_kernel<3, true>), grid, blk, 0, st, A);
+        else hipLaunchKernelGGL((pw_ksplit32_kernel<3, false>), grid, blk, 0, st, A);
+      } else {
+        if (two) hipLaunchKernelGGL((pw_ksplit32_kernel<5, true>), grid, blk, 0, st, A);
+        else hipLaunchKernelGGL((pw_ksplit32_kernel<5, false>), grid, blk, 0, st, A);
+      }
+      return (int)grid.x;
+    }
+  }
   GemmCfg c = pick_gemm(A.M, A.K, A.N, two, stream, fwd);
   if (stream && pre_ok(A) && pre_wanted(A)) c = kGemmCfgs[4];
   A.mtiles = dl3_cdiv(A.M, c.BM);
@@ -1857,6 +2033,10 @@ extern "C" int dl3_pwconv_partials(int M, int K, int N) {
       }
   if (ws_tn(K, N)) {  // the weight-stationary forward kernel writes one row per workgroup
     const int q = ws_grid(M);
+    p = q > p ? q : p;
+  }
+  if (ksplit_tn(M, K, N)) {  // the K-split kernel of the small batches: one row per 32-row tile
+    const int q = dl3_cdiv(M, 32);
     p = q > p ? q : p;
   }
   if (N % 96 == 0) {  // the prefetching bwd-data variant overrides the choice with the 128x96 tile (run_gemm)

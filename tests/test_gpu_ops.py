@@ -231,6 +231,12 @@ PW_CASES = [
     (384, 304, 256, 0, 0, False, 1),     # decoder_conv0_pointwise
     (384, 256, 48, 0, 256, False, None),  # feature_projection0 into the [x, dec_skip1] concat slice
     (128, 256, 728, 0, 0, False, 1),
+    # small batches (round 5, pw_ksplit32_kernel: 1 024 - 16 384 rows, a 96- or 160-wide output, reduction >= 192 split over the waves)
+    (2048, 960, 160, 0, 0, False, 2),
+    (1100, 576, 96, 0, 0, True, 1),      # ragged last 32-row tile, bias
+    (8192, 384, 96, 32, 0, False, 2),    # reads a channel slice
+    (4096, 256, 144, 0, 16, False, 1),   # 144 columns in five blocks, writes a channel slice
+    (1056, 196, 132, 0, 0, True, None),  # reduction not a multiple of the K-tile, ragged column block
 ]
 
 
@@ -360,6 +366,9 @@ BD_CASES = [
     (200, 2048, 256, 1, True, 0, True),      # aspp pointwise: dX is 2048 wide
     (384, 304, 256, 1, True, 0, True),
     (384, 256, 48, 1, True, 0, False),
+    (2048, 160, 960, 2, True, 1, True),      # small batches (pw_ksplit32_kernel): two-tensor operand + residual gradient + sums
+    (1100, 96, 576, 1, True, 0, True),       # ragged last row tile, three column blocks
+    (4096, 160, 320, None, True, 2, True),   # per-image addend
     # short reduction into a wide output, >= 512 row tiles: the variant that prefetches the mask operand before the
     # main loop (128x96 tiles; the ragged last row tile takes the generic epilogue)
     (65536 + 200, 960, 160, 2, True, 0, True),
@@ -421,6 +430,8 @@ MSK_CASES = [
     (4096, 320, 256, None, 2),        # per-image addend (64 rows per image)
     (1000, 144, 24, 2, 0),            # ragged in both directions
     (32768, 728, 728, 1, 1),          # Xception middle flow
+    (8192, 160, 960, 2, 0),           # small batches (pw_ksplit32_kernel): B=2's 64x64 maps
+    (4128, 96, 576, None, 1),
 ]
 
 
