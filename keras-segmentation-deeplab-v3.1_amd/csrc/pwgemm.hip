@@ -1604,13 +1604,15 @@ __global__ __launch_bounds__(256) void pw_ksplit32_kernel(GemmArgs P) {
   }
 }
 
-// shapes and row counts the K-split kernel takes (DL3_KSPLIT=0: never; DL3_KSPLIT_ROWS: row limit, default 16 384)
+// shapes and row counts the K-split kernel takes (DL3_KSPLIT=0: never, 1: without N <= 64; DL3_KSPLIT_ROWS: row limit, default 16 384)
 inline int ksplit_tn(int M, int K, int N) {
   if (env_int("DL3_KSPLIT") == 0) return 0;
   const int lim = env_int("DL3_KSPLIT_ROWS") > 0 ? env_int("DL3_KSPLIT_ROWS") : 16384;
   if (M > lim || M < 1024 || K < 192 || K > DL3_STREAM_KMAX || K % 4 != 0 || N % 4 != 0) return 0;
   const int tn = dl3_cdiv(N, 32);
-  return (tn == 3 || tn == 5) ? tn : 0;   // 96- and 160-wide outputs: the ones the 64-column-per-wave kernels pad
+  if (tn == 2 && env_int("DL3_KSPLIT") == 1) return 0;   // (DL3_KSPLIT=1: without the 64-wide outputs — tuning aid)
+  // 64-, 96- and 160-wide outputs: the ones the 64-column-per-wave kernels pad (to 128, 128 and 256 columns)
+  return (tn == 2 || tn == 3 || tn == 5) ? tn : 0;
 }
 
 // ---- dl3_pwconv_fwd_rows: a handful of rows (the ASPP image-pooling branch: ONE row per image, deeplabv3p.py:375-382,
@@ -1844,7 +1846,10 @@ int run_gemm(GemmArgs A, hipStream_t st) {
     const int ktn = ksplit_tn(A.M, A.K, A.N);
     if (ktn) {
       const dim3 grid(dl3_cdiv(A.M, 32)), blk(256);
-      if (ktn == 3) {
+      if (ktn == 2) {
+        if (two) hipLaunchKernelGGL((pw_ksplit32_kernel<2, true>), grid, blk, 0, st, A);
+        else hipLaunchKernelGGL((pw_ksplit32_kernel<2, false>), grid, blk, 0, st, A);
+      } else if (ktn == 3) {
         if (two) hipLaunchKernelGGL((pw_ksplit32_kernel<3, true>), grid, blk, 0, st, A);
         else hipLaunchKernelGGL((pw_ksplit32_kernel<3, false>), grid, blk, 0, st, A);
       } else {

@@ -237,6 +237,7 @@ PW_CASES = [
     (8192, 384, 96, 32, 0, False, 2),    # reads a channel slice
     (4096, 256, 144, 0, 16, False, 1),   # 144 columns in five blocks, writes a channel slice
     (1056, 196, 132, 0, 0, True, None),  # reduction not a multiple of the K-tile, ragged column block
+    (2048, 384, 64, 0, 0, False, 2),     # 64-wide output: two column blocks per wave
 ]
 
 
@@ -369,6 +370,7 @@ BD_CASES = [
     (2048, 160, 960, 2, True, 1, True),      # small batches (pw_ksplit32_kernel): two-tensor operand + residual gradient + sums
     (1100, 96, 576, 1, True, 0, True),       # ragged last row tile, three column blocks
     (4096, 160, 320, None, True, 2, True),   # per-image addend
+    (2048, 64, 384, None, True, 1, True),    # 64-wide gradient
     # short reduction into a wide output, >= 512 row tiles: the variant that prefetches the mask operand before the
     # main loop (128x96 tiles; the ragged last row tile takes the generic epilogue)
     (65536 + 200, 960, 160, 2, True, 0, True),
