@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -39,6 +40,7 @@ struct GemmArgs {
   float *part;
   int part_rows;  // rows the caller's partial buffer holds: the launch writes gridDim.y of them and zeroes the rest itself
   int mtiles;
+  int py_last;  // pw_gemm_stream_kernel<..., JV>: row slots (of gridDim.y) the exact-width last column tile uses
   const void *bp; int nsub;  // split math: weights pre-split into 3 bf16 planes in MFMA fragment order (pack_b_kernel)
 #ifdef DL3_PHASE_TIMING
   long long *dbg;  // probe build (tools/r3/phase_probe.py): per-workgroup cycles in prologue / K loop / epilogue
@@ -463,8 +465,20 @@ __device__ __forceinline__ void stream_epilogue_full(const GemmArgs &P, const f3
 // GEMMs; their interior tiles take the straight-line epilogue and the masked code is not compiled in at all.
 // WN: waves side by side along N (4/WN stacked along M).  WN = 4 gives 32-row tiles for small M (batch 1-4: a
 // 128-row tile leaves most CUs idle and every workgroup a long serial K loop).
-template <int TM, int TN, bool TWO, int KT, int EPI, int WN = 1, int MATH = 0>
-__global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
+// JV (round 6): the LAST column tile of the launch is JV < TN blocks wide — exactly the columns that are
+// left (N = (gridDim.x - 1) * 160 + 32 JV: Xception's 736 = 4 x 160 + 96) — instead of a fifth 160-wide tile of which 40 %
+// is padding that the matrix pipe multiplies all the same (8 % of the launch's MFMAs).  Its workgroups run the SAME body
+// compiled for TE = JV column blocks (own accumulator array: no predicated MFMAs, no register copies), and because such a
+// tile is 3/5 of the work, the persistent grid gives that column fewer workgroups, each with more row tiles (P.py_last of
+// the gridDim.y row slots; the others return at once): every workgroup of the launch carries the same number of block-tiles.
+// (waves per SIMD: the generic 128 x 96 kernels fit three — 168 VGPRs, no scratch, since round 4 — and the compiler is told so;
+// before the body became a lambda it found that by itself)
+template <int TM, int TN, int EPI, int WN, int MATH, int JV>
+constexpr int stream_occupancy() { return (TM == 1 && TN == 3 && EPI == 0 && WN == 1 && MATH == 0 && JV == 0) ? 3 : 2; }
+
+template <int TM, int TN, bool TWO, int KT, int EPI, int WN = 1, int MATH = 0, int JV = 0>
+__global__ __launch_bounds__(256, (stream_occupancy<TM, TN, EPI, WN, MATH, JV>())) void pw_gemm_stream_kernel(GemmArgs P) {
+  static_assert(JV == 0 || (JV < TN && WN == 1 && MATH == 0 && EPI != 2), "exact-width last column tile: f32 128-row tiles only");
   // MATH 1: split math (see split3) — the A registers are split after the operand transform, the weight tile comes
   // pre-split from pack_b_kernel, six bf16 MFMAs per 16-deep K-tile and 32x32 sub-tile
   constexpr bool SPL = (MATH == 1);
@@ -516,9 +530,16 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
   const int wm = wave / WN, wn = wave % WN;
   const int nw0 = n0 + wn * TN * 32;  // first column of this wave's sub-tile
 
-  float st1[TN], st2[TN];
+  const bool last_partial = JV > 0 && bx == (int)gridDim.x - 1;
+  const unsigned gy_ = last_partial ? (unsigned)P.py_last : gridDim.y;   // row slots of this column tile
+  if constexpr (JV > 0) {
+    if ((unsigned)by >= gy_) return;
+  }
+  auto body = [&](auto te_tag) __attribute__((always_inline)) {
+  constexpr int TE = decltype(te_tag)::value;   // 32-column blocks of this workgroup's tile (TN, or JV in the last column)
+  float st1[TE], st2[TE];
 #pragma unroll
-  for (int i = 0; i < TN; i++) st1[i] = st2[i] = 0.f;
+  for (int i = 0; i < TE; i++) st1[i] = st2[i] = 0.f;
 
   // T(a)[k] = act(ka[k]*a + kb[k]*a2 + kc[k]); k >= K gets all-zero coefficients, so the clamped (in-bounds) loads
   // beyond K contribute act(0) = 0
@@ -542,26 +563,26 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
 
   DL3_T(long long tp0 = 0; long long tp1 = 0; long long tp2 = 0; long long tq0 = 0; long long tq1 = 0; long long tq2 = 0; int ntl = 0;
         long long tw_vm = 0; long long tw_bar = 0;)
-  for (int mt = by; mt < P.mtiles; mt += gridDim.y) {
+  for (int mt = by; mt < P.mtiles; mt += gy_) {
     DL3_T(tq0 = clock64(); ntl++;)
     const int m0 = mt * BM;
-    f32x16 acc[TM][TN];
+    f32x16 acc[TM][TE];
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
-      for (int j = 0; j < TN; j++)
+      for (int j = 0; j < TE; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    const bool full = (m0 + BM <= P.M) && (n0 + BN <= P.N);
-    float pxv[PRE ? TN : 1][16];
+    const bool full = (m0 + BM <= P.M) && (n0 + 32 * TE * WN <= P.N);
+    float pxv[PRE ? TE : 1][16];
     if constexpr (PRE) {
       if (full) {
         const size_t urow = (size_t)(m0 + __builtin_amdgcn_readfirstlane(wm) * 32);
         const float *px = P.ep_x + urow * P.ld_epx + nw0;
         const unsigned lo_x = (unsigned)(4 * lhi * P.ld_epx + l31);
 #pragma unroll
-        for (int j = 0; j < TN; j++)
+        for (int j = 0; j < TE; j++)
 #pragma unroll
           for (int r = 0; r < 16; r++) pxv[j][r] = (px + (size_t)((r & 3) + 8 * (r >> 2)) * P.ld_epx + j * 32)[lo_x];
       }
@@ -661,7 +682,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
       auto mfma_step = [&](const float *Bs, int ks) {
         const u32x4 *Bq = (const u32x4 *)Bs + (ks * 3 * (BN / 32) + wn * TN) * 64 + lane;
 #pragma unroll
-        for (int j = 0; j < TN; j++) {
+        for (int j = 0; j < TE; j++) {
           const bf16x8 bh = __builtin_bit_cast(bf16x8, Bq[j * 64]);
           const bf16x8 bm = __builtin_bit_cast(bf16x8, Bq[((BN / 32) + j) * 64]);
           const bf16x8 bl = __builtin_bit_cast(bf16x8, Bq[(2 * (BN / 32) + j) * 64]);
@@ -742,20 +763,20 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
             load_B_to(kt + PD, rbb[d]);
             load_A_to(kt + PD, ra[d], ra2[d]);
           }
-          float bf[2][TN];
+          float bf[2][TE];
 #pragma unroll
-          for (int j = 0; j < TN; j++) bf[0][j] = Bs[(KH * lhi) * LDB + (wn * TN + j) * 32 + l31];
+          for (int j = 0; j < TE; j++) bf[0][j] = Bs[(KH * lhi) * LDB + (wn * TN + j) * 32 + l31];
 #pragma unroll
           for (int s_ = 0; s_ < KH; ++s_) {
             const int cur = s_ & 1, nxt = cur ^ 1;
             if (s_ + 1 < KH) {
 #pragma unroll
-              for (int j = 0; j < TN; j++) bf[nxt][j] = Bs[(KH * lhi + s_ + 1) * LDB + (wn * TN + j) * 32 + l31];
+              for (int j = 0; j < TE; j++) bf[nxt][j] = Bs[(KH * lhi + s_ + 1) * LDB + (wn * TN + j) * 32 + l31];
             }
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
-              for (int j = 0; j < TN; j++)
+              for (int j = 0; j < TE; j++)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[i][s_ >> 2][s_ & 3], bf[cur][j], acc[i][j], 0, 0, 0);
           }
           if (kt + 1 < ktiles) {
@@ -782,20 +803,20 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
         load_A(kt + 1);
         load_B(kt + 1);
       }
-      float bf[2][TN];
+      float bf[2][TE];
 #pragma unroll
-      for (int j = 0; j < TN; j++) bf[0][j] = Bs[(KH * lhi) * LDB + (wn * TN + j) * 32 + l31];
+      for (int j = 0; j < TE; j++) bf[0][j] = Bs[(KH * lhi) * LDB + (wn * TN + j) * 32 + l31];
 #pragma unroll
       for (int s_ = 0; s_ < KH; ++s_) {
         const int cur = s_ & 1, nxt = cur ^ 1;
         if (s_ + 1 < KH) {
 #pragma unroll
-          for (int j = 0; j < TN; j++) bf[nxt][j] = Bs[(KH * lhi + s_ + 1) * LDB + (wn * TN + j) * 32 + l31];
+          for (int j = 0; j < TE; j++) bf[nxt][j] = Bs[(KH * lhi + s_ + 1) * LDB + (wn * TN + j) * 32 + l31];
         }
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
-          for (int j = 0; j < TN; j++)
+          for (int j = 0; j < TE; j++)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[i][s_ >> 2][s_ & 3], bf[cur][j], acc[i][j], 0, 0, 0);
       }
       // next tile's weight tile -> LDS and operand transform, behind the last MFMA of this K-tile
@@ -824,8 +845,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
     const int m0e = m0, nw0e = nw0;
 #endif
     if (FWD && full) {
-      if (!P.ep_add) stream_epilogue_full<TM, TN, false, false, false>(P, acc, m0e, nw0e, wm, l31, lhi, st1, st2);
-      else stream_epilogue_full<TM, TN, false, true, false>(P, acc, m0e, nw0e, wm, l31, lhi, st1, st2);
+      if (!P.ep_add) stream_epilogue_full<TM, TE, false, false, false>(P, acc, m0e, nw0e, wm, l31, lhi, st1, st2);
+      else stream_epilogue_full<TM, TE, false, true, false>(P, acc, m0e, nw0e, wm, l31, lhi, st1, st2);
       DL3_T(tp2 += clock64() - tq2;)
       continue;
     }
@@ -835,7 +856,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
         const unsigned lo_c = (unsigned)(4 * lhi * P.ldc + l31);
         const bool mode2 = P.stat_mode == 2;
 #pragma unroll
-        for (int j = 0; j < TN; j++) {
+        for (int j = 0; j < TE; j++) {
           const int cl = j * 32 + l31;
           const float es = eco[cl], et = eco[BN + cl], mu = eco[2 * BN + cl], is = eco[3 * BN + cl];
 #pragma unroll
@@ -853,7 +874,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
     }
     // everything else: generic path, every element predicated
 #pragma unroll
-    for (int j = 0; j < TN; j++) {
+    for (int j = 0; j < TE; j++) {
       const int col = nw0e + j * 32 + l31;
       const bool cok = col < P.N;
       const int colc = min(col, P.N - 1);
@@ -914,7 +935,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
     float *sred = lds;  // [WM][BN][2]
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < TN; j++) {
+    for (int j = 0; j < TE; j++) {
       float a1 = st1[j] + __shfl_xor(st1[j], 32, 64);
       float a2 = st2[j] + __shfl_xor(st2[j], 32, 64);
       if (lhi == 0) {
@@ -936,12 +957,19 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
         P.part[((size_t)by * P.N + col) * 2 + 1] = a2;
         // rows of the buffer no workgroup owns (it is sized for the largest grid any tile choice uses): zeroed here, by
         // the row groups in turn, instead of by a memset node behind every launch
-        for (int r = by + (int)gridDim.y; r < P.part_rows; r += (int)gridDim.y) {
+        for (int r = by + (int)gy_; r < P.part_rows; r += (int)gy_) {
           P.part[((size_t)r * P.N + col) * 2 + 0] = 0.f;
           P.part[((size_t)r * P.N + col) * 2 + 1] = 0.f;
         }
       }
     }
+  }
+  };
+  if constexpr (JV > 0) {
+    if (last_partial) body(std::integral_constant<int, JV>{});
+    else body(std::integral_constant<int, TN>{});
+  } else {
+    body(std::integral_constant<int, TN>{});
   }
 }
 
@@ -963,6 +991,23 @@ struct WgradArgs {
 };
 
 // VEC: 1 = 16-byte loads of x and of g / y, 0 = scalar loads of both, 2 (round 5) = 16-byte loads of x only (N = classes)
+//
+// Round 6.  Two things about this kernel cost the MFMA-bound backward launches their distance to the forward
+// GEMM:
+//  * Tile padding was issued as MFMAs: K = 960 / 576 on 128-row tiles, N = 960 / 576 on 128-column tiles leave the last
+//    tile row / column half empty (7-11 % of the launch's matrix work; Xception's 736 x 736 on 128 x 160 tiles: 13 %).
+//    A wave now runs only the 32 x 32 blocks of its sub-tile that lie inside the matrix (ia x jb of TA x TB, wave-uniform):
+//    a wave with nothing to do idles at the barriers and leaves its SIMD's matrix pipe to the co-resident workgroup.
+//  * The dY = cA*g + cB*y + cC stores (round 4) sat in a branch (`if (owner of this stage)`), behind the stage's operand
+//    requests in program order but IN FRONT of the next stage's: vmcnt retires in order and counts stores, so every wait for
+//    the next stage's operands was also a wait for this stage's stores, and the compiler could not even count them (a store
+//    in a branch: s_waitcnt vmcnt(0)).  The write of 25 GB per step cost the weight-gradient launches +3.5-4.3 ms — all of it
+//    exposed, in launches whose HBM side is half idle.  Now (the recipe of round 5): ownership of the dY stores is a
+//    CONTIGUOUS range of the workgroup's stages (the gridDim.y workgroups of a row slab split the slab's stages evenly), so
+//    the loop is cut into a no-store, a store and a no-store segment, each straight-line; inside the store segment every
+//    lane stores every piece (rows beyond M and column groups beyond N are clamped onto valid ones: same address, same
+//    bits), the NEXT stage's operands are requested BEFORE this stage's stores, and the wait for them is a counted
+//    vmcnt(#stores) that leaves the stores in flight.
 template <int TA, int TB, int WA, int WB, int VEC, bool SPL = false>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
   constexpr bool XVEC = VEC != 0, DVEC = VEC == 1;
@@ -979,7 +1024,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
   constexpr int STAGE = MS * LDX + MS * LDD;
   __shared__ float lds[2 * STAGE];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wa = wave / WB, wb = wave % WB;
   const int l31 = lane & 31, lhi = lane >> 5;
   // XCD-aware decode: the tiles of ONE row slab (same activations / gradients, different weight tiles) get consecutive
@@ -996,13 +1041,10 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
   const int mend = min(P.M, mbeg + P.Mper);
   const bool xform = (P.xs != nullptr);
   const bool two = (P.cA != nullptr);
-  // the workgroups of the first K-tile row also write the gradient operand they assemble anyway, dY = cA*g + cB*y + cC,
-  // to HBM (every (row, column) is staged by exactly one (bx, by_ = 0, bz)): the bwd-data GEMM of the layer then reads ONE
-  // tensor instead of two and has no operand transform (round 4)
-  // ... and they take turns: the gridDim.y workgroups that share a row slab (same bx, bz: they all assemble the same dY
-  // stages) each write every gridDim.y-th stage, so that no workgroup carries the whole store stream (first version, all
-  // stores on by_ == 0: the launch waited for those workgroups, +4.5 ms per step for 25 GB of stores)
-  const bool dy_on = (P.dyout != nullptr);
+  // 32 x 32 blocks of this wave's sub-tile that lie inside the K x N matrix (wave-uniform)
+  const int ia = max(0, min(TA, (P.K - kbase - wa * TA * 32 + 31) >> 5));
+  const int jb = max(0, min(TB, (P.N - nbase - wb * TB * 32 + 31) >> 5));
+  const bool wfull = (ia == TA) && (jb == TB);
 
   f32x16 acc[TA][TB];
 #pragma unroll
@@ -1012,88 +1054,109 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  // per-thread column positions are the same for every M stage: hoist coefficients and validity
-  f32x4 xs4[NX], xt4[NX], kA4[ND], kB4[ND], kC4[ND];
-  bool xok[NX][4], dok[ND][4];
-#pragma unroll
-  for (int i = 0; i < NX; i++) {
-    const int idx = tid + 256 * i;
-    const int k = kbase + (idx % (BKT / 4)) * 4;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      xok[i][j] = (k + j) < P.K;
-      const int kc = min(k + j, P.K - 1);
-      xs4[i][j] = xform ? P.xs[kc] : 1.f;
-      xt4[i][j] = xform ? P.xt[kc] : 0.f;
-    }
+  // per-column coefficient vectors of the tile (input transform of x; BatchNorm-backward affine of g, y) live in LDS — as
+  // hoisted registers they were 40-52 VGPRs of every instantiation (an occupancy step for the 128 x 96 / 128 x 128 tiles).
+  // A lane whose 16-byte piece lies beyond N works on a duplicate of the last valid column group (the requests clamp it
+  // there) and reads that group's coefficients, so that it assembles — and, in a store segment, stores — the same bits.
+  __shared__ __attribute__((aligned(16))) float cfx[2][BKT];
+  __shared__ __attribute__((aligned(16))) float cfd[3][BNT];
+  for (int c = tid; c < BKT; c += 256) {
+    const int kc = min(kbase + c, P.K - 1);
+    cfx[0][c] = xform ? P.xs[kc] : 1.f;
+    cfx[1][c] = xform ? P.xt[kc] : 0.f;
   }
-#pragma unroll
-  for (int i = 0; i < ND; i++) {
-    const int idx = tid + 256 * i;
-    const int col = nbase + (idx % (BNT / 4)) * 4;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      dok[i][j] = (col + j) < P.N;
-      const int cc = min(col + j, P.N - 1);
-      kA4[i][j] = two ? P.cA[cc] : 1.f;
-      kB4[i][j] = two ? P.cB[cc] : 0.f;
-      kC4[i][j] = two ? P.cC[cc] : 0.f;
-    }
+  for (int c = tid; c < BNT; c += 256) {
+    const int cc = min(nbase + c, P.N - 1);
+    cfd[0][c] = two ? P.cA[cc] : 1.f;
+    cfd[1][c] = two ? P.cB[cc] : 0.f;
+    cfd[2][c] = two ? P.cC[cc] : 0.f;
   }
+  __syncthreads();
 
   f32x4 rx[NX], rg[ND], ry[ND];
 
-  auto load_tiles = [&](int m0) {
+  // requests of the stage that starts at row m0 (all unconditional: clamped rows / columns / piece indices)
+  auto load_x = [&](int m0) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NX; i++) {
-      const int idx = tid + 256 * i;
-      if (NX * 256 == XQ || idx < XQ) {
-        const int mr = idx / (BKT / 4), kq = idx % (BKT / 4);
-        const int row = min(m0 + mr, P.M - 1), k = kbase + kq * 4;
-        if (XVEC) {
-          rx[i] = ld4(P.x + (size_t)row * P.ldx + min(k, P.K - 4));
-        } else {
+      const int idx = min(tid + 256 * i, XQ - 1);
+      const int mr = idx / (BKT / 4), kq = idx % (BKT / 4);
+      const int row = min(m0 + mr, P.M - 1), k = kbase + kq * 4;
+      if (XVEC) {
+        rx[i] = ld4(P.x + (size_t)row * P.ldx + min(k, P.K - 4));
+      } else {
 #pragma unroll
-          for (int j = 0; j < 4; j++) rx[i][j] = P.x[(size_t)row * P.ldx + min(k + j, P.K - 1)];
-        }
+        for (int j = 0; j < 4; j++) rx[i][j] = P.x[(size_t)row * P.ldx + min(k + j, P.K - 1)];
       }
     }
+  };
+  auto load_d = [&](int m0) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < ND; i++) {
-      const int idx = tid + 256 * i;
-      if (ND * 256 == DQ || idx < DQ) {
-        const int mr = idx / (BNT / 4), nq = idx % (BNT / 4);
-        const int row = min(m0 + mr, P.M - 1), col = nbase + nq * 4;
-        if (DVEC) {
-          const int cc = min(col, P.N - 4);
-          rg[i] = ld4(P.g + (size_t)row * P.ldg + cc);
-          if (two) ry[i] = ld4(P.y + (size_t)row * P.ldy + cc);
-        } else {
+      const int idx = min(tid + 256 * i, DQ - 1);
+      const int mr = idx / (BNT / 4), nq = idx % (BNT / 4);
+      const int row = min(m0 + mr, P.M - 1), col = nbase + nq * 4;
+      if (DVEC) {
+        const int cc = min(col, P.N - 4);
+        rg[i] = ld4(P.g + (size_t)row * P.ldg + cc);
+        if (two) ry[i] = ld4(P.y + (size_t)row * P.ldy + cc);
+      } else {
 #pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const int cc = min(col + j, P.N - 1);
-            rg[i][j] = P.g[(size_t)row * P.ldg + cc];
-            if (two) ry[i][j] = P.y[(size_t)row * P.ldy + cc];
-          }
+        for (int j = 0; j < 4; j++) {
+          const int cc = min(col + j, P.N - 1);
+          rg[i][j] = P.g[(size_t)row * P.ldg + cc];
+          if (two) ry[i][j] = P.y[(size_t)row * P.ldy + cc];
         }
       }
     }
   };
-
-  auto store_tiles = [&](int m0, float *Xs, float *Ds) {
-    const bool dy_owner = dy_on && (((m0 - mbeg) / MS) % (int)gridDim.y == by_);
+  // the loaded stage (rows m0 ..) -> MFMA operands in LDS [+ dY to HBM]; the requests of the stage at mnext are issued in
+  // between: behind the last use of the registers they land in, in front of this stage's stores
+  auto prepare = [&](int m0, int mnext, float *Xs, float *Ds, auto store_tag) __attribute__((always_inline)) {
+    constexpr bool STORE = decltype(store_tag)::value;
+    // x: transform -> LDS (not a vector-memory operation: it may sit anywhere), then its registers take the next stage's
 #pragma unroll
     for (int i = 0; i < NX; i++) {
       const int idx = tid + 256 * i;
-      if (NX * 256 == XQ || idx < XQ) {
-        const int mr = idx / (BKT / 4), kq = idx % (BKT / 4);
-        const bool rok = (m0 + mr) < mend;
-        f32x4 v = dl3_act4(xs4[i] * rx[i] + xt4[i], P.x_act);
+      const int mr = min(idx, XQ - 1) / (BKT / 4), kq = min(idx, XQ - 1) % (BKT / 4);
+      const bool rok = (m0 + mr) < mend;
+      const int kl = XVEC ? min(kbase + kq * 4, P.K - 4) - kbase : kq * 4;   // (the column group the load was clamped to)
+      f32x4 v = dl3_act4(ld4(&cfx[0][kl]) * rx[i] + ld4(&cfx[1][kl]), P.x_act);
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-          if (!(rok && xok[i][j])) v[j] = 0.f;
-        st4(&Xs[mr * LDX + kq * 4], v);
+      for (int j = 0; j < 4; j++)
+        if (!(rok && (kbase + kq * 4 + j) < P.K)) v[j] = 0.f;
+      if (NX * 256 == XQ || idx < XQ) st4(&Xs[mr * LDX + kq * 4], v);
+    }
+    f32x4 td[ND];
+#pragma unroll
+    for (int i = 0; i < ND; i++) {
+      const int nq_ = min(tid + 256 * i, DQ - 1) % (BNT / 4);
+      const int nl = DVEC ? min(nbase + nq_ * 4, P.N - 4) - nbase : nq_ * 4;
+      td[i] = ld4(&cfd[0][nl]) * rg[i] + ld4(&cfd[2][nl]);
+      if (two) td[i] += ld4(&cfd[1][nl]) * ry[i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    load_x(mnext);
+    load_d(mnext);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (STORE) {
+#pragma unroll
+      for (int i = 0; i < ND; i++) {
+        const int idx = min(tid + 256 * i, DQ - 1);
+        const int mr = idx / (BNT / 4), nq = idx % (BNT / 4);
+        if constexpr (DVEC) {
+          float *dp = P.dyout + (size_t)min(m0 + mr, P.M - 1) * P.lddy + min(nbase + nq * 4, P.N - 4);
+          st4_nt(dp, td[i]);
+        } else {
+          if (m0 + mr < mend) {
+            float *dp = P.dyout + (size_t)(m0 + mr) * P.lddy + nbase + nq * 4;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+              if ((nbase + nq * 4 + j) < P.N) dp[j] = td[i][j];
+          }
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int i = 0; i < ND; i++) {
@@ -1101,81 +1164,55 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
       if (ND * 256 == DQ || idx < DQ) {
         const int mr = idx / (BNT / 4), nq = idx % (BNT / 4);
         const bool rok = (m0 + mr) < mend;
-        f32x4 v = kA4[i] * rg[i] + kC4[i];
-        if (two) v += kB4[i] * ry[i];
-        if (dy_owner && rok) {
-          float *dp = P.dyout + (size_t)(m0 + mr) * P.lddy + nbase + nq * 4;
-          if (DVEC) {
-            if (dok[i][0]) st4_nt(dp, v);
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-              if (dok[i][j]) dp[j] = v[j];
-          }
-        }
+        f32x4 v = td[i];
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          if (!(rok && dok[i][j])) v[j] = 0.f;
+          if (!(rok && (nbase + nq * 4 + j) < P.N)) v[j] = 0.f;
         st4(&Ds[mr * LDD + nq * 4], v);
       }
     }
   };
 
-  DL3_T(long long tw_vm = 0; long long tw_bar = 0; int nst = 0; const long long tstart = clock64();)
-  if (mbeg < mend) {
-    load_tiles(mbeg);
-    store_tiles(mbeg, lds, lds + MS * LDX);
-    __syncthreads();
-    int stage = 0;
-    for (int m0 = mbeg; m0 < mend; m0 += MS, stage ^= 1) {
-      const float *Xs = lds + stage * STAGE;
-      const float *Ds = Xs + MS * LDX;
-      const bool more = (m0 + MS < mend);
-      if (more) load_tiles(m0 + MS);
-      if constexpr (SPL) {
-        u32x4 ah[TA], am[TA], al[TA];
+  // the MFMAs of one staged 16-row slice
+  auto mfma_stage = [&](const float *Xs, const float *Ds) __attribute__((always_inline)) {
+    if constexpr (SPL) {
+      u32x4 ah[TA], am[TA], al[TA];
+#pragma unroll
+      for (int i = 0; i < TA; i++) {
+        f32x4 v0, v1;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          v0[e] = Xs[(8 * lhi + e) * LDX + (wa * TA + i) * 32 + l31];
+          v1[e] = Xs[(8 * lhi + 4 + e) * LDX + (wa * TA + i) * 32 + l31];
+        }
+        split3(v0, v1, ah[i], am[i], al[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < TB; j++) {
+        f32x4 v0, v1;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          v0[e] = Ds[(8 * lhi + e) * LDD + (wb * TB + j) * 32 + l31];
+          v1[e] = Ds[(8 * lhi + 4 + e) * LDD + (wb * TB + j) * 32 + l31];
+        }
+        u32x4 bh_, bm_, bl_;
+        split3(v0, v1, bh_, bm_, bl_);
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, bh_), bm = __builtin_bit_cast(bf16x8, bm_),
+                     bl = __builtin_bit_cast(bf16x8, bl_);
 #pragma unroll
         for (int i = 0; i < TA; i++) {
-          f32x4 v0, v1;
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            v0[e] = Xs[(8 * lhi + e) * LDX + (wa * TA + i) * 32 + l31];
-            v1[e] = Xs[(8 * lhi + 4 + e) * LDX + (wa * TA + i) * 32 + l31];
-          }
-          split3(v0, v1, ah[i], am[i], al[i]);
+          const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[i]), xm = __builtin_bit_cast(bf16x8, am[i]),
+                       xl = __builtin_bit_cast(bf16x8, al[i]);
+          f32x16 c = acc[i][j];  // small terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bm, c, 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, c, 0, 0, 0);
         }
-#pragma unroll
-        for (int j = 0; j < TB; j++) {
-          f32x4 v0, v1;
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            v0[e] = Ds[(8 * lhi + e) * LDD + (wb * TB + j) * 32 + l31];
-            v1[e] = Ds[(8 * lhi + 4 + e) * LDD + (wb * TB + j) * 32 + l31];
-          }
-          u32x4 bh_, bm_, bl_;
-          split3(v0, v1, bh_, bm_, bl_);
-          const bf16x8 bh = __builtin_bit_cast(bf16x8, bh_), bm = __builtin_bit_cast(bf16x8, bm_),
-                       bl = __builtin_bit_cast(bf16x8, bl_);
-#pragma unroll
-          for (int i = 0; i < TA; i++) {
-            const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[i]), xm = __builtin_bit_cast(bf16x8, am[i]),
-                         xl = __builtin_bit_cast(bf16x8, al[i]);
-            f32x16 c = acc[i][j];  // small terms first
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bm, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bh, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bm, c, 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, c, 0, 0, 0);
-          }
-        }
-        if (more) {
-          float *Xn = lds + (stage ^ 1) * STAGE;
-          store_tiles(m0 + MS, Xn, Xn + MS * LDX);
-        }
-        __syncthreads();
-        continue;
       }
+    } else if (ia > 0 && jb > 0) {
       float af[2][TA], bf[2][TB];
 #pragma unroll
       for (int i = 0; i < TA; i++) af[0][i] = Xs[lhi * LDX + (wa * TA + i) * 32 + l31];
@@ -1196,15 +1233,43 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
           for (int j = 0; j < TB; j++)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
       }
-      if (more) {
-        float *Xn = lds + (stage ^ 1) * STAGE;
-        DL3_T(const long long w0 = clock64(); __builtin_amdgcn_s_waitcnt(0x0F70); tw_vm += clock64() - w0;)
-        store_tiles(m0 + MS, Xn, Xn + MS * LDX);
-      }
-      DL3_T(const long long w1 = clock64();)
-      __syncthreads();
-      DL3_T(tw_bar += clock64() - w1; nst++;)
     }
+  };
+
+  DL3_T(long long tw_vm = 0; long long tw_bar = 0; int nst = 0; const long long tstart = clock64();)
+  if (mbeg < mend) {
+    const int ns = (mend - mbeg + MS - 1) / MS;          // stages of this workgroup
+    const int mlast = mbeg + (ns - 1) * MS;              // (the last stage asks for itself again instead of for nothing)
+    // stages whose dY this workgroup stores: an even, contiguous share of the row slab's stages for each of the gridDim.y
+    // workgroups that stage the same dY
+    const int gy = (int)gridDim.y;
+    const int s_lo = P.dyout ? (int)((long)by_ * ns / gy) : ns, s_hi = P.dyout ? (int)((long)(by_ + 1) * ns / gy) : ns;
+    auto stage_x = [&](int t) { return lds + (t & 1) * STAGE; };
+    auto run = [&](int t0, int t1, auto store_tag) __attribute__((always_inline)) {
+      for (int t = t0; t < t1; ++t) {
+        mfma_stage(stage_x(t - 1), stage_x(t - 1) + MS * LDX);
+        DL3_T(const long long w0 = clock64(); __builtin_amdgcn_s_waitcnt(0x0F70); tw_vm += clock64() - w0;)
+        prepare(mbeg + t * MS, min(mbeg + (t + 1) * MS, mlast), stage_x(t), stage_x(t) + MS * LDX, store_tag);
+        DL3_T(const long long w1 = clock64();)
+        __syncthreads();
+        DL3_T(tw_bar += clock64() - w1; nst++;)
+      }
+    };
+    load_x(mbeg);
+    load_d(mbeg);
+    if (s_lo == 0 && s_hi > 0) prepare(mbeg, min(mbeg + MS, mlast), stage_x(0), stage_x(0) + MS * LDX, std::true_type{});
+    else prepare(mbeg, min(mbeg + MS, mlast), stage_x(0), stage_x(0) + MS * LDX, std::false_type{});
+    __syncthreads();
+    const int a = max(1, s_lo), b = max(a, s_hi);
+    run(1, min(a, ns), std::false_type{});
+    if (a < b) {
+      // (requests in flight at a loop's entry make its header the pessimistic merge of entry and back edge — every wait
+      // inside becomes vmcnt(0): wait once HERE, and the store segment's waits are counted ones)
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      run(a, b, std::true_type{});
+    }
+    run(b, ns, std::false_type{});
+    mfma_stage(stage_x(ns - 1), stage_x(ns - 1) + MS * LDX);
   }
 #ifdef DL3_PHASE_TIMING
   if (P.dbg && lane == 0) {
@@ -1300,6 +1365,8 @@ __global__ __launch_bounds__(256, OC) void pw_fwd_ws_kernel(GemmArgs P) {
   __shared__ float cf[2 * K];         // scale | shift of the input transform
   __shared__ float bs[NP];            // bias
   __shared__ float Cs[4 * 1024];      // per wave: one 32x32 block on its way out; at the end: the statistic fold
+  // gfx950 only: <4,6,3> keeps 41 KB per workgroup at 3 workgroups per CU (160 KB LDS); a 64 KB-LDS part would get one
+  static_assert(sizeof(float) * (K * NP + 2 * K + NP + 4 * 1024) * OC <= 160 * 1024, "weight-stationary kernel: OC workgroups do not fit a gfx950 CU's LDS");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -1466,6 +1533,9 @@ __global__ __launch_bounds__(256) void pw_ksplit32_kernel(GemmArgs P) {
   __shared__ float cf[(TWO ? 3 : 2) * KCS];
   __shared__ __attribute__((aligned(16))) float wbuf[4][2 * BQ];  // per wave: two weight tiles; later its TN accumulators
   static_assert(2 * BQ == 1024 * TN, "the reduction reuses the weight buffers");
+  // gfx950 only: TN = 5 holds 80 KB of weight tiles + up to 24 KB of coefficients in static LDS — inside the 160 KB of a
+  // CDNA4 CU, beyond the 64 KB of gfx90a / gfx942 (this library is built for gfx950 alone: csrc/Makefile)
+  static_assert(sizeof(float) * ((TWO ? 3 : 2) * KCS + 4 * 2 * BQ) <= 160 * 1024, "K-split kernel: static LDS exceeds a gfx950 CU's 160 KB");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
   const int ktiles = (P.K + KT - 1) / KT;
   const bool xform = (P.ka != nullptr);
@@ -1606,11 +1676,15 @@ __global__ __launch_bounds__(256) void pw_ksplit32_kernel(GemmArgs P) {
 
 // shapes and row counts the K-split kernel takes (DL3_KSPLIT=0: never, 1: without N <= 64; DL3_KSPLIT_ROWS: row limit, default 16 384)
 inline int ksplit_tn(int M, int K, int N) {
-  if (env_int("DL3_KSPLIT") == 0) return 0;
-  const int lim = env_int("DL3_KSPLIT_ROWS") > 0 ? env_int("DL3_KSPLIT_ROWS") : 16384;
+  // read ONCE (like ws_wanted / fused_rows_per_wg): the answer sizes the statistic partial buffers when a plan is lowered
+  // (dl3_pwconv_partials) and picks the kernel at every launch — the two must never disagree
+  static const int env = env_int("DL3_KSPLIT");
+  static const int env_rows = env_int("DL3_KSPLIT_ROWS");
+  if (env == 0) return 0;
+  const int lim = env_rows > 0 ? env_rows : 16384;
   if (M > lim || M < 1024 || K < 192 || K > DL3_STREAM_KMAX || K % 4 != 0 || N % 4 != 0) return 0;
   const int tn = dl3_cdiv(N, 32);
-  if (tn == 2 && env_int("DL3_KSPLIT") == 1) return 0;   // (DL3_KSPLIT=1: without the 64-wide outputs — tuning aid)
+  if (tn == 2 && env == 1) return 0;   // (DL3_KSPLIT=1: without the 64-wide outputs — tuning aid)
   // 64-, 96- and 160-wide outputs: the ones the 64-column-per-wave kernels pad (to 128, 128 and 256 columns)
   return (tn == 2 || tn == 3 || tn == 5) ? tn : 0;
 }
@@ -1765,6 +1839,30 @@ int gemm_grid_y(int M, int N, const GemmCfg &c) {
   return even;
 }
 
+// exact-width last column tile (pw_gemm_stream_kernel<1, 5, ..., JV = 3>): N = q * 160 + 96 with q >= 1 — the 128 x 160
+// configuration on everything but the last 96 columns.  DL3_GEMM_JV=0 switches it off (tuning aid / A-B).
+constexpr int kJvBlocks = 3;
+bool jv_shape(int N) {
+  static const int env = env_int("DL3_GEMM_JV");
+  return env != 0 && N > 160 && N % 160 == 32 * kJvBlocks;
+}
+// row slots per column tile: py_full for the 160-wide tiles, py_last for the 96-wide one, sized so that every workgroup
+// carries the same number of 32-column block-tiles (the narrow tile is 3/5 of a wide one: its workgroups walk 5/3 as many
+// row tiles).  Few row tiles: one workgroup per tile, as gemm_grid_y does.
+void jv_grid(int M, int N, int *py_full, int *py_last) {
+  const int mtiles = dl3_cdiv(M, 128), ntn = dl3_cdiv(N, 160);
+  const int pytot = env_int("DL3_GEMM_PY");
+  const int total = pytot > 0 ? pytot : (((long)mtiles * ntn >= 2048) ? 512 : DL3_GEMM_PY_DEFAULT);
+  int pf = (int)(total / ((ntn - 1) + (double)kJvBlocks / 5.0));
+  if (pf < 32) pf = 32;
+  if (pf >= mtiles) { *py_full = *py_last = mtiles; return; }
+  int pl = total - pf * (ntn - 1);
+  if (pl < 1) pl = 1;
+  if (pl > pf) pl = pf;
+  *py_full = pf;
+  *py_last = pl;
+}
+
 // split math (opt-in): device scratch for the packed weights of the launch in flight, one buffer per DEVICE.  Launches on
 // one stream are ordered, so one buffer serves them all — split-math launches of a device must not be issued from two
 // streams at once (the engine issues them on one stream, eagerly or under capture; the weight-gradient kernels, the
@@ -1861,6 +1959,21 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   }
   GemmCfg c = pick_gemm(A.M, A.K, A.N, two, stream, fwd);
   if (stream && pre_ok(A) && pre_wanted(A)) c = kGemmCfgs[4];
+  if (stream && !split_math() && jv_shape(A.N) && A.M >= 128 && !(c.id == 4 && pre_ok(A)) &&
+      dl3_cdiv(A.N, c.BN) * c.BN != A.N) {
+    // (only where every configuration pads: 736; 256 = 2 x 128 and 576 = 6 x 96 keep their exact tilings)
+    // 128 x 160 tiles + one exact 96-wide last column tile, balanced persistent grid
+    int pf, pl;
+    jv_grid(A.M, A.N, &pf, &pl);
+    A.mtiles = dl3_cdiv(A.M, 128);
+    A.py_last = pl;
+    DL3_T(A.dbg = g_phase_dbg;)
+    const dim3 grid(dl3_cdiv(A.N, 160), pf), blk(256);
+    if (two) hipLaunchKernelGGL((pw_gemm_stream_kernel<1, 5, true, 16, 0, 1, 0, kJvBlocks>), grid, blk, 0, st, A);
+    else if (fwd) hipLaunchKernelGGL((pw_gemm_stream_kernel<1, 5, false, DL3_STREAM_KT_FWD, 1, 1, 0, kJvBlocks>), grid, blk, 0, st, A);
+    else hipLaunchKernelGGL((pw_gemm_stream_kernel<1, 5, false, DL3_STREAM_KT_BWD1, 0, 1, 0, kJvBlocks>), grid, blk, 0, st, A);
+    return pf;
+  }
   A.mtiles = dl3_cdiv(A.M, c.BM);
   DL3_T(A.dbg = g_phase_dbg;)
   dim3 grid(dl3_cdiv(A.N, c.BN), gemm_grid_y(A.M, A.N, c));
@@ -2043,6 +2156,11 @@ extern "C" int dl3_pwconv_partials(int M, int K, int N) {
   if (ksplit_tn(M, K, N)) {  // the K-split kernel of the small batches: one row per 32-row tile
     const int q = dl3_cdiv(M, 32);
     p = q > p ? q : p;
+  }
+  if (jv_shape(N) && M >= 128) {  // exact-width last column tile: its own balanced grid (run_gemm)
+    int pf, pl;
+    jv_grid(M, N, &pf, &pl);
+    p = pf > p ? pf : p;
   }
   if (N % 96 == 0) {  // the prefetching bwd-data variant overrides the choice with the 128x96 tile (run_gemm)
     const int q = gemm_grid_y(M, N, kGemmCfgs[4]);

@@ -41,6 +41,21 @@ BN_VARIANCE = {
 }
 
 
+# tf.nn.fused_batch_norm (tensorflow/python/ops/nn_impl.py, TF 1.13) raises every epsilon to at least 1.001e-5 before the
+# kernel sees it, and Keras 2.2.4 sends every 4-D BatchNormalization through it in both phases (training:
+# K.normalize_batch_in_training -> _fused_normalize_batch_in_training; inference: K.batch_normalization ->
+# fused_batch_norm(is_training=False)).  The 1e-5 layers of the ASPP / decoder (deeplabv3p.py:379,386,393-399,408,422-423,
+# 427-429) therefore normalise with 1.001e-5.  The engine applies the floor where the Python wrapper does — in front of the
+# kernels (dl3_bn_finalize / _direct / _frozen / _frozen_centered take the epsilon they are given); the moving-variance
+# factor of BatchNormalization.call keeps the layer's own epsilon.
+FUSED_BN_MIN_EPSILON = 1.001e-5
+
+
+def fused_bn_epsilon(eps):
+    eps = float(eps)
+    return eps if eps > FUSED_BN_MIN_EPSILON else FUSED_BN_MIN_EPSILON
+
+
 # BatchNorm over at most this many rows takes its batch statistics straight from the tensor (dl3_bn_finalize_direct)
 SMALL_BN_ROWS = 4096
 
@@ -624,7 +639,7 @@ class Engine:
             if v.buf.M <= SMALL_BN_ROWS:
                 # few rows (the image-pooling branch: one row per image): two-pass statistics straight from the tensor
                 self.op(self.ops_fwd, "dl3_bn_finalize_direct", v.p(), v.ld, v.buf.M, C,
-                        self.wptr(n + "/gamma:0"), self.wptr(n + "/beta:0"), l.cfg["eps"], l.cfg["momentum"],
+                        self.wptr(n + "/gamma:0"), self.wptr(n + "/beta:0"), fused_bn_epsilon(l.cfg["eps"]), l.cfg["momentum"],
                         BN_VARIANCE[self.bn_variance](float(v.buf.M), float(l.cfg["eps"])),
                         v.buf.vptr(V_SCALE, v.off), v.buf.vptr(V_SHIFT, v.off), v.buf.vptr(V_MEAN, v.off),
                         v.buf.vptr(V_INVSTD, v.off), self.wptr(n + "/moving_mean:0") if upd else None,
@@ -633,7 +648,7 @@ class Engine:
                 return
             self.bn_sites.append((len(self.ops_fwd), l, v.buf, v.off, C, unit))  # (index in ops_fwd, ...): diagnostics
             self.op(self.ops_fwd, "dl3_bn_finalize", ptr(unit.stat), unit.P, C, C, float(v.buf.M),
-                    self.wptr(n + "/gamma:0"), self.wptr(n + "/beta:0"), l.cfg["eps"], l.cfg["momentum"],
+                    self.wptr(n + "/gamma:0"), self.wptr(n + "/beta:0"), fused_bn_epsilon(l.cfg["eps"]), l.cfg["momentum"],
                     BN_VARIANCE[self.bn_variance](float(v.buf.M), float(l.cfg["eps"])),
                     v.buf.vptr(V_SCALE, v.off), v.buf.vptr(V_SHIFT, v.off), v.buf.vptr(V_MEAN, v.off),
                     v.buf.vptr(V_INVSTD, v.off), self.wptr(n + "/moving_mean:0") if upd else None,
@@ -645,13 +660,13 @@ class Engine:
             # element (dl3_bn_frozen_centered)
             negm = v.buf.vptr(V_NEGMEAN, v.off)
             self.op(self.ops_prep, "dl3_bn_frozen_centered", self.wptr(n + "/gamma:0"), self.wptr(n + "/beta:0"),
-                    self.wptr(n + "/moving_mean:0"), self.wptr(n + "/moving_variance:0"), l.cfg["eps"], C,
+                    self.wptr(n + "/moving_mean:0"), self.wptr(n + "/moving_variance:0"), fused_bn_epsilon(l.cfg["eps"]), C,
                     v.buf.vptr(V_SCALE, v.off), v.buf.vptr(V_SHIFT, v.off), v.buf.vptr(V_MEAN, v.off),
                     v.buf.vptr(V_INVSTD, v.off), negm)
             unit.set_output_offset(negm)   # (the buffer holds y - mean from here on: Buf.centred)
         else:
             self.op(self.ops_prep, "dl3_bn_frozen", self.wptr(n + "/gamma:0"), self.wptr(n + "/beta:0"),
-                    self.wptr(n + "/moving_mean:0"), self.wptr(n + "/moving_variance:0"), l.cfg["eps"], C,
+                    self.wptr(n + "/moving_mean:0"), self.wptr(n + "/moving_variance:0"), fused_bn_epsilon(l.cfg["eps"]), C,
                     v.buf.vptr(V_SCALE, v.off), v.buf.vptr(V_SHIFT, v.off), v.buf.vptr(V_MEAN, v.off),
                     v.buf.vptr(V_INVSTD, v.off))
         self.views[id(l.output)] = v.derive(aff=True)
@@ -1288,10 +1303,17 @@ class Engine:
         else:
             self.run_ops(self.ops_bwd)
 
-    def adam(self, opt=None, grad_scale=1.0, norm=False):
+    def adam(self, opt=None, grad_scale=1.0, norm=None):
         """Keras Adam with decay (notebook cell 2): lr_t = lr/(1+decay*it) * sqrt(1-b2^t)/(1-b1^t).
-        norm (data-parallel engines): the gradient scale is finished on the device, normaliser / count_all from the arena
-        tail (dl3_adam_step_norm); grad_scale is ignored."""
+        norm (the default on data-parallel / external_nnz engines, and the only valid choice there): the gradient scale is
+        finished on the device, normaliser / count_all from the arena tail (dl3_adam_step_norm); grad_scale is ignored.
+        An external_nnz engine's loss kernel divides by the FIXED c0, so adam(opt, scale) without norm would silently
+        apply grad * scale / c0 instead of grad / count_all: refused."""
+        if norm is None:
+            norm = self.external_nnz
+        if self.external_nnz and not norm:
+            raise ValueError("Engine.adam(norm=False) on an external_nnz (data-parallel) engine: its gradients are "
+                             "normalised by a fixed constant and must be finished by dl3_adam_step_norm")
         o = dict(lr=7e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-8, decay=1e-6)
         o.update(opt or {})
         it = self.iteration

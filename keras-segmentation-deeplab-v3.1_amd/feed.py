@@ -44,9 +44,32 @@ class BatchFeeder:
         self.bytes_per_batch = self.nx + self.M * (1 if label_dtype == np.uint8 else 4)
 
     @staticmethod
-    def _pinned(a, like):
+    def _checked(a, like, what):
+        """images must BE bytes and label maps integers: a float array (the reference generator's own X / Y tensors,
+        utils.py:360-402 — already normalised or augmented) would be truncated or wrapped by the narrowing copy into the
+        uint8 / int32 slot instead of rejected"""
+        dt = a.dtype if torch.is_tensor(a) else np.asarray(a).dtype
+        name = str(dt).replace("torch.", "")
+        if what == "images":
+            if name != "uint8":
+                raise ValueError("device feed: images must be uint8 [B,H,W,3] (decoded pixels 0..255), not %s — hand float "
+                                 "tensors to train_on_batch / fit_generator(device_feed=False) instead" % name)
+            return
+        if name not in ("uint8", "int8", "int16", "int32", "int64", "uint16", "uint32", "uint64"):
+            raise ValueError("device feed: label maps must be integers (uint8 / int32 class ids, 255 = void), not %s" % name)
+        if like.dtype == torch.uint8 and name != "uint8":
+            raise ValueError("device feed: this feeder was built for uint8 label maps, got %s" % name)
+        if name in ("int64", "uint32", "uint64"):   # wider than the int32 slot: range-checked before narrowing
+            n = a.numel() if torch.is_tensor(a) else np.asarray(a).size
+            lo, hi = (int(a.min()), int(a.max())) if n else (0, 0)
+            if lo < -2 ** 31 or hi >= 2 ** 31:
+                raise ValueError("device feed: label values %d..%d do not fit the int32 slot" % (lo, hi))
+
+    @classmethod
+    def _pinned(cls, a, like, what="labels"):
         """a as a flat host tensor of like's dtype; pinned tensors pass through untouched (zero copy), anything else is
         copied into the slot's own pinned buffer"""
+        cls._checked(a, like, what)
         if torch.is_tensor(a):
             t = a.reshape(-1)
             if t.is_pinned() and t.dtype == like.dtype:
@@ -60,7 +83,7 @@ class BatchFeeder:
         """enqueue batch (images uint8 [B,H,W,3], labels [B,H,W] or [B,HW]) for `slot` on the copy stream"""
         if self._used[slot]:
             self.ready[slot].synchronize()   # (the slot's previous H2D copy, two steps old, has left its pinned buffer)
-        hx, hl = self._pinned(images, self.hx[slot]), self._pinned(labels, self.hl[slot])
+        hx, hl = self._pinned(images, self.hx[slot], "images"), self._pinned(labels, self.hl[slot], "labels")
         assert hx.numel() == self.nx and hl.numel() == self.M, (hx.numel(), self.nx, hl.numel(), self.M)
         with torch.cuda.stream(self.copy_stream):
             if self._used[slot]:

@@ -473,15 +473,27 @@ class Model:
         self._compile_gen = getattr(self, "_compile_gen", 0) + 1
         self._collected_trainable = {l.name: bool(l.trainable) for l in self.layers}
         self._update_flags = None   # frozen at the first training step after this compile()
-        self._train_eng = None      # a new train function starts from fresh optimizer slots
+        # a new train function starts from fresh optimizer slots (Keras re-creates m / v in get_updates) — but
+        # `optimizer.iterations` is a variable of the OPTIMIZER OBJECT: compiling again with the same Adam instance (the
+        # notebook's fine-tuning recompile) keeps counting, so the lr decay and the bias-correction exponent continue
+        # (ADVICE r5).  A new object, a dict or a string starts at 0.
+        prev, prev_obj = self._train_eng, getattr(self, "_opt_object", None)
+        keep = prev is not None and optimizer is not None and optimizer is prev_obj and not isinstance(optimizer, (dict, str))
+        self._carry_iterations = (int(prev.iteration), prev.drop_step.clone()) if keep else None
+        self._opt_object = optimizer
+        self._train_eng = None
 
-    def distribute(self, dp=None):
+    def distribute(self, dp=None, strict=True):
         """Per-image data parallelism for train_on_batch / fit: this process is one of WORLD_SIZE (one per GPU, launched
-        by torch.distributed.run); every call hands over the GLOBAL batch, each rank trains on its contiguous shard and
-        the gradients are averaged with one RCCL all-reduce (parallel.DataParallel).  Stands in for
-        keras.utils.multi_gpu_model (utils.py:209-211), whose towers likewise keep per-replica BatchNorm statistics."""
+        by torch.distributed.run); every call hands over the GLOBAL batch (or, with global_batch=False, this rank's own
+        shard), each rank trains on its contiguous shard and the gradients are summed with one RCCL all-reduce
+        (parallel.DataParallel).  Stands in for keras.utils.multi_gpu_model (utils.py:209-211), whose towers likewise keep
+        per-replica BatchNorm statistics.
+        strict (default): an RCCL communicator that cannot be brought up RAISES — a silent fall-back to gloo stages every
+        gradient exchange through host memory (10-100x slower); strict=False, or DL3_DIST_BACKEND=gloo asked for explicitly,
+        keeps the warning-and-gloo behaviour the functional tests use."""
         from .parallel import DataParallel
-        self._dp = dp if dp is not None else DataParallel()
+        self._dp = dp if dp is not None else DataParallel(strict=strict)
         self._dp_synced = False
         return self
 
@@ -528,6 +540,14 @@ class Model:
             prev = self._train_eng
             if prev is not None and prev is not eng:
                 eng.adopt_optimizer_state(prev)  # e.g. the last, smaller batch of an epoch keeps the same Adam
+            elif prev is None and getattr(self, "_carry_iterations", None) is not None:
+                # first train function after a compile() that re-used the optimizer object: fresh moments, same clock
+                it, drop = self._carry_iterations
+                eng.iteration = it
+                eng.adam_m.zero_()
+                eng.adam_v.zero_()
+                eng.drop_step.copy_(drop)
+                self._carry_iterations = None
             self._train_eng = eng
         while len(self._engines) > self.MAX_ENGINES:
             k0 = next(iter(self._engines))
@@ -601,33 +621,46 @@ class Model:
         counts = np.concatenate(counts, 0)
         return [num / den, U.Jaccard_from_counts(counts), U.accuracy_from_counts(counts)]
 
-    def train_on_batch(self, x, y, sample_weight=None, lazy_loss=False, **engine_kw):
+    def _dp_active(self):
+        dp = self._dp
+        return dp is not None and (dp.world > 1 or dp.comm is not None)
+
+    def _dp_sync_weights(self, eng):
+        """identical weights and moving statistics on every rank before the first data-parallel step"""
+        if not self._dp_synced:
+            self._dp.broadcast(eng.params)
+            self._dp.broadcast(eng.state)
+            eng.dirty = True
+            self._dp_synced = True
+
+    def train_on_batch(self, x, y, sample_weight=None, lazy_loss=False, global_batch=True, **engine_kw):
         """keras Model.train_on_batch; lazy_loss=True returns an engine.LazyLoss (float() reads it) instead of stalling
-        the stream for one scalar every step — fit / fit_generator use it and read once per epoch"""
+        the stream for one scalar every step — fit / fit_generator use it and read once per epoch.
+        Under distribute(): global_batch=True (Keras' multi_gpu_model contract, utils.py:209-211) — every rank is handed
+        the whole batch and keeps its contiguous shard; global_batch=False — (x, y, sample_weight) ARE this rank's shard
+        (a generator sharded by rank: nothing redundant is built or copied on the host)."""
         dp = self._dp
         # the data-parallel step also runs for a communicator of ONE rank (dp.comm set): every launch of the N-rank step —
-        # the one-float count all-reduce in front of the hipGraph replay, the arena all-reduce behind it — on one GPU
+        # the hipGraph replay, the ONE all-reduce of the arena (gradients + the shard's count and loss sum) behind it, Adam
+        # finishing the scale on the device — on one GPU
         multi = dp is not None and (dp.world > 1 or dp.comm is not None)
         if multi:
             n = x.shape[0]
-            if n < dp.world:
+            if global_batch and n < dp.world:
                 raise ValueError("global batch of %d images cannot be split over %d ranks" % (n, dp.world))
             # a ragged batch (the last one of a Sequence) gives its remainder to the last rank, like the reference's
             # multi_gpu_model towers; the loss is normalised by the GLOBAL count(w != 0) (Engine.train_step)
-            lo, hi = dp.shard(n)
-            x, y = x[lo:hi], y[lo:hi]
-            if sample_weight is not None:
-                sample_weight = sample_weight[lo:hi]
+            if global_batch:
+                lo, hi = dp.shard(n)
+                x, y = x[lo:hi], y[lo:hi]
+                if sample_weight is not None:
+                    sample_weight = sample_weight[lo:hi]
             engine_kw = dict(engine_kw, external_nnz=True)
         eng = self._engine(x.shape[0], True, **engine_kw)
         opt = (self._compiled or {}).get("optimizer") or {}
         if not multi:
             return eng.train_step(x, y, sample_weight, opt, lazy=lazy_loss)
-        if not self._dp_synced:  # identical weights and moving statistics on every rank before the first step
-            dp.broadcast(eng.params)
-            dp.broadcast(eng.state)
-            eng.dirty = True
-            self._dp_synced = True
+        self._dp_sync_weights(eng)
         # sum_all(l*w) / count_all(w != 0), from the arena tail the one all-reduce summed: the same number on every rank
         return eng.train_step(x, y, sample_weight, opt, comm=dp, lazy=lazy_loss)
 
@@ -654,17 +687,21 @@ class Model:
                 hist.append(self.train_on_batch(x[i:i + batch_size], y[i:i + batch_size], sw, lazy_loss=True))
         return [float(l) for l in hist]
 
-    def fit_generator(self, generator, steps_per_epoch=None, epochs=1, verbose=0, device_feed=False, n_classes=None, **kw):
+    def fit_generator(self, generator, steps_per_epoch=None, epochs=1, verbose=0, device_feed=False, n_classes=None,
+                      global_batch=True, **kw):
         """Minimal Model.fit_generator (utils.py:233): generator yields (X, Y, {'pred_mask': SW}) or (X, Y, SW).
         device_feed=True (not in Keras): the generator yields (uint8 images [B,H,W,3], raw label maps [B,H,W] uint8 / int32)
         — what cv2 decodes, before SegmentationGenerator.__getitem__ turns it into float tensors (utils.py:375-402): the
         batch crosses PCIe as bytes on a copy stream while the previous step runs, and X / Y / SW are produced on the device
-        (feed.BatchFeeder: widening copy + dl3_prepare_targets)."""
+        (feed.BatchFeeder: widening copy + dl3_prepare_targets).
+        Under distribute() (utils.py:209-211 + :231-241): global_batch=True — the generator yields the GLOBAL batch and each
+        rank stages only its contiguous shard (rows dp.shard(n)) — or global_batch=False — the generator is already sharded
+        by rank (e.g. `idx[rank::world]`) and yields this rank's images only.  Either way only the shard crosses PCIe."""
         self._check_fit_kw(kw)
         hist = []
         steps = steps_per_epoch or len(generator)
         if device_feed:
-            return self._fit_device_feed(generator, steps, epochs, n_classes)
+            return self._fit_device_feed(generator, steps, epochs, n_classes, global_batch)
         for _ in range(epochs):
             for i in range(steps):
                 item = generator[i] if hasattr(generator, "__getitem__") else next(generator)
@@ -672,16 +709,16 @@ class Model:
                 SW = item[2] if len(item) > 2 else None
                 if isinstance(SW, dict):
                     SW = list(SW.values())[0]
-                hist.append(self.train_on_batch(X, Y, SW, lazy_loss=True))
+                hist.append(self.train_on_batch(X, Y, SW, lazy_loss=True, global_batch=global_batch))
             hist = [float(l) for l in hist]   # one read per epoch
             if hasattr(generator, "on_epoch_end"):
                 generator.on_epoch_end()
         return hist
 
-    def _fit_device_feed(self, generator, steps, epochs, n_classes):
+    def _fit_device_feed(self, generator, steps, epochs, n_classes, global_batch=True):
         from .feed import BatchFeeder
-        if self._dp is not None and (self._dp.world > 1 or self._dp.comm is not None):
-            raise NotImplementedError("device_feed under Model.distribute(): shard the generator per rank instead")
+        dp = self._dp if self._dp_active() else None
+        ekw = dict(external_nnz=True) if dp is not None else {}
         opt = (self._compiled or {}).get("optimizer") or {}
         C = int(n_classes if n_classes is not None else self.output.shape[-1])
         hist, feeders = [], {}
@@ -689,13 +726,23 @@ class Model:
             def batches():
                 for i in range(steps):
                     item = generator[i] if hasattr(generator, "__getitem__") else next(generator)
-                    yield np.asarray(item[0]), np.asarray(item[1])
+                    X, L = np.asarray(item[0]), np.asarray(item[1])
+                    if dp is not None and global_batch:
+                        # the rank's contiguous shard of the global batch (the remainder of a batch that does not divide goes
+                        # to the last rank, like multi_gpu_model's last tower): only these rows are staged and copied
+                        if X.shape[0] < dp.world:
+                            raise ValueError("global batch of %d images cannot be split over %d ranks" % (X.shape[0], dp.world))
+                        lo, hi = dp.shard(X.shape[0])
+                        X, L = X[lo:hi], L[lo:hi]
+                    yield X, L
             losses = []
             it = iter(batches())
             first = next(it, None)
             if first is None:
                 break
-            eng = self._engine(first[0].shape[0], True)
+            eng = self._engine(first[0].shape[0], True, **ekw)
+            if dp is not None:
+                self._dp_sync_weights(eng)
             key = (id(eng), first[1].dtype.str)
             if key not in feeders:
                 feeders[key] = BatchFeeder(eng, C, np.uint8 if first[1].dtype == np.uint8 else np.int32)
@@ -709,7 +756,11 @@ class Model:
 
             def step():
                 eng.fwd_bwd()
-                eng.adam(opt)
+                if dp is not None:
+                    # ONE all-reduce of the arena (gradients + the shard's count(w != 0) and loss sum) behind the replayed
+                    # graph, the scale finished on the device (Engine.train_step does the same for host-array batches)
+                    dp.allreduce_grads(eng.grads)
+                eng.adam(opt)   # (norm defaults to the engine's external_nnz)
                 losses.append(eng.loss_handle())
 
             feeders[key].run(chain(), step)

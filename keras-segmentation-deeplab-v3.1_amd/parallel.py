@@ -26,7 +26,12 @@ import torch.distributed as dist
 
 
 class DataParallel:
-    def __init__(self, backend=None, device=None):
+    def __init__(self, backend=None, device=None, strict=None):
+        # strict: a failed RCCL bring-up raises instead of falling back to gloo (None: DL3_DIST_STRICT=1; Model.distribute()
+        # passes True — an explicit DL3_DIST_BACKEND=gloo / backend="gloo" is not a fall-back and is always honoured)
+        self.strict = (os.environ.get("DL3_DIST_STRICT", "0") == "1") if strict is None else bool(strict)
+        if os.environ.get("DL3_DIST_STRICT") == "0":
+            self.strict = False
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -67,8 +72,9 @@ class DataParallel:
             return
         if rc == 0:
             L.dl3_comm_destroy(handle)
-        if os.environ.get("DL3_DIST_STRICT", "0") == "1":
-            capi.check(rc or 1, "dl3_comm_init (on some rank)")
+        if self.strict:
+            capi.check(rc or 1, "dl3_comm_init (on some rank; strict data plane: no gloo fall-back — "
+                       "Model.distribute(strict=False) or DL3_DIST_STRICT=0 allows it)")
         import warnings
         warnings.warn("dl3_comm_init failed on at least one rank (%s): gradients will be exchanged over gloo through "
                       "host memory, NOT over RCCL/xGMI — expect the exchange to dominate small steps"

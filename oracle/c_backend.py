@@ -124,7 +124,8 @@ def batchnorm(x, gamma, beta, mmean, mvar, eps, training, momentum=0.99, tape=No
     M = x.size // C
     y, xhat = np.empty_like(x), np.empty_like(x)
     mean, var, invstd = np.empty(C), np.empty(C), np.empty(C)
-    getattr(lib(), "dl3ops_bn_train_fwd_" + sfx)(_p(x), _p(gm), _p(bt), creal(eps), _p(y), _p(xhat), _p(mean), _p(var),
+    # (the epsilon floor of tf.nn.fused_batch_norm is applied here, on the graph side: the C operator takes what it is given)
+    getattr(lib(), "dl3ops_bn_train_fwd_" + sfx)(_p(x), _p(gm), _p(bt), creal(O.fused_bn_epsilon(eps)), _p(y), _p(xhat), _p(mean), _p(var),
                                                  _p(invstd), *_L(M, C))
     if stats_out is not None:  # the moving-average convention is dl3_oracle's (Keras 2.2.4 on TF 1.13)
         unb = var * M / (M - 1) if M > 1 else var

@@ -167,9 +167,24 @@ def conv2d(x, w, stride, pad_t, pad_l, Ho, Wo, bias=None, tape=None):
     return _rec(tape, y, ins, bwd)
 
 
+# [TF-semantics] tensorflow/python/ops/nn_impl.py fused_batch_norm (TF 1.13): `min_epsilon = 1.001e-5;
+# epsilon = epsilon if epsilon > min_epsilon else min_epsilon` (a cuDNN requirement the Python wrapper applies on every
+# device).  Keras 2.2.4 reaches it for every 4-D NHWC BatchNormalization, in both phases: tensorflow_backend.py
+# normalize_batch_in_training -> _fused_normalize_batch_in_training (training) and batch_normalization ->
+# tf.nn.fused_batch_norm(is_training=False) (inference).  It only bites the 1e-5 layers of the ASPP / decoder
+# (deeplabv3p.py:379,386,393-399,408,422-423,427-429): 1e-5 -> 1.001e-5.  The moving-variance factor of
+# BatchNormalization.call uses the layer's own `self.epsilon`, un-floored.
+TF_FUSED_BN_MIN_EPSILON = 1.001e-5
+
+
+def fused_bn_epsilon(eps):
+    """the epsilon tf.nn.fused_batch_norm normalises with (see TF_FUSED_BN_MIN_EPSILON)"""
+    return eps if eps > TF_FUSED_BN_MIN_EPSILON else TF_FUSED_BN_MIN_EPSILON
+
+
 def batchnorm(x, gamma, beta, mmean, mvar, eps, training, momentum=0.99, tape=None, stats_out=None):
     """BatchNormalization over the last axis.
-    inference: gamma*(x-mm)/sqrt(mv+eps)+beta.
+    inference: gamma*(x-mm)/sqrt(mv+eps_f)+beta, eps_f = fused_bn_epsilon(eps).
     training [TF-semantics FusedBatchNorm]: biased batch variance over (N,H,W) for the
     normalisation; moving = m*moving + (1-m)*batch.  The variance that enters the moving average, in the reference's
     environment (Keras 2.2.4 on TF 1.13): tf.nn.fused_batch_norm returns the Bessel-corrected batch
@@ -182,7 +197,7 @@ def batchnorm(x, gamma, beta, mmean, mvar, eps, training, momentum=0.99, tape=No
         M = x.size // x.shape[-1]
         mean = x.mean(axis=axes, dtype=np.float64)
         var = ((x.astype(np.float64) - mean) ** 2).mean(axis=axes)
-        invstd = 1.0 / np.sqrt(var + eps)
+        invstd = 1.0 / np.sqrt(var + fused_bn_epsilon(eps))
         xhat = ((x - mean) * invstd).astype(x.dtype)
         y = (xhat * gamma + beta).astype(x.dtype)
         if stats_out is not None:
@@ -201,7 +216,7 @@ def batchnorm(x, gamma, beta, mmean, mvar, eps, training, momentum=0.99, tape=No
             return dx.astype(x.dtype), dgamma.astype(x.dtype), dbeta.astype(x.dtype)
 
         return _rec(tape, y, (x, gamma, beta), bwd)
-    invstd = 1.0 / np.sqrt(mvar.astype(np.float64) + eps)
+    invstd = 1.0 / np.sqrt(mvar.astype(np.float64) + fused_bn_epsilon(eps))
     xhat = ((x - mmean) * invstd).astype(x.dtype)
     y = (xhat * gamma + beta).astype(x.dtype)
 

@@ -18,6 +18,13 @@ import torch.nn.functional as F
 
 
 
+def _fused_eps(eps):
+    """[TF-semantics] tf.nn.fused_batch_norm (nn_impl.py, TF 1.13) never normalises with an epsilon below 1.001e-5; Keras
+    2.2.4 runs every 4-D BatchNormalization through it in both phases (own restatement: this file shares no code with
+    dl3_oracle.py)"""
+    return max(float(eps), 1.001e-5)
+
+
 def _same(size, k, s, r):
     """[TF-semantics] padding='SAME' (tensorflow/core/framework/common_shape_fns.cc GetWindowedOutputSize):
     the output has ceil(size/s) positions, the input is padded just enough for the last window to fit and the
@@ -121,8 +128,8 @@ class Ref:
             with torch.no_grad():
                 self.batch_stats[name] = (x.mean(dim=(0, 2, 3)).numpy(), x.var(dim=(0, 2, 3), unbiased=False).numpy())
                 self.bn_meta[name] = (eps, x.shape[0] * x.shape[2] * x.shape[3])
-            return F.batch_norm(x, None, None, g, b, True, 0.0, eps)
-        y = F.batch_norm(x, mm, mv, g, b, False, 0.0, eps)
+            return F.batch_norm(x, None, None, g, b, True, 0.0, _fused_eps(eps))
+        y = F.batch_norm(x, mm, mv, g, b, False, 0.0, _fused_eps(eps))
         if self.record is not None:
             self.record[name] = y.detach().permute(0, 2, 3, 1).numpy().copy()
         return y

@@ -394,8 +394,9 @@ def _batch_statistics_check(model, Bbig, x, labels, sw):
             var, mean = torch.var_mean(t.double(), dim=0, unbiased=False)
             got_m = buf.vec[V_MEAN, off:off + C].double()
             got_s = buf.vec[V_INVSTD, off:off + C].double()
-            ref_s = 1.0 / torch.sqrt(var + bn.cfg["eps"])
-            spread = torch.sqrt(var + bn.cfg["eps"])
+            eps_f = max(bn.cfg["eps"], 1.001e-5)   # tf.nn.fused_batch_norm's epsilon floor (engine.fused_bn_epsilon)
+            ref_s = 1.0 / torch.sqrt(var + eps_f)
+            spread = torch.sqrt(var + eps_f)
             worst_m = max(worst_m, float(((got_m - mean).abs() / spread).max()))
             worst_s = max(worst_s, float(((got_s - ref_s).abs() / ref_s).max()))
             n += 1

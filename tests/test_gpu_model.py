@@ -471,6 +471,20 @@ def test_single_image_batch_statistics_trap():
     assert np.isfinite(eng.grads.cpu().numpy()).all()
     assert np.abs(eng.grad_of("image_pooling/kernel:0")).max() < 1e-6
     assert np.abs(eng.grad_of("aspp0/kernel:0")).max() > 1e-6
+    # ... and with the epsilon tf.nn.fused_batch_norm actually uses (engine.fused_bn_epsilon: never below 1.001e-5): at
+    # variance 0 the layer's 1 / sigma is 1 / sqrt(1.001e-5) and its output is beta exactly
+    from dl3_amd.engine import V_INVSTD, V_SCALE, V_SHIFT, V_MEAN
+    bufs = [(b, off, C) for b in eng.bufs for bn, off, C in b.bns if bn.name == "image_pooling_BN"]
+    assert len(bufs) == 1
+    b, off, C = bufs[0]
+    inv = b.vec[V_INVSTD, off:off + C].cpu().numpy()
+    want = np.float32(1.0 / np.sqrt(np.float64(np.float32(1.001e-5))))
+    assert np.allclose(inv, want, rtol=2e-6), (inv[:4], want)
+    assert abs(float(want) * np.sqrt(1e-5) - 1.0) > 4e-4   # (1 / sqrt(1e-5) would be 5e-4 away)
+    y = b.t.view(b.M, b.ld)[:, off:off + C].cpu().numpy()
+    out = y * b.vec[V_SCALE, off:off + C].cpu().numpy() + b.vec[V_SHIFT, off:off + C].cpu().numpy()
+    beta = model.get_layer("image_pooling_BN").weights["image_pooling_BN/beta:0"]
+    assert np.allclose(out, beta[None, :], atol=1e-3 * max(1.0, float(np.abs(beta).max())))
 
 
 def test_inference_graph_replay_matches_eager():
@@ -727,6 +741,34 @@ def test_compile_accepts_the_references_adam_object():
         outs.append((losses, model._active.params.cpu().numpy().copy()))
     assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
     assert outs[0][0][-1] < outs[0][0][0]
+
+
+def test_recompile_with_the_same_adam_object_keeps_its_iterations():
+    """Keras 2.2.4: `optimizer.iterations` belongs to the optimizer OBJECT — compiling again with the same Adam instance (the
+    notebook's fine-tuning recompile) re-creates the m / v slots but keeps counting, so lr decay and the bias-correction
+    exponent continue; a new object starts at 0."""
+    from dl3_amd.optimizers import Adam
+    rng = np.random.default_rng(14)
+    x = rng.integers(0, 256, (2, 64, 64, 3)).astype(np.float32)
+    y = rng.integers(0, 3, (2, 64 * 64, 1)).astype(np.float32)
+    model, params = _build(input_shape=(64, 64, 3), classes=3)
+    _load(model, params)
+    opt = Adam(lr=7e-4, epsilon=1e-8, decay=1e-2)
+    model.compile(optimizer=opt)
+    for _ in range(3):
+        model.train_on_batch(x, y, dropout=False)
+    e1 = model._active
+    assert e1.iteration == 3 and float(e1.adam_m.abs().max()) > 0
+    model.compile(optimizer=opt)               # same object: the clock goes on, the moments start over
+    model.train_on_batch(x, y, dropout=False)
+    e2 = model._active
+    assert e2 is not e1 and e2.iteration == 4
+    # the first step of the new train function is Adam's step t = 4 from zero moments: m = (1 - beta_1) g exactly
+    g = e2.grads[:e2.n_param]
+    assert torch.allclose(e2.adam_m[:e2.n_param], (1.0 - 0.9) * g, rtol=1e-6, atol=0)
+    model.compile(optimizer=Adam(lr=7e-4, epsilon=1e-8, decay=1e-2))   # a NEW object starts at 0
+    model.train_on_batch(x, y, dropout=False)
+    assert model._active.iteration == 1
 
 
 def test_backward_fork_is_bit_identical(monkeypatch):

@@ -515,6 +515,48 @@ def test_pwconv_bwd_weight_writes_dy(L, case):
     assert np.isnan(got[:, N:]).all()   # nothing written beyond the N columns
 
 
+@pytest.mark.parametrize("cfg", range(10))
+def test_pwconv_bwd_weight_dy_every_tile_configuration(L, cfg, monkeypatch):
+    """round 6: the dY stores of the weight-gradient kernel are a contiguous range of each workgroup's stages (no-store /
+    store / no-store segments), issued behind the next stage's requests, with rows beyond M and column groups beyond N
+    clamped onto valid ones — every tile configuration, K and N ragged against every tile size (1 - 7 workgroups share a
+    row slab), M not a multiple of the 16-row stage, 1 - 5 valid 32-blocks in the edge tiles (idle waves skip their MFMAs)"""
+    monkeypatch.setenv("DL3_WGRAD_CFG", str(cfg))
+    for case in ((1003, 200, 328, 2, True, False), (2570, 960, 160, 1, True, False), (333, 96, 576, None, True, False),
+                 (40, 160, 960, 2, True, False)):
+        test_pwconv_bwd_weight_writes_dy(L, case)
+        test_pwconv_bwd_weight(L, case)
+
+
+@pytest.mark.parametrize("case", [(65536 + 8, 160, 960, 2, True, False), (65536, 960, 160, 2, True, False),
+                                  (65536 + 24, 96, 576, 2, True, False), (65536, 576, 160, 1, True, False),
+                                  (65536, 736, 736, 1, True, False)])
+def test_pwconv_bwd_weight_dy_benchmark_routes(L, case):
+    """... and at the row counts of the benchmarked plans (M >= 32 768 picks the tiles by the measured shortcuts): the
+    160-wide tiles with 1, 5 and 8 workgroups per row slab, the half-empty last tile row / column of K = 960 / 576 and
+    N = 960 / 576, Xception's 736 x 736"""
+    test_pwconv_bwd_weight_writes_dy(L, case)
+
+
+JV_CASES = [(1300, 736, 736), (52480 + 37, 736, 736), (700, 64, 416), (256, 2048, 256)]
+
+
+@pytest.mark.parametrize("M,K,N", JV_CASES)
+def test_pwconv_exact_width_last_column_tile(L, M, K, N, monkeypatch):
+    """round 6 (pw_gemm_stream_kernel<1, 5, ..., JV = 3>): N = q x 160 + 96 runs 160-wide column tiles plus ONE exact 96-wide
+    tile whose workgroups walk 5/3 as many row tiles (balanced persistent grid; some row slots of the last column return at
+    once): forward with BatchNorm sums, two-tensor and single-tensor bwd-data with mask, addend and sums, ragged last row
+    tile, few and many row tiles — and DL3_GEMM_JV=0 (read once per process: checked through the partial-row count only)"""
+    test_pwconv_fwd(L, (M, K, N, 0, 0, False, 1))
+    test_pwconv_fwd(L, (M, K, N, 0, 32, True, None))
+    if N == K:
+        test_pwconv_bwd_data(L, (M, K, N, 1, True, 1, True))
+        test_pwconv_bwd_data(L, (M, K, N, 1, False, 1, True))
+        test_pwconv_bwd_data(L, (M, K, N, None, False, 0, False))
+    else:
+        test_pwconv_bwd_data(L, (M, N, K, 1, True, 0, True))    # (the GEMM's output width is the layer's K)
+
+
 FUSED_CASES = [
     # M, K, N, act, two-tensor dY, residual addend, stats (0 none, 1 on the forward input, 2 on another tensor)
     (4096 + 17, 16, 96, None, True, True, 1),    # block 1 expand: K below one 32-block, 3 column blocks, ragged rows

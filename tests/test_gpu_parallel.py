@@ -351,3 +351,112 @@ def test_data_parallel_step_has_no_host_round_trip():
     assert abs(vals[-1] - eng.loss_value()) < 1e-7 * abs(vals[-1])
     assert float(eng.grads[eng.tail].item()) == float((sw != 0).sum())
     dp.close()
+
+
+# ---- round 6: fed batches under data parallelism -------------------------------------------------------
+def _byte_batches(steps, B, shape, classes, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(steps):
+        img = rng.integers(0, 256, (B,) + shape, dtype=np.uint8)
+        lab = rng.integers(0, classes, (B, shape[0], shape[1]), dtype=np.uint8)
+        lab[rng.uniform(size=lab.shape) < 0.1] = 255
+        out.append((img, lab))
+    return out
+
+
+def test_device_feed_under_distribute_equals_train_on_batch_one_rank_rccl():
+    """Model.fit_generator(device_feed=True) under Model.distribute() (utils.py:209-211 + :231-241): the fed loop — bytes
+    over a copy stream, targets on the device, captured step, ONE arena all-reduce, Adam finishing the scale on the device —
+    lands on the same weights, bit for bit, as train_on_batch on the host-side (X, Y, SW) of the same batches (a
+    communicator of one rank: what a one-GPU box can run)."""
+    import dl3_amd  # noqa: F401
+    from dl3_amd.parallel import DataParallel
+    from dl3_amd import utils as U
+    from tests.test_gpu_model import _build, _load
+    shape, classes, B, steps = (64, 64, 3), 3, 2, 4
+    batches = _byte_batches(steps, B, shape, classes, 21)
+
+    def run(fed):
+        model, params = _build("mobilenetv2", shape, classes, "deeplab")
+        _load(model, params)
+        model.compile(optimizer=dict(lr=7e-4))
+        dp = DataParallel().attach_single_rank_rccl()
+        model.distribute(dp)
+        if fed:
+            losses = model.fit_generator(batches, steps_per_epoch=steps, device_feed=True, n_classes=classes)
+        else:
+            losses = []
+            for img, lab in batches:
+                y, sw = U.prepare_targets(lab, classes)
+                losses.append(float(model.train_on_batch(img, y, sw)))
+        eng = model._active
+        assert eng.external_nnz and eng.graph is not None
+        torch.cuda.synchronize()
+        w = eng.params.cpu().numpy().copy()
+        dp.close()
+        return losses, w
+
+    lf, wf = run(True)
+    lh, wh = run(False)
+    print("fed under distribute(): losses %s / host arrays %s" % (lf, lh))
+    assert np.array_equal(wf, wh) and lf == lh
+
+
+def _worker_fed(rank, world, port, out_dir, global_batch):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), DL3_DIST_BACKEND="gloo")
+    torch.cuda.set_device(0)
+    model = _model(seed=1 + rank)
+    model.compile(optimizer=dict(lr=7e-4))
+    model.distribute()
+    steps = 3
+    batches = _byte_batches(steps, GLOBAL_B, SHAPE, CLASSES, 33)
+    if not global_batch:   # a generator sharded by rank: it yields this rank's rows only
+        lo, hi = model._dp.shard(GLOBAL_B)
+        batches = [(i[lo:hi], l[lo:hi]) for i, l in batches]
+    losses = model.fit_generator(batches, steps_per_epoch=steps, device_feed=True, n_classes=CLASSES,
+                                 global_batch=global_batch)
+    eng = model._active
+    assert eng.B == GLOBAL_B // world and eng.external_nnz
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "fed%d_%d.npz" % (int(global_batch), rank)), params=eng.params.cpu().numpy(),
+             losses=np.array(losses))
+    model._dp.close()
+
+
+def _worker_fed_reference(rank, world, port, out_dir):
+    """the same three steps through train_on_batch on host arrays of the GLOBAL batch (the path round 5 tested)"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), DL3_DIST_BACKEND="gloo")
+    torch.cuda.set_device(0)
+    from dl3_amd import utils as U
+    model = _model(seed=1 + rank)
+    model.compile(optimizer=dict(lr=7e-4))
+    model.distribute()
+    losses = []
+    for img, lab in _byte_batches(3, GLOBAL_B, SHAPE, CLASSES, 33):
+        y, sw = U.prepare_targets(lab, CLASSES)
+        losses.append(float(model.train_on_batch(img, y, sw)))
+    eng = model._active
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "ref%d.npz" % rank), params=eng.params.cpu().numpy(), losses=np.array(losses))
+    model._dp.close()
+
+
+def test_device_feed_under_distribute_two_processes(tmp_path):
+    """two ranks on one GPU (gloo data plane): fit_generator(device_feed=True) under distribute() with the generator
+    yielding the GLOBAL batch (each rank stages its shard only) and with a generator already sharded by rank
+    (global_batch=False) — both end on the weights of train_on_batch on the global batch, identical on the two ranks, and
+    report the same global loss."""
+    d = str(tmp_path)
+    mp.spawn(_worker_fed_reference, args=(2, _free_port(), d), nprocs=2, join=True)
+    for gb in (True, False):
+        mp.spawn(_worker_fed, args=(2, _free_port(), d, gb), nprocs=2, join=True)
+    ref = [np.load(os.path.join(d, "ref%d.npz" % r)) for r in (0, 1)]
+    assert np.array_equal(ref[0]["params"], ref[1]["params"])
+    for gb in (1, 0):
+        fed = [np.load(os.path.join(d, "fed%d_%d.npz" % (gb, r))) for r in (0, 1)]
+        assert np.array_equal(fed[0]["params"], fed[1]["params"]) and np.array_equal(fed[0]["losses"], fed[1]["losses"])
+        assert np.array_equal(fed[0]["params"], ref[0]["params"]), "fed shards != train_on_batch on the global batch"
+        assert np.array_equal(fed[0]["losses"], ref[0]["losses"])

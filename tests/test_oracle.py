@@ -101,6 +101,46 @@ def test_icnr_mapping():
         assert np.array_equal(W[0, 0, :, k], X[0, 0, :, k % 4])
 
 
+def test_fused_batchnorm_epsilon_floor_known_answers():
+    """tf.nn.fused_batch_norm never normalises with an epsilon below 1.001e-5 (nn_impl.py, TF 1.13) and Keras 2.2.4 runs
+    every 4-D BatchNormalization through it: the 1e-5 layers of the ASPP / decoder (deeplabv3p.py:379,386,408,422-423) use
+    1.001e-5, the 1e-3 layers are untouched.  KAT: the B=1 image-pooling case — ONE value per channel, variance exactly 0 —
+    must give beta and 1/sqrt(1.001e-5); three restatements."""
+    import torch
+    from oracle import c_backend as CB
+    from oracle import torch_ref as T
+    assert O.fused_bn_epsilon(1e-5) == 1.001e-5 and O.fused_bn_epsilon(1e-3) == 1e-3 and O.fused_bn_epsilon(1.001e-5) == 1.001e-5
+    assert T._fused_eps(1e-5) == 1.001e-5 and T._fused_eps(1e-3) == 1e-3
+    g, b = np.array([1.5, -2.0, 0.25]), np.array([0.5, 1.0, -1.0])
+    x1 = np.array([3.0, -7.0, 0.125]).reshape(1, 1, 1, 3)
+    for bn in (O.batchnorm, CB.batchnorm):
+        st = {}
+        y = bn(x1, g, b, np.zeros(3), np.ones(3), 1e-5, True, momentum=0.99, stats_out=st)
+        assert np.array_equal(y.reshape(3), b) and np.all(st["batch_var"] == 0)
+        # two values per channel: var = d^2 exactly, x_hat = +-d / sqrt(d^2 + 1.001e-5) — with d^2 << eps the floor is 1e-3 of the result
+        d = 1e-4
+        x2 = np.stack([x1.reshape(3) + d, x1.reshape(3) - d]).reshape(2, 1, 1, 3)
+        y2 = bn(x2, g, b, np.zeros(3), np.ones(3), 1e-5, True)
+        want = b + g * d / np.sqrt(d * d + 1.001e-5)
+        assert np.allclose(y2[0].reshape(3), want, rtol=1e-9, atol=0)
+        assert not np.allclose(y2[0].reshape(3) - b, g * d / np.sqrt(d * d + 1e-5), rtol=2e-4, atol=0)   # (the un-floored value differs by 5e-4)
+        # inference: moving variance 0 -> scale = gamma / sqrt(1.001e-5)
+        yi = bn(x1, g, b, np.full(3, 1.0), np.zeros(3), 1e-5, False)
+        assert np.allclose(yi.reshape(3), b + g * (x1.reshape(3) - 1.0) / np.sqrt(1.001e-5), rtol=1e-12)
+        # a 1e-3 layer is untouched
+        y3 = bn(x2, g, b, np.zeros(3), np.ones(3), 1e-3, True)
+        assert np.allclose(y3[0].reshape(3), b + g * d / np.sqrt(d * d + 1e-3), rtol=1e-9)
+    # the torch restatement, through its own BatchNorm call
+    ref = T.Ref({"n/gamma:0": g, "n/beta:0": b, "n/moving_mean:0": np.ones(3), "n/moving_variance:0": np.zeros(3)}, True,
+                dtype=torch.float64)
+    xt = torch.tensor(np.stack([x1.reshape(3) + 1e-4, x1.reshape(3) - 1e-4]).reshape(2, 3, 1, 1))
+    yt = ref.bn(xt, "n", eps=1e-5).detach().numpy()
+    assert np.allclose(yt[0].reshape(3), b + g * 1e-4 / np.sqrt(1e-8 + 1.001e-5), rtol=1e-9)
+    ref.training = False
+    yi = ref.bn(torch.tensor(x1.reshape(1, 3, 1, 1)), "n", eps=1e-5).detach().numpy()
+    assert np.allclose(yi.reshape(3), b + g * (x1.reshape(3) - 1.0) / np.sqrt(1.001e-5), rtol=1e-12)
+
+
 def test_batchnorm_and_loss_semantics():
     rng = np.random.default_rng(0)
     x = rng.normal(2, 3, (4, 5, 5, 3))

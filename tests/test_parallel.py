@@ -122,6 +122,41 @@ def test_ranks_agree_when_the_rccl_communicator_fails_on_one_of_them(tmp_path):
     assert int(r0["destroyed"]) == 1 and int(r1["destroyed"]) == 0
 
 
+def _worker_strict(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    os.environ.pop("DL3_DIST_BACKEND", None)
+    os.environ.pop("DL3_DIST_STRICT", None)
+    import dl3_amd  # noqa: F401
+    from dl3_amd import capi
+    from dl3_amd.parallel import DataParallel
+    stub = _StubLib(rank)
+    capi.lib = lambda: stub
+    raised = ""
+    try:
+        DataParallel(backend="rccl", strict=True)   # what Model.distribute() builds by default
+    except capi.DL3Error as e:
+        raised = str(e)
+    np.savez(os.path.join(out_dir, "st%d.npz" % rank), raised=raised, destroyed=stub.destroyed)
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def test_strict_data_plane_raises_on_every_rank_instead_of_falling_back(tmp_path):
+    """Model.distribute() (strict=True, round 6): when the RCCL communicator fails on ANY rank, EVERY rank raises — no
+    silent gloo exchange through host memory — and the rank whose communicator did come up destroys it first"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_strict, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = [np.load(os.path.join(str(tmp_path), "st%d.npz" % r)) for r in (0, 1)]
+    for r in (r0, r1):
+        assert "dl3_comm_init" in str(r["raised"]) and "strict" in str(r["raised"])
+    assert int(r0["destroyed"]) == 1 and int(r1["destroyed"]) == 0
+
+
 def _ragged():
     rng = np.random.default_rng(5)
     x = rng.integers(0, 256, (5, 32, 32, 3)).astype(np.float32)
