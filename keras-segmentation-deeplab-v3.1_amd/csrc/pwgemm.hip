@@ -17,7 +17,6 @@
 #include <stdlib.h>
 
 #include <mutex>
-#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -40,7 +39,6 @@ struct GemmArgs {
   float *part;
   int part_rows;  // rows the caller's partial buffer holds: the launch writes gridDim.y of them and zeroes the rest itself
   int mtiles;
-  int py_last;  // pw_gemm_stream_kernel<..., JV>: row slots (of gridDim.y) the exact-width last column tile uses
   const void *bp; int nsub;  // split math: weights pre-split into 3 bf16 planes in MFMA fragment order (pack_b_kernel)
 #ifdef DL3_PHASE_TIMING
   long long *dbg;  // probe build (tools/r3/phase_probe.py): per-workgroup cycles in prologue / K loop / epilogue
@@ -465,20 +463,8 @@ __device__ __forceinline__ void stream_epilogue_full(const GemmArgs &P, const f3
 // GEMMs; their interior tiles take the straight-line epilogue and the masked code is not compiled in at all.
 // WN: waves side by side along N (4/WN stacked along M).  WN = 4 gives 32-row tiles for small M (batch 1-4: a
 // 128-row tile leaves most CUs idle and every workgroup a long serial K loop).
-// JV (round 6): the LAST column tile of the launch is JV < TN blocks wide — exactly the columns that are
-// left (N = (gridDim.x - 1) * 160 + 32 JV: Xception's 736 = 4 x 160 + 96) — instead of a fifth 160-wide tile of which 40 %
-// is padding that the matrix pipe multiplies all the same (8 % of the launch's MFMAs).  Its workgroups run the SAME body
-// compiled for TE = JV column blocks (own accumulator array: no predicated MFMAs, no register copies), and because such a
-// tile is 3/5 of the work, the persistent grid gives that column fewer workgroups, each with more row tiles (P.py_last of
-// the gridDim.y row slots; the others return at once): every workgroup of the launch carries the same number of block-tiles.
-// (waves per SIMD: the generic 128 x 96 kernels fit three — 168 VGPRs, no scratch, since round 4 — and the compiler is told so;
-// before the body became a lambda it found that by itself)
-template <int TM, int TN, int EPI, int WN, int MATH, int JV>
-constexpr int stream_occupancy() { return (TM == 1 && TN == 3 && EPI == 0 && WN == 1 && MATH == 0 && JV == 0) ? 3 : 2; }
-
-template <int TM, int TN, bool TWO, int KT, int EPI, int WN = 1, int MATH = 0, int JV = 0>
-__global__ __launch_bounds__(256, (stream_occupancy<TM, TN, EPI, WN, MATH, JV>())) void pw_gemm_stream_kernel(GemmArgs P) {
-  static_assert(JV == 0 || (JV < TN && WN == 1 && MATH == 0 && EPI != 2), "exact-width last column tile: f32 128-row tiles only");
+template <int TM, int TN, bool TWO, int KT, int EPI, int WN = 1, int MATH = 0>
+__global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
   // MATH 1: split math (see split3) — the A registers are split after the operand transform, the weight tile comes
   // pre-split from pack_b_kernel, six bf16 MFMAs per 16-deep K-tile and 32x32 sub-tile
   constexpr bool SPL = (MATH == 1);
@@ -530,16 +516,9 @@ __global__ __launch_bounds__(256, (stream_occupancy<TM, TN, EPI, WN, MATH, JV>()
   const int wm = wave / WN, wn = wave % WN;
   const int nw0 = n0 + wn * TN * 32;  // first column of this wave's sub-tile
 
-  const bool last_partial = JV > 0 && bx == (int)gridDim.x - 1;
-  const unsigned gy_ = last_partial ? (unsigned)P.py_last : gridDim.y;   // row slots of this column tile
-  if constexpr (JV > 0) {
-    if ((unsigned)by >= gy_) return;
-  }
-  auto body = [&](auto te_tag) __attribute__((always_inline)) {
-  constexpr int TE = decltype(te_tag)::value;   // 32-column blocks of this workgroup's tile (TN, or JV in the last column)
-  float st1[TE], st2[TE];
+  float st1[TN], st2[TN];
 #pragma unroll
-  for (int i = 0; i < TE; i++) st1[i] = st2[i] = 0.f;
+  for (int i = 0; i < TN; i++) st1[i] = st2[i] = 0.f;
 
   // T(a)[k] = act(ka[k]*a + kb[k]*a2 + kc[k]); k >= K gets all-zero coefficients, so the clamped (in-bounds) loads
   // beyond K contribute act(0) = 0
@@ -563,26 +542,26 @@ __global__ __launch_bounds__(256, (stream_occupancy<TM, TN, EPI, WN, MATH, JV>()
 
   DL3_T(long long tp0 = 0; long long tp1 = 0; long long tp2 = 0; long long tq0 = 0; long long tq1 = 0; long long tq2 = 0; int ntl = 0;
         long long tw_vm = 0; long long tw_bar = 0;)
-  for (int mt = by; mt < P.mtiles; mt += gy_) {
+  for (int mt = by; mt < P.mtiles; mt += gridDim.y) {
     DL3_T(tq0 = clock64(); ntl++;)
     const int m0 = mt * BM;
-    f32x16 acc[TM][TE];
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
-      for (int j = 0; j < TE; j++)
+      for (int j = 0; j < TN; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    const bool full = (m0 + BM <= P.M) && (n0 + 32 * TE * WN <= P.N);
-    float pxv[PRE ? TE : 1][16];
+    const bool full = (m0 + BM <= P.M) && (n0 + BN <= P.N);
+    float pxv[PRE ? TN : 1][16];
     if constexpr (PRE) {
       if (full) {
         const size_t urow = (size_t)(m0 + __builtin_amdgcn_readfirstlane(wm) * 32);
         const float *px = P.ep_x + urow * P.ld_epx + nw0;
         const unsigned lo_x = (unsigned)(4 * lhi * P.ld_epx + l31);
 #pragma unroll
-        for (int j = 0; j < TE; j++)
+        for (int j = 0; j < TN; j++)
 #pragma unroll
           for (int r = 0; r < 16; r++) pxv[j][r] = (px + (size_t)((r & 3) + 8 * (r >> 2)) * P.ld_epx + j * 32)[lo_x];
       }
@@ -682,7 +661,7 @@ __global__ __launch_bounds__(256, (stream_occupancy<TM, TN, EPI, WN, MATH, JV>()
       auto mfma_step = [&](const float *Bs, int ks) {
         const u32x4 *Bq = (const u32x4 *)Bs + (ks * 3 * (BN / 32) + wn * TN) * 64 + lane;
 #pragma unroll
-        for (int j = 0; j < TE; j++) {
+        for (int j = 0; j < TN; j++) {
           const bf16x8 bh = __builtin_bit_cast(bf16x8, Bq[j * 64]);
           const bf16x8 bm = __builtin_bit_cast(bf16x8, Bq[((BN / 32) + j) * 64]);
           const bf16x8 bl = __builtin_bit_cast(bf16x8, Bq[(2 * (BN / 32) + j) * 64]);
@@ -763,20 +742,20 @@ __global__ __launch_bounds__(256, (stream_occupancy<TM, TN, EPI, WN, MATH, JV>()
             load_B_to(kt + PD, rbb[d]);
             load_A_to(kt + PD, ra[d], ra2[d]);
           }
-          float bf[2][TE];
+          float bf[2][TN];
 #pragma unroll
-          for (int j = 0; j < TE; j++) bf[0][j] = Bs[(KH * lhi) * LDB + (wn * TN + j) * 32 + l31];
+          for (int j = 0; j < TN; j++) bf[0][j] = Bs[(KH * lhi) * LDB + (wn * TN + j) * 32 + l31];
 #pragma unroll
           for (int s_ = 0; s_ < KH; ++s_) {
             const int cur = s_ & 1, nxt = cur ^ 1;
             if (s_ + 1 < KH) {
 #pragma unroll
-              for (int j = 0; j < TE; j++) bf[nxt][j] = Bs[(KH * lhi + s_ + 1) * LDB + (wn * TN + j) * 32 + l31];
+              for (int j = 0; j < TN; j++) bf[nxt][j] = Bs[(KH * lhi + s_ + 1) * LDB + (wn * TN + j) * 32 + l31];
             }
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
-              for (int j = 0; j < TE; j++)
+              for (int j = 0; j < TN; j++)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[i][s_ >> 2][s_ & 3], bf[cur][j], acc[i][j], 0, 0, 0);
           }
           if (kt + 1 < ktiles) {
@@ -803,20 +782,20 @@ __global__ __launch_bounds__(256, (stream_occupancy<TM, TN, EPI, WN, MATH, JV>()
         load_A(kt + 1);
         load_B(kt + 1);
       }
-      float bf[2][TE];
+      float bf[2][TN];
 #pragma unroll
-      for (int j = 0; j < TE; j++) bf[0][j] = Bs[(KH * lhi) * LDB + (wn * TN + j) * 32 + l31];
+      for (int j = 0; j < TN; j++) bf[0][j] = Bs[(KH * lhi) * LDB + (wn * TN + j) * 32 + l31];
 #pragma unroll
       for (int s_ = 0; s_ < KH; ++s_) {
         const int cur = s_ & 1, nxt = cur ^ 1;
         if (s_ + 1 < KH) {
 #pragma unroll
-          for (int j = 0; j < TE; j++) bf[nxt][j] = Bs[(KH * lhi + s_ + 1) * LDB + (wn * TN + j) * 32 + l31];
+          for (int j = 0; j < TN; j++) bf[nxt][j] = Bs[(KH * lhi + s_ + 1) * LDB + (wn * TN + j) * 32 + l31];
         }
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
-          for (int j = 0; j < TE; j++)
+          for (int j = 0; j < TN; j++)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[i][s_ >> 2][s_ & 3], bf[cur][j], acc[i][j], 0, 0, 0);
       }
       // next tile's weight tile -> LDS and operand transform, behind the last MFMA of this K-tile
@@ -845,8 +824,8 @@ __global__ __launch_bounds__(256, (stream_occupancy<TM, TN, EPI, WN, MATH, JV>()
     const int m0e = m0, nw0e = nw0;
 #endif
     if (FWD && full) {
-      if (!P.ep_add) stream_epilogue_full<TM, TE, false, false, false>(P, acc, m0e, nw0e, wm, l31, lhi, st1, st2);
-      else stream_epilogue_full<TM, TE, false, true, false>(P, acc, m0e, nw0e, wm, l31, lhi, st1, st2);
+      if (!P.ep_add) stream_epilogue_full<TM, TN, false, false, false>(P, acc, m0e, nw0e, wm, l31, lhi, st1, st2);
+      else stream_epilogue_full<TM, TN, false, true, false>(P, acc, m0e, nw0e, wm, l31, lhi, st1, st2);
       DL3_T(tp2 += clock64() - tq2;)
       continue;
     }
@@ -856,7 +835,7 @@ __global__ __launch_bounds__(256, (stream_occupancy<TM, TN, EPI, WN, MATH, JV>()
         const unsigned lo_c = (unsigned)(4 * lhi * P.ldc + l31);
         const bool mode2 = P.stat_mode == 2;
 #pragma unroll
-        for (int j = 0; j < TE; j++) {
+        for (int j = 0; j < TN; j++) {
           const int cl = j * 32 + l31;
           const float es = eco[cl], et = eco[BN + cl], mu = eco[2 * BN + cl], is = eco[3 * BN + cl];
 #pragma unroll
@@ -874,7 +853,7 @@ __global__ __launch_bounds__(256, (stream_occupancy<TM, TN, EPI, WN, MATH, JV>()
     }
     // everything else: generic path, every element predicated
 #pragma unroll
-    for (int j = 0; j < TE; j++) {
+    for (int j = 0; j < TN; j++) {
       const int col = nw0e + j * 32 + l31;
       const bool cok = col < P.N;
       const int colc = min(col, P.N - 1);
@@ -935,7 +914,7 @@ __global__ __launch_bounds__(256, (stream_occupancy<TM, TN, EPI, WN, MATH, JV>()
     float *sred = lds;  // [WM][BN][2]
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < TE; j++) {
+    for (int j = 0; j < TN; j++) {
       float a1 = st1[j] + __shfl_xor(st1[j], 32, 64);
       float a2 = st2[j] + __shfl_xor(st2[j], 32, 64);
       if (lhi == 0) {
@@ -957,19 +936,12 @@ __global__ __launch_bounds__(256, (stream_occupancy<TM, TN, EPI, WN, MATH, JV>()
         P.part[((size_t)by * P.N + col) * 2 + 1] = a2;
         // rows of the buffer no workgroup owns (it is sized for the largest grid any tile choice uses): zeroed here, by
         // the row groups in turn, instead of by a memset node behind every launch
-        for (int r = by + (int)gy_; r < P.part_rows; r += (int)gy_) {
+        for (int r = by + (int)gridDim.y; r < P.part_rows; r += (int)gridDim.y) {
           P.part[((size_t)r * P.N + col) * 2 + 0] = 0.f;
           P.part[((size_t)r * P.N + col) * 2 + 1] = 0.f;
         }
       }
     }
-  }
-  };
-  if constexpr (JV > 0) {
-    if (last_partial) body(std::integral_constant<int, JV>{});
-    else body(std::integral_constant<int, TN>{});
-  } else {
-    body(std::integral_constant<int, TN>{});
   }
 }
 
@@ -991,23 +963,6 @@ struct WgradArgs {
 };
 
 // VEC: 1 = 16-byte loads of x and of g / y, 0 = scalar loads of both, 2 (round 5) = 16-byte loads of x only (N = classes)
-//
-// Round 6.  Two things about this kernel cost the MFMA-bound backward launches their distance to the forward
-// GEMM:
-//  * Tile padding was issued as MFMAs: K = 960 / 576 on 128-row tiles, N = 960 / 576 on 128-column tiles leave the last
-//    tile row / column half empty (7-11 % of the launch's matrix work; Xception's 736 x 736 on 128 x 160 tiles: 13 %).
-//    A wave now runs only the 32 x 32 blocks of its sub-tile that lie inside the matrix (ia x jb of TA x TB, wave-uniform):
-//    a wave with nothing to do idles at the barriers and leaves its SIMD's matrix pipe to the co-resident workgroup.
-//  * The dY = cA*g + cB*y + cC stores (round 4) sat in a branch (`if (owner of this stage)`), behind the stage's operand
-//    requests in program order but IN FRONT of the next stage's: vmcnt retires in order and counts stores, so every wait for
-//    the next stage's operands was also a wait for this stage's stores, and the compiler could not even count them (a store
-//    in a branch: s_waitcnt vmcnt(0)).  The write of 25 GB per step cost the weight-gradient launches +3.5-4.3 ms — all of it
-//    exposed, in launches whose HBM side is half idle.  Now (the recipe of round 5): ownership of the dY stores is a
-//    CONTIGUOUS range of the workgroup's stages (the gridDim.y workgroups of a row slab split the slab's stages evenly), so
-//    the loop is cut into a no-store, a store and a no-store segment, each straight-line; inside the store segment every
-//    lane stores every piece (rows beyond M and column groups beyond N are clamped onto valid ones: same address, same
-//    bits), the NEXT stage's operands are requested BEFORE this stage's stores, and the wait for them is a counted
-//    vmcnt(#stores) that leaves the stores in flight.
 template <int TA, int TB, int WA, int WB, int VEC, bool SPL = false>
 __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
   constexpr bool XVEC = VEC != 0, DVEC = VEC == 1;
@@ -1024,7 +979,7 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
   constexpr int STAGE = MS * LDX + MS * LDD;
   __shared__ float lds[2 * STAGE];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wa = wave / WB, wb = wave % WB;
   const int l31 = lane & 31, lhi = lane >> 5;
   // XCD-aware decode: the tiles of ONE row slab (same activations / gradients, different weight tiles) get consecutive
@@ -1041,10 +996,13 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
   const int mend = min(P.M, mbeg + P.Mper);
   const bool xform = (P.xs != nullptr);
   const bool two = (P.cA != nullptr);
-  // 32 x 32 blocks of this wave's sub-tile that lie inside the K x N matrix (wave-uniform)
-  const int ia = max(0, min(TA, (P.K - kbase - wa * TA * 32 + 31) >> 5));
-  const int jb = max(0, min(TB, (P.N - nbase - wb * TB * 32 + 31) >> 5));
-  const bool wfull = (ia == TA) && (jb == TB);
+  // the workgroups of the first K-tile row also write the gradient operand they assemble anyway, dY = cA*g + cB*y + cC,
+  // to HBM (every (row, column) is staged by exactly one (bx, by_ = 0, bz)): the bwd-data GEMM of the layer then reads ONE
+  // tensor instead of two and has no operand transform (round 4)
+  // ... and they take turns: the gridDim.y workgroups that share a row slab (same bx, bz: they all assemble the same dY
+  // stages) each write every gridDim.y-th stage, so that no workgroup carries the whole store stream (first version, all
+  // stores on by_ == 0: the launch waited for those workgroups, +4.5 ms per step for 25 GB of stores)
+  const bool dy_on = (P.dyout != nullptr);
 
   f32x16 acc[TA][TB];
 #pragma unroll
@@ -1054,109 +1012,88 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  // per-column coefficient vectors of the tile (input transform of x; BatchNorm-backward affine of g, y) live in LDS — as
-  // hoisted registers they were 40-52 VGPRs of every instantiation (an occupancy step for the 128 x 96 / 128 x 128 tiles).
-  // A lane whose 16-byte piece lies beyond N works on a duplicate of the last valid column group (the requests clamp it
-  // there) and reads that group's coefficients, so that it assembles — and, in a store segment, stores — the same bits.
-  __shared__ __attribute__((aligned(16))) float cfx[2][BKT];
-  __shared__ __attribute__((aligned(16))) float cfd[3][BNT];
-  for (int c = tid; c < BKT; c += 256) {
-    const int kc = min(kbase + c, P.K - 1);
-    cfx[0][c] = xform ? P.xs[kc] : 1.f;
-    cfx[1][c] = xform ? P.xt[kc] : 0.f;
+  // per-thread column positions are the same for every M stage: hoist coefficients and validity
+  f32x4 xs4[NX], xt4[NX], kA4[ND], kB4[ND], kC4[ND];
+  bool xok[NX][4], dok[ND][4];
+#pragma unroll
+  for (int i = 0; i < NX; i++) {
+    const int idx = tid + 256 * i;
+    const int k = kbase + (idx % (BKT / 4)) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      xok[i][j] = (k + j) < P.K;
+      const int kc = min(k + j, P.K - 1);
+      xs4[i][j] = xform ? P.xs[kc] : 1.f;
+      xt4[i][j] = xform ? P.xt[kc] : 0.f;
+    }
   }
-  for (int c = tid; c < BNT; c += 256) {
-    const int cc = min(nbase + c, P.N - 1);
-    cfd[0][c] = two ? P.cA[cc] : 1.f;
-    cfd[1][c] = two ? P.cB[cc] : 0.f;
-    cfd[2][c] = two ? P.cC[cc] : 0.f;
+#pragma unroll
+  for (int i = 0; i < ND; i++) {
+    const int idx = tid + 256 * i;
+    const int col = nbase + (idx % (BNT / 4)) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      dok[i][j] = (col + j) < P.N;
+      const int cc = min(col + j, P.N - 1);
+      kA4[i][j] = two ? P.cA[cc] : 1.f;
+      kB4[i][j] = two ? P.cB[cc] : 0.f;
+      kC4[i][j] = two ? P.cC[cc] : 0.f;
+    }
   }
-  __syncthreads();
 
   f32x4 rx[NX], rg[ND], ry[ND];
 
-  // requests of the stage that starts at row m0 (all unconditional: clamped rows / columns / piece indices)
-  auto load_x = [&](int m0) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < NX; i++) {
-      const int idx = min(tid + 256 * i, XQ - 1);
-      const int mr = idx / (BKT / 4), kq = idx % (BKT / 4);
-      const int row = min(m0 + mr, P.M - 1), k = kbase + kq * 4;
-      if (XVEC) {
-        rx[i] = ld4(P.x + (size_t)row * P.ldx + min(k, P.K - 4));
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; j++) rx[i][j] = P.x[(size_t)row * P.ldx + min(k + j, P.K - 1)];
-      }
-    }
-  };
-  auto load_d = [&](int m0) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < ND; i++) {
-      const int idx = min(tid + 256 * i, DQ - 1);
-      const int mr = idx / (BNT / 4), nq = idx % (BNT / 4);
-      const int row = min(m0 + mr, P.M - 1), col = nbase + nq * 4;
-      if (DVEC) {
-        const int cc = min(col, P.N - 4);
-        rg[i] = ld4(P.g + (size_t)row * P.ldg + cc);
-        if (two) ry[i] = ld4(P.y + (size_t)row * P.ldy + cc);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int cc = min(col + j, P.N - 1);
-          rg[i][j] = P.g[(size_t)row * P.ldg + cc];
-          if (two) ry[i][j] = P.y[(size_t)row * P.ldy + cc];
-        }
-      }
-    }
-  };
-  // the loaded stage (rows m0 ..) -> MFMA operands in LDS [+ dY to HBM]; the requests of the stage at mnext are issued in
-  // between: behind the last use of the registers they land in, in front of this stage's stores
-  auto prepare = [&](int m0, int mnext, float *Xs, float *Ds, auto store_tag) __attribute__((always_inline)) {
-    constexpr bool STORE = decltype(store_tag)::value;
-    // x: transform -> LDS (not a vector-memory operation: it may sit anywhere), then its registers take the next stage's
+  auto load_tiles = [&](int m0) {
 #pragma unroll
     for (int i = 0; i < NX; i++) {
       const int idx = tid + 256 * i;
-      const int mr = min(idx, XQ - 1) / (BKT / 4), kq = min(idx, XQ - 1) % (BKT / 4);
-      const bool rok = (m0 + mr) < mend;
-      const int kl = XVEC ? min(kbase + kq * 4, P.K - 4) - kbase : kq * 4;   // (the column group the load was clamped to)
-      f32x4 v = dl3_act4(ld4(&cfx[0][kl]) * rx[i] + ld4(&cfx[1][kl]), P.x_act);
+      if (NX * 256 == XQ || idx < XQ) {
+        const int mr = idx / (BKT / 4), kq = idx % (BKT / 4);
+        const int row = min(m0 + mr, P.M - 1), k = kbase + kq * 4;
+        if (XVEC) {
+          rx[i] = ld4(P.x + (size_t)row * P.ldx + min(k, P.K - 4));
+        } else {
 #pragma unroll
-      for (int j = 0; j < 4; j++)
-        if (!(rok && (kbase + kq * 4 + j) < P.K)) v[j] = 0.f;
-      if (NX * 256 == XQ || idx < XQ) st4(&Xs[mr * LDX + kq * 4], v);
+          for (int j = 0; j < 4; j++) rx[i][j] = P.x[(size_t)row * P.ldx + min(k + j, P.K - 1)];
+        }
+      }
     }
-    f32x4 td[ND];
 #pragma unroll
     for (int i = 0; i < ND; i++) {
-      const int nq_ = min(tid + 256 * i, DQ - 1) % (BNT / 4);
-      const int nl = DVEC ? min(nbase + nq_ * 4, P.N - 4) - nbase : nq_ * 4;
-      td[i] = ld4(&cfd[0][nl]) * rg[i] + ld4(&cfd[2][nl]);
-      if (two) td[i] += ld4(&cfd[1][nl]) * ry[i];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    load_x(mnext);
-    load_d(mnext);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (STORE) {
-#pragma unroll
-      for (int i = 0; i < ND; i++) {
-        const int idx = min(tid + 256 * i, DQ - 1);
+      const int idx = tid + 256 * i;
+      if (ND * 256 == DQ || idx < DQ) {
         const int mr = idx / (BNT / 4), nq = idx % (BNT / 4);
-        if constexpr (DVEC) {
-          float *dp = P.dyout + (size_t)min(m0 + mr, P.M - 1) * P.lddy + min(nbase + nq * 4, P.N - 4);
-          st4_nt(dp, td[i]);
+        const int row = min(m0 + mr, P.M - 1), col = nbase + nq * 4;
+        if (DVEC) {
+          const int cc = min(col, P.N - 4);
+          rg[i] = ld4(P.g + (size_t)row * P.ldg + cc);
+          if (two) ry[i] = ld4(P.y + (size_t)row * P.ldy + cc);
         } else {
-          if (m0 + mr < mend) {
-            float *dp = P.dyout + (size_t)(m0 + mr) * P.lddy + nbase + nq * 4;
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-              if ((nbase + nq * 4 + j) < P.N) dp[j] = td[i][j];
+          for (int j = 0; j < 4; j++) {
+            const int cc = min(col + j, P.N - 1);
+            rg[i][j] = P.g[(size_t)row * P.ldg + cc];
+            if (two) ry[i][j] = P.y[(size_t)row * P.ldy + cc];
           }
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  auto store_tiles = [&](int m0, float *Xs, float *Ds) {
+    const bool dy_owner = dy_on && (((m0 - mbeg) / MS) % (int)gridDim.y == by_);
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+      const int idx = tid + 256 * i;
+      if (NX * 256 == XQ || idx < XQ) {
+        const int mr = idx / (BKT / 4), kq = idx % (BKT / 4);
+        const bool rok = (m0 + mr) < mend;
+        f32x4 v = dl3_act4(xs4[i] * rx[i] + xt4[i], P.x_act);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (!(rok && xok[i][j])) v[j] = 0.f;
+        st4(&Xs[mr * LDX + kq * 4], v);
+      }
     }
 #pragma unroll
     for (int i = 0; i < ND; i++) {
@@ -1164,55 +1101,81 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
       if (ND * 256 == DQ || idx < DQ) {
         const int mr = idx / (BNT / 4), nq = idx % (BNT / 4);
         const bool rok = (m0 + mr) < mend;
-        f32x4 v = td[i];
+        f32x4 v = kA4[i] * rg[i] + kC4[i];
+        if (two) v += kB4[i] * ry[i];
+        if (dy_owner && rok) {
+          float *dp = P.dyout + (size_t)(m0 + mr) * P.lddy + nbase + nq * 4;
+          if (DVEC) {
+            if (dok[i][0]) st4_nt(dp, v);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+              if (dok[i][j]) dp[j] = v[j];
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          if (!(rok && (nbase + nq * 4 + j) < P.N)) v[j] = 0.f;
+          if (!(rok && dok[i][j])) v[j] = 0.f;
         st4(&Ds[mr * LDD + nq * 4], v);
       }
     }
   };
 
-  // the MFMAs of one staged 16-row slice
-  auto mfma_stage = [&](const float *Xs, const float *Ds) __attribute__((always_inline)) {
-    if constexpr (SPL) {
-      u32x4 ah[TA], am[TA], al[TA];
-#pragma unroll
-      for (int i = 0; i < TA; i++) {
-        f32x4 v0, v1;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          v0[e] = Xs[(8 * lhi + e) * LDX + (wa * TA + i) * 32 + l31];
-          v1[e] = Xs[(8 * lhi + 4 + e) * LDX + (wa * TA + i) * 32 + l31];
-        }
-        split3(v0, v1, ah[i], am[i], al[i]);
-      }
-#pragma unroll
-      for (int j = 0; j < TB; j++) {
-        f32x4 v0, v1;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          v0[e] = Ds[(8 * lhi + e) * LDD + (wb * TB + j) * 32 + l31];
-          v1[e] = Ds[(8 * lhi + 4 + e) * LDD + (wb * TB + j) * 32 + l31];
-        }
-        u32x4 bh_, bm_, bl_;
-        split3(v0, v1, bh_, bm_, bl_);
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, bh_), bm = __builtin_bit_cast(bf16x8, bm_),
-                     bl = __builtin_bit_cast(bf16x8, bl_);
+  DL3_T(long long tw_vm = 0; long long tw_bar = 0; int nst = 0; const long long tstart = clock64();)
+  if (mbeg < mend) {
+    load_tiles(mbeg);
+    store_tiles(mbeg, lds, lds + MS * LDX);
+    __syncthreads();
+    int stage = 0;
+    for (int m0 = mbeg; m0 < mend; m0 += MS, stage ^= 1) {
+      const float *Xs = lds + stage * STAGE;
+      const float *Ds = Xs + MS * LDX;
+      const bool more = (m0 + MS < mend);
+      if (more) load_tiles(m0 + MS);
+      if constexpr (SPL) {
+        u32x4 ah[TA], am[TA], al[TA];
 #pragma unroll
         for (int i = 0; i < TA; i++) {
-          const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[i]), xm = __builtin_bit_cast(bf16x8, am[i]),
-                       xl = __builtin_bit_cast(bf16x8, al[i]);
-          f32x16 c = acc[i][j];  // small terms first
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bm, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bh, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bm, c, 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, c, 0, 0, 0);
+          f32x4 v0, v1;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            v0[e] = Xs[(8 * lhi + e) * LDX + (wa * TA + i) * 32 + l31];
+            v1[e] = Xs[(8 * lhi + 4 + e) * LDX + (wa * TA + i) * 32 + l31];
+          }
+          split3(v0, v1, ah[i], am[i], al[i]);
         }
+#pragma unroll
+        for (int j = 0; j < TB; j++) {
+          f32x4 v0, v1;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            v0[e] = Ds[(8 * lhi + e) * LDD + (wb * TB + j) * 32 + l31];
+            v1[e] = Ds[(8 * lhi + 4 + e) * LDD + (wb * TB + j) * 32 + l31];
+          }
+          u32x4 bh_, bm_, bl_;
+          split3(v0, v1, bh_, bm_, bl_);
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, bh_), bm = __builtin_bit_cast(bf16x8, bm_),
+                       bl = __builtin_bit_cast(bf16x8, bl_);
+#pragma unroll
+          for (int i = 0; i < TA; i++) {
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[i]), xm = __builtin_bit_cast(bf16x8, am[i]),
+                         xl = __builtin_bit_cast(bf16x8, al[i]);
+            f32x16 c = acc[i][j];  // small terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bm, c, 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, c, 0, 0, 0);
+          }
+        }
+        if (more) {
+          float *Xn = lds + (stage ^ 1) * STAGE;
+          store_tiles(m0 + MS, Xn, Xn + MS * LDX);
+        }
+        __syncthreads();
+        continue;
       }
-    } else if (ia > 0 && jb > 0) {
       float af[2][TA], bf[2][TB];
 #pragma unroll
       for (int i = 0; i < TA; i++) af[0][i] = Xs[lhi * LDX + (wa * TA + i) * 32 + l31];
@@ -1233,43 +1196,15 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
           for (int j = 0; j < TB; j++)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
       }
-    }
-  };
-
-  DL3_T(long long tw_vm = 0; long long tw_bar = 0; int nst = 0; const long long tstart = clock64();)
-  if (mbeg < mend) {
-    const int ns = (mend - mbeg + MS - 1) / MS;          // stages of this workgroup
-    const int mlast = mbeg + (ns - 1) * MS;              // (the last stage asks for itself again instead of for nothing)
-    // stages whose dY this workgroup stores: an even, contiguous share of the row slab's stages for each of the gridDim.y
-    // workgroups that stage the same dY
-    const int gy = (int)gridDim.y;
-    const int s_lo = P.dyout ? (int)((long)by_ * ns / gy) : ns, s_hi = P.dyout ? (int)((long)(by_ + 1) * ns / gy) : ns;
-    auto stage_x = [&](int t) { return lds + (t & 1) * STAGE; };
-    auto run = [&](int t0, int t1, auto store_tag) __attribute__((always_inline)) {
-      for (int t = t0; t < t1; ++t) {
-        mfma_stage(stage_x(t - 1), stage_x(t - 1) + MS * LDX);
+      if (more) {
+        float *Xn = lds + (stage ^ 1) * STAGE;
         DL3_T(const long long w0 = clock64(); __builtin_amdgcn_s_waitcnt(0x0F70); tw_vm += clock64() - w0;)
-        prepare(mbeg + t * MS, min(mbeg + (t + 1) * MS, mlast), stage_x(t), stage_x(t) + MS * LDX, store_tag);
-        DL3_T(const long long w1 = clock64();)
-        __syncthreads();
-        DL3_T(tw_bar += clock64() - w1; nst++;)
+        store_tiles(m0 + MS, Xn, Xn + MS * LDX);
       }
-    };
-    load_x(mbeg);
-    load_d(mbeg);
-    if (s_lo == 0 && s_hi > 0) prepare(mbeg, min(mbeg + MS, mlast), stage_x(0), stage_x(0) + MS * LDX, std::true_type{});
-    else prepare(mbeg, min(mbeg + MS, mlast), stage_x(0), stage_x(0) + MS * LDX, std::false_type{});
-    __syncthreads();
-    const int a = max(1, s_lo), b = max(a, s_hi);
-    run(1, min(a, ns), std::false_type{});
-    if (a < b) {
-      // (requests in flight at a loop's entry make its header the pessimistic merge of entry and back edge — every wait
-      // inside becomes vmcnt(0): wait once HERE, and the store segment's waits are counted ones)
-      __builtin_amdgcn_s_waitcnt(0x0F70);
-      run(a, b, std::true_type{});
+      DL3_T(const long long w1 = clock64();)
+      __syncthreads();
+      DL3_T(tw_bar += clock64() - w1; nst++;)
     }
-    run(b, ns, std::false_type{});
-    mfma_stage(stage_x(ns - 1), stage_x(ns - 1) + MS * LDX);
   }
 #ifdef DL3_PHASE_TIMING
   if (P.dbg && lane == 0) {
@@ -1518,6 +1453,327 @@ __global__ __launch_bounds__(256, OC) void pw_fwd_ws_kernel(GemmArgs P) {
   }
 }
 
+// ---- round 6: weight-stationary GEMM for the MFMA-bound short reductions ------------------------------------------------
+// The expand convolutions forward / the project convolutions' bwd-data (deeplabv3p.py:175-198: reduction 64 / 96 / 160 into a
+// 384 / 576 / 960-wide output at 64 x 64) spend a third of every row tile outside the K loop in the tiled stream kernel: ten
+// K-tiles of a reduction of 160 are 25 us of MFMAs between a prologue (first operand round trip, two barriers) and an
+// epilogue of 6-8 us during which the wave issues none (DESIGN.md, round 3 phase table: matrix pipe 71 % / 50 % busy).
+// Here a workgroup of NW = 8 waves keeps its WHOLE weight slice W[K][32 TN] in LDS for its lifetime (102 KB at K = 160,
+// TN = 5: one workgroup per CU, two waves per SIMD) and every wave walks 32-row tiles on its own, like pw_fwd_ws_kernel: all
+// K/8 16-byte requests of a tile up front (the lane's half of its row: K/2 registers), K/2 x TN MFMAs against fragments read
+// straight from the resident slice — no weight staging, no barrier anywhere in the loop — then the epilogue, block by block
+// through a per-wave LDS square (16-byte stores of whole rows).  The two waves of a SIMD drift apart by themselves: while one
+// is in its epilogue or waits for its rows, the other one owns the matrix pipe.
+// BWD: the bwd-data instantiation (dX = dY . W^T with the single-tensor dY the weight-gradient launch materialised): no operand
+// transform; the epilogue multiplies by the activation mask of the forward input x and reduces the BatchNorm-backward sums
+// sum(v), sum(v * x_hat).  Both need x element by element — it is requested 16 bytes at a time in the SAME row-piece layout the
+// output leaves in (block j + 1's pieces while block j is finished), and the sums are kept per lane for its four columns,
+// folded over the eight row lanes once at the end.
+template <int KQ, int TN, int NW, bool BWD = false>
+__global__ __launch_bounds__(64 * NW) void pw_ws2_kernel(GemmArgs P) {
+  constexpr int KH = 4 * KQ, K = 8 * KQ, NP = 32 * TN;
+  __shared__ __attribute__((aligned(16))) float Ws[K * NP];   // W[k][n0 + n], zero beyond N
+  __shared__ __attribute__((aligned(16))) float cf[2 * K];    // scale | shift of the input transform
+  __shared__ __attribute__((aligned(16))) float bs[BWD ? 4 * NP : NP];   // bias | BWD: mask scale, mask shift, mean, 1 / sigma of x
+  __shared__ __attribute__((aligned(16))) float Cs[NW * 1024];  // per wave: one 32x32 block on its way out; at the end: the statistic fold
+  static_assert(sizeof(float) * (K * NP + 2 * K + 4 * NP + NW * 1024) <= 160 * 1024, "gfx950: 160 KB of LDS per CU");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  // XCD-aware decode: the column tiles of one row group walk the same rows at the same time — one XCD, one L2
+  const int nwg = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = b & 7;
+  const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (b >> 3);
+  const int ct = lid % gridDim.x, rg = lid / gridDim.x, nrg = gridDim.y;
+  const int n0 = ct * NP;
+  const bool xform = (P.ka != nullptr);
+
+  for (int i = tid; i < K * NP; i += 64 * NW) {
+    const int k = i / NP, n = n0 + i % NP;
+    Ws[i] = n < P.N ? P.b[(size_t)k * P.ldb + n] : 0.f;
+  }
+  for (int i = tid; i < K; i += 64 * NW) {
+    cf[i] = xform ? P.ka[i] : 1.f;
+    cf[K + i] = xform ? P.kc[i] : 0.f;
+  }
+  for (int i = tid; i < NP; i += 64 * NW) {
+    const int col = min(n0 + i, P.N - 1);
+    if constexpr (BWD) {
+      bs[i] = P.ep_scale ? P.ep_scale[col] : 1.f;
+      bs[NP + i] = P.ep_scale ? P.ep_shift[col] : 0.f;
+      bs[2 * NP + i] = P.stat_mode == 2 ? P.ep_mean[col] : 0.f;
+      bs[3 * NP + i] = P.stat_mode == 2 ? P.ep_invstd[col] : 0.f;
+    } else {
+      bs[i] = (P.bias && n0 + i < P.N) ? P.bias[n0 + i] : 0.f;
+    }
+  }
+  float st1[TN], st2[TN];
+#pragma unroll
+  for (int j = 0; j < TN; j++) st1[j] = st2[j] = 0.f;
+  f32x4 q1[BWD ? TN : 1], q2[BWD ? TN : 1];   // BWD: the lane's sums for the four columns of its pieces, per column block
+  if constexpr (BWD) {
+#pragma unroll
+    for (int j = 0; j < TN; j++) q1[j] = q2[j] = splat4(0.f);
+  }
+  __syncthreads();
+
+  const int nfull = P.M >> 5;
+  const int gw = rg * NW + wave, GW = nrg * NW;
+  float *const cw = Cs + wave * 1024;
+  const float *const wfrag = Ws + KH * lhi * NP + l31;
+  const float *const cfs = cf + KH * lhi, *const cft = cf + K + KH * lhi;
+  const int c4 = (lane & 7) * 4, r0 = lane >> 3;
+  const int ncol = min(NP, P.N - n0);                   // columns of this tile inside the matrix (a multiple of 4)
+  const int jl = (ncol - 1) >> 5;                        // its last column block
+  const int c4l = c4 % (ncol - 32 * jl);                 // lanes beyond the last block's columns repeat a valid column group
+
+  // The lane's K/2 operand values arrive as a stream of NCH chunks per tile through a ring of two register slots: while the
+  // MFMAs of chunk c run, chunk c + 1 is in flight and chunk c + 2 — of this tile or, behind its last two chunks, of the wave's
+  // NEXT tile — is requested as soon as slot c & 1 has been read.  The stream never drains at a tile boundary: the next tile's
+  // first two chunks are requested before this tile's epilogue (and in front of its stores: counted waits).
+  // chunks per tile (even: the slot of a chunk is c & 1 in every tile).  BWD: two pieces per chunk — its epilogue needs the
+  // registers (the forward-input pieces of two column blocks, the per-column sums)
+  constexpr int NCH = BWD ? KQ / 2 : 4;
+  static_assert(NCH % 2 == 0, "an even number of chunks per tile");
+  constexpr int SQ = KQ / NCH;                       // 16-byte pieces per chunk
+  static_assert(KQ % NCH == 0, "the reduction must split into an even number of equal chunks");
+  f32x4 nx[2][SQ];
+  auto req = [&](int t, int c, f32x4 (&slot)[SQ]) __attribute__((always_inline)) {
+    const int row = min(t * 32 + l31, P.M - 1);
+    const float *p = P.a + (size_t)row * P.lda + KH * lhi + 4 * SQ * c;
+#pragma unroll
+    for (int j = 0; j < SQ; j++) slot[j] = ld4(p + 4 * j);
+  };
+  // tile t: its chunks 0 and 1 are in flight (or landed) on entry; tn = the wave's next tile (itself again at the end:
+  // harmless duplicate requests instead of a branch around requests).  The B fragments of k-step s + 1 are read from the
+  // resident slice while the TN MFMAs of k-step s run (two register sets, the order pinned with sched_group_barrier: left
+  // alone the scheduler sinks every ds_read next to its MFMA — read, s_waitcnt lgkmcnt(0), two MFMAs — and with eight
+  // waves on the LDS that round trip is longer than the two MFMAs)
+  DL3_T(long long tp0 = 0; long long tp1 = 0; long long tp2 = 0; int ntl = 0;)
+  auto mfma_tile = [&](f32x16 (&acc)[TN], int t, int tn) __attribute__((always_inline)) {
+    float bf[2][TN];
+#pragma unroll
+    for (int j = 0; j < TN; j++) bf[0][j] = wfrag[j * 32];
+    DL3_T(const long long w1 = clock64();)
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+#pragma unroll
+      for (int q = 0; q < SQ; q++) {
+        const int kq = SQ * c + q;
+        f32x4 v;
+        if constexpr (BWD) v = nx[c & 1][q];
+        else v = dl3_act4(ld4(cfs + 4 * kq) * nx[c & 1][q] + ld4(cft + 4 * kq), P.a_act);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int ks = 4 * kq + e, cur = ks & 1;
+          if (ks + 1 < KH) {
+#pragma unroll
+            for (int j = 0; j < TN; j++) bf[cur ^ 1][j] = wfrag[(ks + 1) * NP + j * 32];
+          }
+#pragma unroll
+          for (int j = 0; j < TN; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[e], bf[cur][j], acc[j], 0, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, TN, 0);   // TN LDS reads (k-step s + 1) ...
+          __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);   // ... then the TN MFMAs of k-step s
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 2 < NCH) req(t, c + 2, nx[c & 1]);
+      else req(tn, c + 2 - NCH, nx[c & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    DL3_T(tp1 += clock64() - w1;)
+  };
+
+  if (gw < nfull) {
+    req(gw, 0, nx[0]);
+    req(gw, 1, nx[1]);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  for (int t = gw; t < nfull; t += GW) {
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+    mfma_tile(acc, t, t + GW < nfull ? t + GW : t);
+    DL3_T(const long long e0 = clock64(); ntl++;)
+#ifdef DL3_WS2_DIRECT_EPILOGUE   // (measured: 160 -> 960 at 524 288 rows 1.51 -> 1.59 ms; kept for the record)
+    // straight from the accumulator layout: register r of lane l is row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31 — a
+    // store instruction writes two 128-byte row segments.  (The HBM-bound sibling pw_fwd_ws_kernel takes the block through
+    // LDS for 16-byte stores of whole rows — four times fewer store instructions, but an LDS round trip per block in a
+    // phase during which the wave issues no MFMA; this kernel is matrix-bound, its epilogue wants to be SHORT.)
+    float *const cp = P.c + (size_t)(t * 32) * P.ldc + n0;        // (wave-uniform)
+    const unsigned lo = (unsigned)(4 * lhi * P.ldc + l31);
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      if (j < jl || (j == jl && j * 32 + l31 < ncol)) {           // (full tiles: uniformly true)
+        const float bj = bs[j * 32 + l31];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const float v = acc[j][r] + bj;
+          st1[j] += v;
+          st2[j] += v * v;
+          __builtin_nontemporal_store(v, &(cp + (size_t)((r & 3) + 8 * (r >> 2)) * P.ldc + j * 32)[lo]);
+        }
+      }
+    }
+#else
+    if constexpr (BWD) {
+      float *const cp = P.c + (size_t)(t * 32 + r0) * P.ldc + n0;
+      const float *const xp = P.ep_x + (size_t)(t * 32 + r0) * P.ld_epx + n0;
+      f32x4 xq[2][4];
+#pragma unroll
+      for (int p = 0; p < 4; p++) xq[0][p] = ld4(xp + (size_t)(8 * p) * P.ld_epx + (0 == jl ? c4l : c4));
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        if (j <= jl) {
+          if (j + 1 <= jl) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) xq[(j + 1) & 1][p] = ld4(xp + (size_t)(8 * p) * P.ld_epx + (j + 1) * 32 + (j + 1 == jl ? c4l : c4));
+          }
+#pragma unroll
+          for (int r = 0; r < 16; r++) cw[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 32 + l31] = acc[j][r];
+          __builtin_amdgcn_wave_barrier();
+          const int cc = (j == jl) ? c4l : c4;
+          const f32x4 es = ld4(bs + j * 32 + cc), et = ld4(bs + NP + j * 32 + cc);
+          const f32x4 mu = ld4(bs + 2 * NP + j * 32 + cc), is = ld4(bs + 3 * NP + j * 32 + cc);
+          // (a lane that repeats a column group — cc != c4 in the last block — stores duplicates but must not count them)
+          const float own = (cc == c4) ? 1.f : 0.f;
+#pragma unroll
+          for (int p = 0; p < 4; p++) {
+            const f32x4 x = xq[j & 1][p];
+            const f32x4 o = ld4(cw + (r0 + 8 * p) * 32 + cc) * dl3_mask4(es * x + et, P.ep_act);
+            st4_nt(cp + (size_t)(8 * p) * P.ldc + j * 32 + cc, o);
+            q1[j] += own * o;
+            q2[j] += own * (o * ((x - mu) * is));
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    } else {
+    float *const cp = P.c + (size_t)(t * 32 + r0) * P.ldc + n0;
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      if (j <= jl) {   // (workgroup-uniform: column blocks wholly beyond N — only in the last column tile — are skipped)
+        const float bj = bs[j * 32 + l31];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const float v = acc[j][r] + bj;
+          st1[j] += v;
+          st2[j] += v * v;
+          cw[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 32 + l31] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int cc = (j == jl) ? c4l : c4;
+        f32x4 o[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) o[p] = ld4(cw + (r0 + 8 * p) * 32 + cc);
+#pragma unroll
+        for (int p = 0; p < 4; p++) st4_nt(cp + (size_t)(8 * p) * P.ldc + j * 32 + cc, o[p]);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    }
+#endif
+    DL3_T(tp2 += clock64() - e0;)
+  }
+#ifdef DL3_PHASE_TIMING
+  if (P.dbg && lane == 0) {
+    long long *d = P.dbg + ((size_t)b * NW + wave) * 8;
+    d[0] = tp0; d[1] = tp1; d[2] = tp2; d[3] = ntl; d[4] = 0; d[5] = 0;
+  }
+#endif
+  if ((P.M & 31) != 0 && gw == nfull % GW) {
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    req(nfull, 0, nx[0]);
+    req(nfull, 1, nx[1]);
+    mfma_tile(acc, nfull, nfull);
+    const int m0 = nfull * 32;
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const int col = n0 + j * 32 + l31;
+      const float bj = BWD ? 0.f : bs[j * 32 + l31];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        float v = acc[j][r] + bj;
+        if (row < P.M && col < P.N) {
+          if constexpr (BWD) {
+            const float x = P.ep_x[(size_t)row * P.ld_epx + col];
+            v *= dl3_act_mask(bs[j * 32 + l31] * x + bs[NP + j * 32 + l31], P.ep_act);
+            st1[j] += v;
+            st2[j] += v * ((x - bs[2 * NP + j * 32 + l31]) * bs[3 * NP + j * 32 + l31]);
+          } else {
+            st1[j] += v;
+            st2[j] += v * v;
+          }
+          P.c[(size_t)row * P.ldc + col] = v;
+        }
+      }
+    }
+  }
+
+  if (P.stat_mode != 0) {
+    // half-waves, then the NW waves in wave order: one partial row per row group
+    __syncthreads();
+    float *sred = Cs;  // [NW][NP][2]
+    if constexpr (BWD) {
+      // the lane's sums for its four columns: over the eight row lanes (lane bits 3-5), then lanes 0-7 own 4 columns each
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+#pragma unroll
+        for (int o = 8; o <= 32; o <<= 1) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            q1[j][e] += __shfl_xor(q1[j][e], o, 64);
+            q2[j][e] += __shfl_xor(q2[j][e], o, 64);
+          }
+        }
+        if (lane < 8) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            sred[(wave * NP + j * 32 + c4 + e) * 2 + 0] = q1[j][e];
+            sred[(wave * NP + j * 32 + c4 + e) * 2 + 1] = q2[j][e];
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const float a1 = st1[j] + __shfl_xor(st1[j], 32, 64), a2 = st2[j] + __shfl_xor(st2[j], 32, 64);
+      if (lhi == 0) {
+        // (BWD: st1 / st2 only hold the ragged last tile's share, on top of the row-piece sums written above)
+        sred[(wave * NP + j * 32 + l31) * 2 + 0] = (BWD ? sred[(wave * NP + j * 32 + l31) * 2 + 0] : 0.f) + a1;
+        sred[(wave * NP + j * 32 + l31) * 2 + 1] = (BWD ? sred[(wave * NP + j * 32 + l31) * 2 + 1] : 0.f) + a2;
+      }
+    }
+    __syncthreads();
+    for (int cl = tid; cl < NP; cl += 64 * NW) {
+      const int col = n0 + cl;
+      if (col < P.N) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+          a1 += sred[(w * NP + cl) * 2 + 0];
+          a2 += sred[(w * NP + cl) * 2 + 1];
+        }
+        P.part[((size_t)rg * P.N + col) * 2 + 0] = a1;
+        P.part[((size_t)rg * P.N + col) * 2 + 1] = a2;
+        for (int r = rg + nrg; r < P.part_rows; r += nrg) {
+          P.part[((size_t)r * P.N + col) * 2 + 0] = 0.f;
+          P.part[((size_t)r * P.N + col) * 2 + 1] = 0.f;
+        }
+      }
+    }
+  }
+}
+
 // ---- small batches (round 5): 32 rows x all N <= 160 columns per workgroup, the REDUCTION split over the four
 // waves.  At B = 2 - 4 the 64x64 maps are 8 192 - 16 384 rows: the 32-row stream kernels put their four waves side by side
 // along N (64 columns each), which pads a 160-wide output to 256 columns (1.6x the MFMAs) and a 96-wide one to 128, on a
@@ -1755,6 +2011,35 @@ int ws_grid(int M) {
   const int g = dl3_cdiv(tiles, 4);
   return g < 768 ? g : 768;
 }
+#ifndef DL3_WS2_NW
+#define DL3_WS2_NW 8
+#endif
+// round 6: the weight-stationary kernel for MFMA-bound short reductions (pw_ws2_kernel): row groups per column tile — one
+// workgroup per CU over all column tiles
+int ws2_groups(int M, int ntn) {
+  const int tiles = dl3_cdiv(M, 32);
+  int g = 256 / ntn;
+  if (g < 1) g = 1;
+  const int cap = dl3_cdiv(tiles, DL3_WS2_NW);
+  return g < cap ? g : cap;
+}
+// shapes it takes: a reduction of 160 or 96 (MobileNetV2's 64 x 64 blocks, deeplabv3p.py:175-198) into an output at least twice
+// as wide, from 131 072 rows (B >= 32: below, a wave walks too few tiles to pay for loading its 60-100 KB weight slice;
+// 65 536 rows: 0.195 -> 0.22 ms).  DL3_WS2=0: the tiled stream kernel serves everything (read once).
+bool ws2_shape(int M, int K, int N) {
+  static const int env = env_int("DL3_WS2");
+  if (env == 0) return false;
+  return M >= 131072 && ((K == 160 && N % 4 == 0 && N >= 320) || (K == 96 && N % 4 == 0 && N >= 192));
+}
+// 1: forward, 2: bwd-data (single-tensor dY, mask and BatchNorm-backward sums from the forward input, no addend), 0: no
+int ws2_wanted(const GemmArgs &A, bool fwd, bool vec) {
+  if (!vec || A.ep_add || A.a2 || A.bias && !fwd) return 0;
+  if (A.ldc % 4 != 0 || (((uintptr_t)A.c) & 15) != 0 || !ws2_shape(A.M, A.K, A.N)) return 0;
+  if (fwd) return 1;
+  if (A.ka || !A.ep_x || A.ld_epx % 4 != 0 || (((uintptr_t)A.ep_x) & 15) != 0 || A.stat_mode == 1) return 0;
+  return 2;
+}
+
 // forward launch served by the weight-stationary kernel?  (DL3_FWD_WS=0 disables; the tiled kernel serves everything)
 bool ws_wanted(const GemmArgs &A, bool fwd, bool vec) {
   static const int env = env_int("DL3_FWD_WS");
@@ -1817,7 +2102,7 @@ bool pre_wanted(const GemmArgs &A) {
   return A.K <= (kmax > 0 ? kmax : 320) && A.N % 96 == 0 && A.N >= 2 * A.K && A.M >= 65536;
 }
 
-int gemm_grid_y(int M, int N, const GemmCfg &c) {
+int gemm_grid_y(int M, int N, const GemmCfg &c, int K = 0) {
   const int mtiles = dl3_cdiv(M, c.BM), ntn = dl3_cdiv(N, c.BN);
   // target number of workgroups per launch (DL3_GEMM_PY overrides: tuning aid).  Measured on MI355X, whole step:
   const int pytot = env_int("DL3_GEMM_PY");
@@ -1825,7 +2110,13 @@ int gemm_grid_y(int M, int N, const GemmCfg &c) {
   // its row tiles (sweep at B=64: 256 -> 64.3 ms, 384 -> 66.4, 512 -> 57.7, 640 -> 63.0, 768 -> 60.3, 2048 -> 58.4: any
   // count that is not a whole number of waves of the chip leaves a ragged last wave); fewer tiles: several waves of
   // short workgroups balance better (B=2: 2048 -> 4.97 ms, 512 -> 5.08)
-  const int dflt = ((long)mtiles * ntn >= 2048) ? 512 : DL3_GEMM_PY_DEFAULT;
+  // round 6: ... and 5-16 LONG tiles per resident workgroup (reduction >= 512, at most 1 024 row tiles: Xception at B = 16 / 32)
+  // do not want the persistent loop either: a workgroup that walks 5 or 6 such tiles wastes up to a fifth of the launch on
+  // the quantisation, which the dispatcher's own balancing of one- or two-tile workgroups does not (same-call A/B, cfg4 B=16:
+  // 736 -> 736 forward 0.680 -> 0.630 ms, 1536 -> 1536 2.65 -> 2.46; 85.2 -> 87.4 img/s; MobileNetV2 B=16 / 128 unchanged / -0.5 %)
+  const long tiles = (long)mtiles * ntn;
+  const bool long_few = K >= 512 && mtiles <= 1024 && tiles < 8192;
+  const int dflt = long_few ? 4096 : (tiles >= 2048 ? 512 : DL3_GEMM_PY_DEFAULT);
   int py = (pytot > 0 ? pytot : dflt) / ntn;
   if (py < 32) py = 32;
   if (mtiles <= py) return mtiles;
@@ -1837,30 +2128,6 @@ int gemm_grid_y(int M, int N, const GemmCfg &c) {
   const int ragged = env_int("DL3_GEMM_RAGGED");
   if (ragged == 1 || (ragged != 0 && (long)even * ntn * 10 < 512L * 9)) return py;
   return even;
-}
-
-// exact-width last column tile (pw_gemm_stream_kernel<1, 5, ..., JV = 3>): N = q * 160 + 96 with q >= 1 — the 128 x 160
-// configuration on everything but the last 96 columns.  DL3_GEMM_JV=0 switches it off (tuning aid / A-B).
-constexpr int kJvBlocks = 3;
-bool jv_shape(int N) {
-  static const int env = env_int("DL3_GEMM_JV");
-  return env != 0 && N > 160 && N % 160 == 32 * kJvBlocks;
-}
-// row slots per column tile: py_full for the 160-wide tiles, py_last for the 96-wide one, sized so that every workgroup
-// carries the same number of 32-column block-tiles (the narrow tile is 3/5 of a wide one: its workgroups walk 5/3 as many
-// row tiles).  Few row tiles: one workgroup per tile, as gemm_grid_y does.
-void jv_grid(int M, int N, int *py_full, int *py_last) {
-  const int mtiles = dl3_cdiv(M, 128), ntn = dl3_cdiv(N, 160);
-  const int pytot = env_int("DL3_GEMM_PY");
-  const int total = pytot > 0 ? pytot : (((long)mtiles * ntn >= 2048) ? 512 : DL3_GEMM_PY_DEFAULT);
-  int pf = (int)(total / ((ntn - 1) + (double)kJvBlocks / 5.0));
-  if (pf < 32) pf = 32;
-  if (pf >= mtiles) { *py_full = *py_last = mtiles; return; }
-  int pl = total - pf * (ntn - 1);
-  if (pl < 1) pl = 1;
-  if (pl > pf) pl = pf;
-  *py_full = pf;
-  *py_last = pl;
 }
 
 // split math (opt-in): device scratch for the packed weights of the launch in flight, one buffer per DEVICE.  Launches on
@@ -1925,6 +2192,23 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   // (a per-image addend stays on the forward instantiation when its straight-line epilogue can take it: 32-row blocks
   // inside one image)
   const bool fwd = !two && !A.ep_x && A.stat_mode != 2 && !(A.ep_add && A.add_div > 1 && A.add_div % 32 != 0);
+  if (const int w2 = split_math() ? 0 : ws2_wanted(A, fwd, vec)) {
+    const int tn = A.K == 160 ? 5 : 3, ntn = dl3_cdiv(A.N, 32 * tn), nrg = ws2_groups(A.M, ntn);
+    if (w2 == 2) {
+      const dim3 grid(ntn, nrg);
+      if (A.K == 160) hipLaunchKernelGGL((pw_ws2_kernel<20, 5, DL3_WS2_NW, true>), grid, dim3(64 * DL3_WS2_NW), 0, st, A);
+      else hipLaunchKernelGGL((pw_ws2_kernel<12, 3, DL3_WS2_NW, true>), grid, dim3(64 * DL3_WS2_NW), 0, st, A);
+      return nrg;
+    }
+    const dim3 grid(ntn, nrg), blk(512);
+    DL3_T(A.dbg = g_phase_dbg;)
+#ifndef DL3_WS2_NW
+#define DL3_WS2_NW 8
+#endif
+    if (A.K == 160) hipLaunchKernelGGL((pw_ws2_kernel<20, 5, DL3_WS2_NW>), grid, dim3(64 * DL3_WS2_NW), 0, st, A);
+    else hipLaunchKernelGGL((pw_ws2_kernel<12, 3, DL3_WS2_NW>), grid, dim3(64 * DL3_WS2_NW), 0, st, A);
+    return nrg;
+  }
   if (ws_wanted(A, fwd, vec) && !split_math()) {
     const dim3 grid(ws_grid(A.M)), blk(256);
 #define DL3_WS(KQ_, TN_, OC_) hipLaunchKernelGGL((pw_fwd_ws_kernel<KQ_, TN_, OC_>), grid, blk, 0, st, A)
@@ -1959,24 +2243,9 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   }
   GemmCfg c = pick_gemm(A.M, A.K, A.N, two, stream, fwd);
   if (stream && pre_ok(A) && pre_wanted(A)) c = kGemmCfgs[4];
-  if (stream && !split_math() && jv_shape(A.N) && A.M >= 128 && !(c.id == 4 && pre_ok(A)) &&
-      dl3_cdiv(A.N, c.BN) * c.BN != A.N) {
-    // (only where every configuration pads: 736; 256 = 2 x 128 and 576 = 6 x 96 keep their exact tilings)
-    // 128 x 160 tiles + one exact 96-wide last column tile, balanced persistent grid
-    int pf, pl;
-    jv_grid(A.M, A.N, &pf, &pl);
-    A.mtiles = dl3_cdiv(A.M, 128);
-    A.py_last = pl;
-    DL3_T(A.dbg = g_phase_dbg;)
-    const dim3 grid(dl3_cdiv(A.N, 160), pf), blk(256);
-    if (two) hipLaunchKernelGGL((pw_gemm_stream_kernel<1, 5, true, 16, 0, 1, 0, kJvBlocks>), grid, blk, 0, st, A);
-    else if (fwd) hipLaunchKernelGGL((pw_gemm_stream_kernel<1, 5, false, DL3_STREAM_KT_FWD, 1, 1, 0, kJvBlocks>), grid, blk, 0, st, A);
-    else hipLaunchKernelGGL((pw_gemm_stream_kernel<1, 5, false, DL3_STREAM_KT_BWD1, 0, 1, 0, kJvBlocks>), grid, blk, 0, st, A);
-    return pf;
-  }
   A.mtiles = dl3_cdiv(A.M, c.BM);
   DL3_T(A.dbg = g_phase_dbg;)
-  dim3 grid(dl3_cdiv(A.N, c.BN), gemm_grid_y(A.M, A.N, c));
+  dim3 grid(dl3_cdiv(A.N, c.BN), gemm_grid_y(A.M, A.N, c, A.K));
   // stream-A kernel: 10-25 % faster than the LDS-staged kernel on every layer shape, forward and bwd-data
   // (tools/gemm_tune.py).  The two-tensor bwd-data operand uses 16-deep K-tiles so that its register budget does not
   // spill.  DL3_GEMM_IMPL=0 forces the staged kernel (which also serves unaligned operands).
@@ -2146,24 +2415,23 @@ extern "C" int dl3_pwconv_partials(int M, int K, int N) {
   for (int two = 0; two < 2; two++)
     for (int small = 0; small < 2; small++)
       for (int fwd = 0; fwd < 2; fwd++) {
-        const int q = gemm_grid_y(M, N, pick_gemm(M, K, N, two != 0, small != 0, fwd != 0));
+        const int q = gemm_grid_y(M, N, pick_gemm(M, K, N, two != 0, small != 0, fwd != 0), K);
         p = q > p ? q : p;
       }
   if (ws_tn(K, N)) {  // the weight-stationary forward kernel writes one row per workgroup
     const int q = ws_grid(M);
     p = q > p ? q : p;
   }
+  if (ws2_shape(M, K, N)) {
+    const int q = ws2_groups(M, dl3_cdiv(N, K == 160 ? 160 : 96));
+    p = q > p ? q : p;
+  }
   if (ksplit_tn(M, K, N)) {  // the K-split kernel of the small batches: one row per 32-row tile
     const int q = dl3_cdiv(M, 32);
     p = q > p ? q : p;
   }
-  if (jv_shape(N) && M >= 128) {  // exact-width last column tile: its own balanced grid (run_gemm)
-    int pf, pl;
-    jv_grid(M, N, &pf, &pl);
-    p = pf > p ? pf : p;
-  }
   if (N % 96 == 0) {  // the prefetching bwd-data variant overrides the choice with the 128x96 tile (run_gemm)
-    const int q = gemm_grid_y(M, N, kGemmCfgs[4]);
+    const int q = gemm_grid_y(M, N, kGemmCfgs[4], K);
     p = q > p ? q : p;
   }
   return p;

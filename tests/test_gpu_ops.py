@@ -517,10 +517,8 @@ def test_pwconv_bwd_weight_writes_dy(L, case):
 
 @pytest.mark.parametrize("cfg", range(10))
 def test_pwconv_bwd_weight_dy_every_tile_configuration(L, cfg, monkeypatch):
-    """round 6: the dY stores of the weight-gradient kernel are a contiguous range of each workgroup's stages (no-store /
-    store / no-store segments), issued behind the next stage's requests, with rows beyond M and column groups beyond N
-    clamped onto valid ones — every tile configuration, K and N ragged against every tile size (1 - 7 workgroups share a
-    row slab), M not a multiple of the 16-row stage, 1 - 5 valid 32-blocks in the edge tiles (idle waves skip their MFMAs)"""
+    """dl3_pwconv_bwd_weight_dy under every tile configuration: K and N ragged against every tile size (1 - 7 workgroups share
+    a row slab and take turns with the dY stores), M not a multiple of the 16-row stage, fewer rows than one stage"""
     monkeypatch.setenv("DL3_WGRAD_CFG", str(cfg))
     for case in ((1003, 200, 328, 2, True, False), (2570, 960, 160, 1, True, False), (333, 96, 576, None, True, False),
                  (40, 160, 960, 2, True, False)):
@@ -538,15 +536,34 @@ def test_pwconv_bwd_weight_dy_benchmark_routes(L, case):
     test_pwconv_bwd_weight_writes_dy(L, case)
 
 
-JV_CASES = [(1300, 736, 736), (52480 + 37, 736, 736), (700, 64, 416), (256, 2048, 256)]
+@pytest.mark.parametrize("case", [(266000 + 17, 160, 960, 0, 0, False, 2), (140000, 96, 576, 0, 0, True, 1),
+                                  (133000, 160, 320, 0, 64, False, None), (131072 + 5, 160, 1000, 0, 0, False, 2)])
+def test_pwconv_fwd_weight_stationary_short_reductions(L, case):
+    """round 6 (pw_ws2_kernel, forward): a reduction of 160 / 96 into an output at least twice as wide from 131 072 rows — the
+    whole weight slice of a column tile resident in LDS, eight waves walking 32-row tiles without a barrier: ragged last row
+    tile, a last column tile with 8 of its 160 columns (N = 1 000), bias, an output that is a channel slice"""
+    assert L.dl3_pwconv_partials(case[0], case[1], case[2]) >= 1
+    test_pwconv_fwd(L, case)
 
 
-@pytest.mark.parametrize("M,K,N", JV_CASES)
-def test_pwconv_exact_width_last_column_tile(L, M, K, N, monkeypatch):
-    """round 6 (pw_gemm_stream_kernel<1, 5, ..., JV = 3>): N = q x 160 + 96 runs 160-wide column tiles plus ONE exact 96-wide
-    tile whose workgroups walk 5/3 as many row tiles (balanced persistent grid; some row slots of the last column return at
-    once): forward with BatchNorm sums, two-tensor and single-tensor bwd-data with mask, addend and sums, ragged last row
-    tile, few and many row tiles — and DL3_GEMM_JV=0 (read once per process: checked through the partial-row count only)"""
+@pytest.mark.parametrize("case", [(262144 + 19, 960, 160, 2, False, 0, True), (131072, 576, 96, 2, False, 0, True),
+                                  (140000, 1000, 160, 1, False, 0, True), (133000, 384, 96, None, False, 0, True),
+                                  (131072 + 7, 320, 160, 2, False, 0, False)])
+def test_pwconv_bwd_data_weight_stationary_short_reductions(L, case):
+    """... and its bwd-data instantiation (single-tensor dY): activation mask from the forward input requested in the row-piece
+    layout the output leaves in, BatchNorm-backward sums kept per lane for four columns and folded over the row lanes at the
+    end; ragged last row tile, ragged last column tile (K = 1 000), no mask, no sums"""
+    test_pwconv_bwd_data(L, case)
+
+
+WIDE_CASES = [(1300, 736, 736), (52480 + 37, 736, 736), (700, 64, 416), (256, 2048, 256)]
+
+
+@pytest.mark.parametrize("M,K,N", WIDE_CASES)
+def test_pwconv_long_reduction_few_row_tiles(L, M, K, N):
+    """round 6: launches with a long reduction and at most 1 024 row tiles (Xception at B = 16 / 32: 736 -> 736 at 65 536 rows)
+    leave the persistent 512-workgroup loop for one or two tiles per workgroup (gemm_grid_y): forward with BatchNorm sums,
+    two-tensor and single-tensor bwd-data with mask, addend and sums, a ragged last row tile, N = 4 x 160 + 96"""
     test_pwconv_fwd(L, (M, K, N, 0, 0, False, 1))
     test_pwconv_fwd(L, (M, K, N, 0, 32, True, None))
     if N == K:

@@ -1,0 +1,9 @@
+#!/bin/bash
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+out=$REPO/gpurun_out/c10; mkdir -p $out; cd $REPO
+DL3_WS2=1 timeout 600 python -m pytest tests/gpu_ws2_probe.py -q -x 2>&1 | tail -3
+S="fwd:524288x160x960 fwd:524288x96x576 fwd:262144x160x960"
+for rep in 1 2; do
+for v in "DL3_WS2=0" "DL3_WS2=1"; do echo "## $v"; env $v python tools/r6/gemm_bench.py $S; done
+done 2>&1 | grep -v amdgpu.ids | tee $out/ws2.txt
+for v in 1; do echo "## DL3_WS2=$v"; DL3_WS2=$v PROBE_KINDS=fwd PROBE_SHAPES=4096x160x960,4096x96x576 python tools/r3/phase_probe.py 128; done 2>&1 | grep -v amdgpu.ids | tee $out/phase.txt
