@@ -2023,14 +2023,15 @@ int ws2_groups(int M, int ntn) {
   const int cap = dl3_cdiv(tiles, DL3_WS2_NW);
   return g < cap ? g : cap;
 }
-// shapes it takes: a reduction of 160 or 96 (MobileNetV2's 64 x 64 blocks, deeplabv3p.py:175-198) into an output at least twice
+// shapes it takes: a reduction of 160, 96 or 64 (MobileNetV2's 64 x 64 blocks, deeplabv3p.py:175-198) into an output at least twice
 // as wide, from 131 072 rows (B >= 32: below, a wave walks too few tiles to pay for loading its 60-100 KB weight slice;
 // 65 536 rows: 0.195 -> 0.22 ms).  DL3_WS2=0: the tiled stream kernel serves everything (read once).
 bool ws2_shape(int M, int K, int N) {
   static const int env = env_int("DL3_WS2");
   if (env == 0) return false;
-  return M >= 131072 && ((K == 160 && N % 4 == 0 && N >= 320) || (K == 96 && N % 4 == 0 && N >= 192));
+  return M >= 131072 && N % 4 == 0 && ((K == 160 && N >= 320) || (K == 96 && N >= 192) || (K == 64 && N >= 128));
 }
+inline int ws2_tn(int K) { return K == 160 ? 5 : (K == 96 ? 3 : 4); }
 // 1: forward, 2: bwd-data (single-tensor dY, mask and BatchNorm-backward sums from the forward input, no addend), 0: no
 int ws2_wanted(const GemmArgs &A, bool fwd, bool vec) {
   if (!vec || A.ep_add || A.a2 || A.bias && !fwd) return 0;
@@ -2193,11 +2194,12 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   // inside one image)
   const bool fwd = !two && !A.ep_x && A.stat_mode != 2 && !(A.ep_add && A.add_div > 1 && A.add_div % 32 != 0);
   if (const int w2 = split_math() ? 0 : ws2_wanted(A, fwd, vec)) {
-    const int tn = A.K == 160 ? 5 : 3, ntn = dl3_cdiv(A.N, 32 * tn), nrg = ws2_groups(A.M, ntn);
+    const int tn = ws2_tn(A.K), ntn = dl3_cdiv(A.N, 32 * tn), nrg = ws2_groups(A.M, ntn);
     if (w2 == 2) {
       const dim3 grid(ntn, nrg);
       if (A.K == 160) hipLaunchKernelGGL((pw_ws2_kernel<20, 5, DL3_WS2_NW, true>), grid, dim3(64 * DL3_WS2_NW), 0, st, A);
-      else hipLaunchKernelGGL((pw_ws2_kernel<12, 3, DL3_WS2_NW, true>), grid, dim3(64 * DL3_WS2_NW), 0, st, A);
+      else if (A.K == 96) hipLaunchKernelGGL((pw_ws2_kernel<12, 3, DL3_WS2_NW, true>), grid, dim3(64 * DL3_WS2_NW), 0, st, A);
+      else hipLaunchKernelGGL((pw_ws2_kernel<8, 4, DL3_WS2_NW, true>), grid, dim3(64 * DL3_WS2_NW), 0, st, A);
       return nrg;
     }
     const dim3 grid(ntn, nrg), blk(512);
@@ -2206,7 +2208,8 @@ int run_gemm(GemmArgs A, hipStream_t st) {
 #define DL3_WS2_NW 8
 #endif
     if (A.K == 160) hipLaunchKernelGGL((pw_ws2_kernel<20, 5, DL3_WS2_NW>), grid, dim3(64 * DL3_WS2_NW), 0, st, A);
-    else hipLaunchKernelGGL((pw_ws2_kernel<12, 3, DL3_WS2_NW>), grid, dim3(64 * DL3_WS2_NW), 0, st, A);
+    else if (A.K == 96) hipLaunchKernelGGL((pw_ws2_kernel<12, 3, DL3_WS2_NW>), grid, dim3(64 * DL3_WS2_NW), 0, st, A);
+    else hipLaunchKernelGGL((pw_ws2_kernel<8, 4, DL3_WS2_NW>), grid, dim3(64 * DL3_WS2_NW), 0, st, A);
     return nrg;
   }
   if (ws_wanted(A, fwd, vec) && !split_math()) {
@@ -2423,7 +2426,7 @@ extern "C" int dl3_pwconv_partials(int M, int K, int N) {
     p = q > p ? q : p;
   }
   if (ws2_shape(M, K, N)) {
-    const int q = ws2_groups(M, dl3_cdiv(N, K == 160 ? 160 : 96));
+    const int q = ws2_groups(M, dl3_cdiv(N, 32 * ws2_tn(K)));
     p = q > p ? q : p;
   }
   if (ksplit_tn(M, K, N)) {  // the K-split kernel of the small batches: one row per 32-row tile

@@ -210,14 +210,17 @@ def test_cfg4_xception_os8_512_forward():
     x, _, _ = _data(shape, 2, classes, seed=2)
     params = T.calibrate_bn(params, x, dtype=torch.float32, **kw)  # moving statistics from the 2-image batch
     _load(model, params)
-    # VERDICT r4 #6: the HIP path's argmax against float64 should not flip more pixels than torch-fp32's does.  On ONE
-    # image the two counts are a draw (round 5, tools/r5/xception_layer_distance.py --seed 2..5, statistics calibrated per
-    # seed: gpu/fp32 = 45/29, 40/60, 44/48, 34/38; a one-ulp change of the stem convolution's summation moved image 0 from
-    # 45 to 52 — the image-pooling branch's error is one vector per image, added to every pixel: coherent, its direction
-    # decides), so the bar is on the sum over four images and leaves room for that draw; per image the flips must sit on
-    # pixels fp32 cannot resolve (_flips: margin and the GPU's own logit error at every flipped pixel under the fp32 yardstick).
-    flips_gpu = flips_32 = 0
-    for i, x1 in enumerate([x[:1]] + [_data(shape, 1, classes, seed=sd)[0] for sd in (3, 4, 5)]):
+    # VERDICT r4 #6 / r5 #6: the HIP path's argmax against float64 should not flip more pixels than torch-fp32's does.  On ONE
+    # image the two counts are a draw (the image-pooling branch's error is one vector per image, added to every pixel:
+    # coherent, its direction decides; a one-ulp change of the stem convolution's summation moved image 0 by 7 flips), so the
+    # question is asked of SIXTEEN images (round 6, tools/r6/xception_argmax_stats.py, profiles/r06_xception_argmax_16.txt:
+    # gpu 262 / torch-fp32 306 flips, the HIP path ahead on 12 of the 16, mean logits error 8.91e-5 / 8.90e-5) and the bar
+    # is the one VERDICT r5 set: the sum within 1.15 x torch-fp32's + 5.  Per image the flips must sit on pixels fp32
+    # cannot resolve (_flips: margin and the GPU's own logit error at every flipped pixel under the fp32 yardstick).
+    flips_gpu = flips_32 = ahead = 0
+    n_img = 16
+    for i in range(n_img):
+        x1 = x[:1] if i == 0 else _data(shape, 1, classes, seed=2 + i)[0]
         probs = model.predict(x1, batch_size=1)
         got = model._active.logits()
         ref = T.infer_logits(params, x1, dtype=torch.float64, **kw)
@@ -225,11 +228,14 @@ def test_cfg4_xception_os8_512_forward():
         e = relerr(got, ref)
         print("xception OS=8 512x512 forward, image %d: logits rel err %.2e (oracle fp32: %.2e)" % (i, e, relerr(ref32, ref)))
         assert e < 1e-3
-        flips_gpu += _flips(model._active.argmax(), ref, ref32, "xception OS=8 512x512 B=1 image %d" % i, got=got)
-        flips_32 += int((ref32.argmax(-1) != ref.argmax(-1)).sum())
-        assert np.allclose(probs.reshape(ref.shape), O.softmax(ref), atol=1e-3 * float(np.abs(ref).max()))
-    print("xception OS=8 512x512 forward, four images: argmax flips gpu %d, torch-fp32 %d" % (flips_gpu, flips_32))
-    assert flips_gpu <= 1.5 * flips_32 + 10, (flips_gpu, flips_32)
+        fg = _flips(model._active.argmax(), ref, ref32, "xception OS=8 512x512 B=1 image %d" % i, got=got)
+        f32 = int((ref32.argmax(-1) != ref.argmax(-1)).sum())
+        flips_gpu, flips_32, ahead = flips_gpu + fg, flips_32 + f32, ahead + (fg < f32) - (fg > f32)
+        if i < 2:
+            assert np.allclose(probs.reshape(ref.shape), O.softmax(ref), atol=1e-3 * float(np.abs(ref).max()))
+    print("xception OS=8 512x512 forward, %d images: argmax flips gpu %d, torch-fp32 %d (gpu ahead on %+d images net)" % (
+        n_img, flips_gpu, flips_32, ahead))
+    assert flips_gpu <= 1.15 * flips_32 + 5, (flips_gpu, flips_32)
 
 
 def test_cfg4_xception_os8_256_train_step():
@@ -313,6 +319,7 @@ def _benchmarked_plan(backbone, OS, Bbig, monkeypatch, oracle_pair):
     print("%s OS=%d B=%d frozen-BN plan: %d fwd + %d bwd launches, loss %.7f" % (
         backbone, OS, Bbig, len(big.ops_fwd), len(big.ops_bwd), loss_big))
     yard = None   # the oracle's own fp32-to-float64 gradient distance at this size (the noise floor of ANY fp32 evaluation)
+    yard_logits = None   # ... and its logits distance
 
     del big, snaps
     _drop_engines(model)
@@ -349,6 +356,7 @@ def _benchmarked_plan(backbone, OS, Bbig, monkeypatch, oracle_pair):
                   % (e, relerr(lo32, lo64), np.sqrt(num / den), np.sqrt(n32 / den)))
             assert e < 1e-3 and np.sqrt(num / den) < max(2e-3, 2.0 * np.sqrt(n32 / den))
             yard = float(np.sqrt(n32 / den))
+            yard_logits = float(relerr(lo32, lo64))
     torch.cuda.synchronize()
     lg_small = torch.cat(lgs, 0)
     e_log = float((lg_big - lg_small).abs().max() / lg_small.abs().max())
@@ -369,7 +377,11 @@ def _benchmarked_plan(backbone, OS, Bbig, monkeypatch, oracle_pair):
     # in fp32 summation order: forward agrees to ~1e-5, and a ReLU6 mask that flips on a pre-activation within that noise
     # moves a gradient by its square root — both engines are draws of the same fp32 noise, whose size the oracle's own
     # fp32 run measures (yard).  An index or plan bug at large M shows up as an O(1) error in some tensor.
-    assert e_log < 5e-5 and e_loss < 1e-5
+    # (round 6: the two plans of cfg4 used to take the same kernel for every layer and agreed bit for bit in the logits; since the
+    # weight-stationary kernel serves reductions of 64 from 131 072 rows, entry_flow_block1's stride-2 shortcut runs on it at
+    # B=16 and on the tiled kernel at B=2 — another summation order.  The bound is the oracle's own fp32 distance: two fp32
+    # evaluations may part by as much as ONE of them parts from float64.)
+    assert e_log < max(5e-5, yard_logits or 0.0) and e_loss < 1e-5
     assert whole < max(1e-3, 0.5 * yard if yard else 2e-3) and worst < 3e-2
     del small
     _drop_engines(model)
@@ -415,7 +427,7 @@ def test_benchmarked_plan_b128(monkeypatch):
 def test_benchmarked_plan_cfg4_b16(monkeypatch):
     """cfg4 (Xception OS=8) at the batch bench.py times it at (B=16) against eight runs of the B=2 engine (whose batch-mode
     twin is oracle-checked at this size by test_cfg4_xception_os8_512_train_step)"""
-    model, x, labels, sw = _benchmarked_plan("xception", 8, 16, monkeypatch, oracle_pair=False)
+    model, x, labels, sw = _benchmarked_plan("xception", 8, 16, monkeypatch, oracle_pair=True)
     _batch_statistics_check(model, 16, x, labels, sw)
 
 

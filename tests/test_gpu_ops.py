@@ -537,7 +537,8 @@ def test_pwconv_bwd_weight_dy_benchmark_routes(L, case):
 
 
 @pytest.mark.parametrize("case", [(266000 + 17, 160, 960, 0, 0, False, 2), (140000, 96, 576, 0, 0, True, 1),
-                                  (133000, 160, 320, 0, 64, False, None), (131072 + 5, 160, 1000, 0, 0, False, 2)])
+                                  (133000, 160, 320, 0, 64, False, None), (131072 + 5, 160, 1000, 0, 0, False, 2),
+                                  (131072 + 33, 64, 384, 64, 0, False, 2), (140000, 64, 200, 0, 0, False, None)])
 def test_pwconv_fwd_weight_stationary_short_reductions(L, case):
     """round 6 (pw_ws2_kernel, forward): a reduction of 160 / 96 into an output at least twice as wide from 131 072 rows — the
     whole weight slice of a column tile resident in LDS, eight waves walking 32-row tiles without a barrier: ragged last row
@@ -548,7 +549,8 @@ def test_pwconv_fwd_weight_stationary_short_reductions(L, case):
 
 @pytest.mark.parametrize("case", [(262144 + 19, 960, 160, 2, False, 0, True), (131072, 576, 96, 2, False, 0, True),
                                   (140000, 1000, 160, 1, False, 0, True), (133000, 384, 96, None, False, 0, True),
-                                  (131072 + 7, 320, 160, 2, False, 0, False)])
+                                  (131072 + 7, 320, 160, 2, False, 0, False), (131072 + 40, 384, 64, None, False, 0, True),
+                                  (150000, 200, 64, 2, False, 0, True)])
 def test_pwconv_bwd_data_weight_stationary_short_reductions(L, case):
     """... and its bwd-data instantiation (single-tensor dY): activation mask from the forward input requested in the row-piece
     layout the output leaves in, BatchNorm-backward sums kept per lane for four columns and folded over the row lanes at the
