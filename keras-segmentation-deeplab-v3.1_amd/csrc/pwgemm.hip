@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -1212,6 +1213,317 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(WgradArgs P) {
     d[0] = 0; d[1] = clock64() - tstart; d[2] = 0; d[3] = nst; d[4] = tw_vm; d[5] = tw_bar;
   }
 #endif
+  float *out = P.ws + (size_t)bz * P.K * P.N;
+#pragma unroll
+  for (int i = 0; i < TA; i++)
+#pragma unroll
+    for (int j = 0; j < TB; j++) {
+      const int col = nbase + (wb * TB + j) * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int krow = kbase + (wa * TA + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (krow < P.K && col < P.N) out[(size_t)krow * P.N + col] = acc[i][j][r];
+      }
+    }
+}
+
+// ---- round 6: the weight gradient of a layer whose whole reduction-side width fits ONE tile row (K <= 32 TA WA: the expand
+// convolutions 96 -> 576 and 160 -> 960, deeplabv3p.py:175-178) — the HBM-heavy half of the family (a narrow x, a wide g / y,
+// and the dY store on top: 3.4 - 3.9 TB/s in the tiled kernel).  One workgroup per row slab stages every dY stage exactly
+// once, so the dY store needs no ownership at all and the stage loop is straight-line:
+//   * the dY store (DYS) is a template parameter: every lane stores every piece (rows beyond M and column groups beyond N are clamped onto
+//     valid ones: same address, same bits) — no store sits in a branch;
+//   * the NEXT stage's operands are requested BEFORE this stage's stores: vmcnt retires in order and counts stores, so a
+//     request issued behind a store cannot be waited for without waiting for the store; this way the wait is a counted
+//     vmcnt(#stores) that leaves them in flight for a whole further stage (ISA: s_waitcnt vmcnt(2) in the loop);
+//   * the per-column coefficient vectors live in LDS instead of 40-52 hoisted registers;
+//   * waves whose 32-column blocks lie wholly beyond N (the half-empty last column tile of N = 960 / 576 on 128-wide
+//     tiles) skip their MFMAs and leave the SIMD's matrix pipe to the co-resident workgroup.
+// Same-box microbenchmark against pw_wgrad_kernel (profiles/r06_ab_calls.txt call 3): 96 -> 576 0.941 -> 0.860 ms, 160 -> 960
+// 1.945 -> 1.841 ms.  With several workgroups per row slab (K > one tile row) the same structure LOST 2-9 % — whichever
+// way the stores were shared out, the slab's workgroups fell out of step and re-read g / y from HBM instead of the XCD's
+// L2 — so those launches stay on pw_wgrad_kernel.
+template <int TA, int TB, int WA, int WB, bool DYS>
+__global__ __launch_bounds__(256, 2) void pw_wgrad_row_kernel(WgradArgs P) {
+  constexpr int VEC = 1;
+  constexpr bool SPL = false;
+  constexpr bool XVEC = VEC != 0, DVEC = VEC == 1;
+  static_assert(WA * WB == 4, "4 waves per workgroup");
+  // SPL: split math (see split3).  The reduction index is the pixel row, and a bf16 MFMA wants 8 CONSECUTIVE reduction
+  // elements per lane: lane (column c, half h) gathers rows 8h..8h+7 of its column from the fp32 stage in LDS (the same
+  // number of ds_read_b32 per pixel as the f32 MFMA's one-per-k-step), splits them in registers, and one 16-row stage is
+  // one k-step of six bf16 MFMAs per 32x32 sub-tile.
+  static_assert(!SPL || DL3_WGRAD_MS == 16, "split math: a stage is one 16-deep bf16 MFMA k-step");
+  constexpr int BKT = 32 * TA * WA, BNT = 32 * TB * WB, MS = DL3_WGRAD_MS;
+  constexpr int LDX = BKT + 4, LDD = BNT + 4;
+  constexpr int XQ = MS * BKT / 4, DQ = MS * BNT / 4;  // float4s per stage
+  constexpr int NX = (XQ + 255) / 256, ND = (DQ + 255) / 256;
+  constexpr int STAGE = MS * LDX + MS * LDD;
+  __shared__ float lds[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wa = wave / WB, wb = wave % WB;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  // XCD-aware decode: the tiles of ONE row slab (same activations / gradients, different weight tiles) get consecutive
+  // virtual ids and therefore one XCD and its L2.  With the plain (x, y, z) order consecutive tiles land on different
+  // XCDs and every tile re-reads its slab from HBM (TCC hit rate 0-3 % measured; the 160x960 layer moved 2.5 GB instead
+  // of 1.1 GB per launch and ran at HBM speed, not MFMA speed).
+  const int nwg = gridDim.x * gridDim.y * gridDim.z;
+  const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+  const int vid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+  const int bx = vid % gridDim.x, by_ = (vid / gridDim.x) % gridDim.y, bz = vid / (gridDim.x * gridDim.y);
+  const int kbase = by_ * BKT, nbase = bx * BNT;
+  const int mbeg = bz * P.Mper;
+  const int mend = min(P.M, mbeg + P.Mper);
+  const bool xform = (P.xs != nullptr);
+  const bool two = (P.cA != nullptr);
+  // 32 x 32 blocks of this wave's sub-tile that lie inside the K x N matrix (wave-uniform)
+  const int ia = max(0, min(TA, (P.K - kbase - wa * TA * 32 + 31) >> 5));
+  const int jb = max(0, min(TB, (P.N - nbase - wb * TB * 32 + 31) >> 5));
+  const bool wfull = (ia == TA) && (jb == TB);
+
+  f32x16 acc[TA][TB];
+#pragma unroll
+  for (int i = 0; i < TA; i++)
+#pragma unroll
+    for (int j = 0; j < TB; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // per-column coefficient vectors of the tile (input transform of x; BatchNorm-backward affine of g, y) live in LDS — as
+  // hoisted registers they were 40-52 VGPRs of every instantiation (an occupancy step for the 128 x 96 / 128 x 128 tiles).
+  // Columns beyond K / N carry the LAST valid column group's values shifted in: a lane whose 16-byte piece lies beyond N
+  // works on a duplicate of the last valid group (load_tiles clamps it there) and must assemble the same bits for it.
+  __shared__ __attribute__((aligned(16))) float cfx[2][BKT];
+  __shared__ __attribute__((aligned(16))) float cfd[3][BNT];
+  for (int c = tid; c < BKT; c += 256) {
+    const int kc = min(kbase + c, P.K - 1);
+    cfx[0][c] = xform ? P.xs[kc] : 1.f;
+    cfx[1][c] = xform ? P.xt[kc] : 0.f;
+  }
+  for (int c = tid; c < BNT; c += 256) {
+    const int cc = min(nbase + c, P.N - 1);
+    cfd[0][c] = two ? P.cA[cc] : 1.f;
+    cfd[1][c] = two ? P.cB[cc] : 0.f;
+    cfd[2][c] = two ? P.cC[cc] : 0.f;
+  }
+  __syncthreads();
+
+  f32x4 rx[NX], rg[ND], ry[ND];
+
+  // requests of the stage that starts at row m0 (all unconditional: clamped rows / columns / piece indices)
+  auto load_tiles = [&](int m0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+      const int idx = min(tid + 256 * i, XQ - 1);
+      const int mr = idx / (BKT / 4), kq = idx % (BKT / 4);
+      const int row = min(m0 + mr, P.M - 1), k = kbase + kq * 4;
+      if (XVEC) {
+        rx[i] = ld4(P.x + (size_t)row * P.ldx + min(k, P.K - 4));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) rx[i][j] = P.x[(size_t)row * P.ldx + min(k + j, P.K - 1)];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ND; i++) {
+      const int idx = min(tid + 256 * i, DQ - 1);
+      const int mr = idx / (BNT / 4), nq = idx % (BNT / 4);
+      const int row = min(m0 + mr, P.M - 1), col = nbase + nq * 4;
+      if (DVEC) {
+        const int cc = min(col, P.N - 4);
+        rg[i] = ld4(P.g + (size_t)row * P.ldg + cc);
+        if (two) ry[i] = ld4(P.y + (size_t)row * P.ldy + cc);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int cc = min(col + j, P.N - 1);
+          rg[i][j] = P.g[(size_t)row * P.ldg + cc];
+          if (two) ry[i][j] = P.y[(size_t)row * P.ldy + cc];
+        }
+      }
+    }
+  };
+
+  // the loaded stage (rows m0 ..) -> MFMA operands in LDS [+ dY to HBM]; the requests of the stage at mnext are issued in
+  // between: behind the last use of the registers they land in, in front of this stage's stores
+  auto load_x = [&](int m0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+      const int idx = min(tid + 256 * i, XQ - 1);
+      const int mr = idx / (BKT / 4), kq = idx % (BKT / 4);
+      const int row = min(m0 + mr, P.M - 1), k = kbase + kq * 4;
+      if (XVEC) {
+        rx[i] = ld4(P.x + (size_t)row * P.ldx + min(k, P.K - 4));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) rx[i][j] = P.x[(size_t)row * P.ldx + min(k + j, P.K - 1)];
+      }
+    }
+  };
+  auto load_d = [&](int m0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < ND; i++) {
+      const int idx = min(tid + 256 * i, DQ - 1);
+      const int mr = idx / (BNT / 4), nq = idx % (BNT / 4);
+      const int row = min(m0 + mr, P.M - 1), col = nbase + nq * 4;
+      if (DVEC) {
+        const int cc = min(col, P.N - 4);
+        rg[i] = ld4(P.g + (size_t)row * P.ldg + cc);
+        if (two) ry[i] = ld4(P.y + (size_t)row * P.ldy + cc);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int cc = min(col + j, P.N - 1);
+          rg[i][j] = P.g[(size_t)row * P.ldg + cc];
+          if (two) ry[i][j] = P.y[(size_t)row * P.ldy + cc];
+        }
+      }
+    }
+  };
+  auto prepare = [&](int m0, int mnext, float *Xs, float *Ds, auto store_tag) __attribute__((always_inline)) {
+    constexpr bool STORE = decltype(store_tag)::value;
+    // x: transform -> LDS (not a vector-memory operation: it may sit anywhere), then its registers take the next stage's
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+      const int idx = tid + 256 * i;
+      const int mr = min(idx, XQ - 1) / (BKT / 4), kq = min(idx, XQ - 1) % (BKT / 4);
+      const bool rok = (m0 + mr) < mend;
+      const int kl = XVEC ? min(kbase + kq * 4, P.K - 4) - kbase : kq * 4;   // (the column group the load was clamped to)
+      f32x4 v = dl3_act4(ld4(&cfx[0][kl]) * rx[i] + ld4(&cfx[1][kl]), P.x_act);
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (!(rok && (kbase + kq * 4 + j) < P.K)) v[j] = 0.f;
+      if (NX * 256 == XQ || idx < XQ) st4(&Xs[mr * LDX + kq * 4], v);
+    }
+    f32x4 td[ND];
+#pragma unroll
+    for (int i = 0; i < ND; i++) {
+      const int nq_ = min(tid + 256 * i, DQ - 1) % (BNT / 4);
+      const int nl = DVEC ? min(nbase + nq_ * 4, P.N - 4) - nbase : nq_ * 4;
+      td[i] = ld4(&cfd[0][nl]) * rg[i] + ld4(&cfd[2][nl]);
+      if (two) td[i] += ld4(&cfd[1][nl]) * ry[i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    load_x(mnext);
+    load_d(mnext);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (STORE) {
+#pragma unroll
+      for (int i = 0; i < ND; i++) {
+        const int idx = min(tid + 256 * i, DQ - 1);
+        const int mr = idx / (BNT / 4), nq = idx % (BNT / 4);
+        if constexpr (DVEC) {
+          float *dp = P.dyout + (size_t)min(m0 + mr, P.M - 1) * P.lddy + min(nbase + nq * 4, P.N - 4);
+          st4_nt(dp, td[i]);
+        } else {
+          if (m0 + mr < mend) {
+            float *dp = P.dyout + (size_t)(m0 + mr) * P.lddy + nbase + nq * 4;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+              if ((nbase + nq * 4 + j) < P.N) dp[j] = td[i][j];
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < ND; i++) {
+      const int idx = tid + 256 * i;
+      if (ND * 256 == DQ || idx < DQ) {
+        const int mr = idx / (BNT / 4), nq = idx % (BNT / 4);
+        const bool rok = (m0 + mr) < mend;
+        f32x4 v = td[i];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (!(rok && (nbase + nq * 4 + j) < P.N)) v[j] = 0.f;
+        st4(&Ds[mr * LDD + nq * 4], v);
+      }
+    }
+  };
+
+  // the MFMAs of one staged 16-row slice
+  auto mfma_stage = [&](const float *Xs, const float *Ds) __attribute__((always_inline)) {
+    if constexpr (SPL) {
+      u32x4 ah[TA], am[TA], al[TA];
+#pragma unroll
+      for (int i = 0; i < TA; i++) {
+        f32x4 v0, v1;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          v0[e] = Xs[(8 * lhi + e) * LDX + (wa * TA + i) * 32 + l31];
+          v1[e] = Xs[(8 * lhi + 4 + e) * LDX + (wa * TA + i) * 32 + l31];
+        }
+        split3(v0, v1, ah[i], am[i], al[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < TB; j++) {
+        f32x4 v0, v1;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          v0[e] = Ds[(8 * lhi + e) * LDD + (wb * TB + j) * 32 + l31];
+          v1[e] = Ds[(8 * lhi + 4 + e) * LDD + (wb * TB + j) * 32 + l31];
+        }
+        u32x4 bh_, bm_, bl_;
+        split3(v0, v1, bh_, bm_, bl_);
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, bh_), bm = __builtin_bit_cast(bf16x8, bm_),
+                     bl = __builtin_bit_cast(bf16x8, bl_);
+#pragma unroll
+        for (int i = 0; i < TA; i++) {
+          const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[i]), xm = __builtin_bit_cast(bf16x8, am[i]),
+                       xl = __builtin_bit_cast(bf16x8, al[i]);
+          f32x16 c = acc[i][j];  // small terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bm, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bm, c, 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, c, 0, 0, 0);
+        }
+      }
+    } else if (ia > 0 && jb > 0) {
+      float af[2][TA], bf[2][TB];
+#pragma unroll
+      for (int i = 0; i < TA; i++) af[0][i] = Xs[lhi * LDX + (wa * TA + i) * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TB; j++) bf[0][j] = Ds[lhi * LDD + (wb * TB + j) * 32 + l31];
+#pragma unroll
+      for (int ks = 0; ks < MS / 2; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks + 1 < MS / 2) {
+#pragma unroll
+          for (int i = 0; i < TA; i++) af[nxt][i] = Xs[(2 * ks + 2 + lhi) * LDX + (wa * TA + i) * 32 + l31];
+#pragma unroll
+          for (int j = 0; j < TB; j++) bf[nxt][j] = Ds[(2 * ks + 2 + lhi) * LDD + (wb * TB + j) * 32 + l31];
+        }
+#pragma unroll
+        for (int i = 0; i < TA; i++)
+#pragma unroll
+          for (int j = 0; j < TB; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+    if (mbeg < mend) {
+    const int ns = (mend - mbeg + MS - 1) / MS;          // stages of this workgroup
+    const int mlast = mbeg + (ns - 1) * MS;              // (the last stage asks for itself again instead of for nothing)
+    auto stage_x = [&](int t) { return lds + (t & 1) * STAGE; };
+    load_x(mbeg);
+    load_d(mbeg);
+    prepare(mbeg, min(mbeg + MS, mlast), stage_x(0), stage_x(0) + MS * LDX, std::integral_constant<bool, DYS>{});
+    __syncthreads();
+    // (requests in flight at the loop's entry would make its header the pessimistic merge of entry and back edge — every
+    // wait inside vmcnt(0): wait once here)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (int t = 1; t < ns; ++t) {
+      mfma_stage(stage_x(t - 1), stage_x(t - 1) + MS * LDX);
+      prepare(mbeg + t * MS, min(mbeg + (t + 1) * MS, mlast), stage_x(t), stage_x(t) + MS * LDX, std::integral_constant<bool, DYS>{});
+      __syncthreads();
+    }
+    mfma_stage(stage_x(ns - 1), stage_x(ns - 1) + MS * LDX);
+  }
   float *out = P.ws + (size_t)bz * P.K * P.N;
 #pragma unroll
   for (int i = 0; i < TA; i++)
@@ -2603,6 +2915,20 @@ static int pwconv_bwd_weight_impl(const float *x, int ldx, const float *in_scale
   dim3 grid(dl3_cdiv(N, c.BNT), dl3_cdiv(K, c.BKT), S);
   const bool xvec = (K % 4 == 0) && (ldx % 4 == 0) && al16(x);
   const bool dvec = (N % 4 == 0) && (ldg % 4 == 0) && al16(g) && (!two || ((ldyraw % 4 == 0) && al16(yraw)));
+  // one tile row covers the whole K (expand convolutions): the straight-line kernel with the requests in front of the stores
+  static const int row_env = env_int("DL3_WGRAD_ROW");   // (0: off — tuning aid / A-B)
+  if (row_env != 0 && grid.y == 1 && xvec && dvec && !split_math() && (c.id == 2 || c.id == 8) && M >= 32768) {
+    if (c.id == 2) {
+      if (dy_out) hipLaunchKernelGGL((pw_wgrad_row_kernel<5, 1, 1, 4, true>), grid, dim3(256), 0, st, A);
+      else hipLaunchKernelGGL((pw_wgrad_row_kernel<5, 1, 1, 4, false>), grid, dim3(256), 0, st, A);
+    } else {
+      if (dy_out) hipLaunchKernelGGL((pw_wgrad_row_kernel<3, 1, 1, 4, true>), grid, dim3(256), 0, st, A);
+      else hipLaunchKernelGGL((pw_wgrad_row_kernel<3, 1, 1, 4, false>), grid, dim3(256), 0, st, A);
+    }
+    DL3_LAUNCH_CHECK("pwconv_bwd_weight");
+    if (!dw) return DL3_OK;
+    return dl3_reduce_partials(A.ws, S, K * N, dw, stream);
+  }
   switch (c.id) {
     case 0: launch_wgrad<1, 1, 2, 2>(A, grid, st, (xvec && dvec) ? 1 : (xvec ? 2 : 0)); break;
     case 1: launch_wgrad<2, 2, 2, 2>(A, grid, st, (xvec && dvec) ? 1 : (xvec ? 2 : 0)); break;
