@@ -103,8 +103,18 @@ int dl3_pwconv_partials(int M, int K, int N);
 /* which kernel a dl3_pwconv_fwd launch of this shape takes (16-byte aligned operands, leading dimensions multiples of 4,
  * no addend): 0 the tiled MFMA GEMM, 1 the weight-stationary streaming kernel of the HBM-bound layers (round 5: the
  * whole K x N matrix in LDS, every wave walks 32-row tiles on its own, 16-byte stores; deeplabv3p.py:175-198 at
- * 16..192 channels, M >= 32768; DL3_FWD_WS=0 disables it).  Diagnostic only: results do not depend on it. */
+ * 16..192 channels, M >= 32768), 2 the weight-stationary kernel of the MFMA-bound short reductions (round 6: K = 160 / 96 /
+ * 64 into an output at least twice as wide, M >= 131072; DL3_WS2=0 disables it).  Diagnostic only. */
 int dl3_pwconv_fwd_impl(int M, int K, int N);
+/* ... and the route of a launch by name, for plans that want to assert what they benchmark (tests/test_host.py):
+ * dir 0 = forward (as dl3_pwconv_fwd_impl), 1 = bwd-data with the single-tensor dY, a mask operand and no addend, 2 = the
+ * weight gradient (two-tensor operand).  Returns DL3_ROUTE_*.  Diagnostic only. */
+#define DL3_ROUTE_TILED 0      /* pw_gemm_stream_kernel / pw_gemm_kernel / pw_wgrad_kernel */
+#define DL3_ROUTE_WS_HBM 1     /* pw_fwd_ws_kernel */
+#define DL3_ROUTE_WS_MFMA 2    /* pw_ws2_kernel */
+#define DL3_ROUTE_KSPLIT 3     /* pw_ksplit32_kernel (1 024 - 16 384 rows) */
+#define DL3_ROUTE_WGRAD_ROW 4  /* pw_wgrad_row_kernel (one tile row over K) */
+int dl3_pwconv_route(int dir, int M, int K, int N);
 /* y[M,N](ldy) = T(x)[M,K](ldx) . w[K,N] (+bias[N]); stat_partial (nullable) [P][N][2] = sum(y), sum(y^2) */
 int dl3_pwconv_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,
                    const float *w, const float *bias, float *y, int ldy, int M, int K, int N,

@@ -892,12 +892,10 @@ int march_fast() {
   // same box; ms off -> on): backward 64x64x960 r4 1.674 -> 1.577, x576 r2 1.021 -> 0.932, x384 r2 0.802 -> 0.732, x192
   // 0.329 -> 0.293, 256x256x32 0.926 -> 0.868, but 128x128x144 (576-byte pixels: every other 128-byte store straddles two
   // lines) 1.356 -> 1.435; forward 256x256x32 0.467 -> 0.422, 128x128x144 0.569 -> 0.603, the 64x64 maps within noise.
-  static const int v = [] { const char *e = getenv("DL3_DW_FAST"); return e ? atoi(e) : 7; }();
-  return v;
+  return 7;   // (the DL3_DW_FAST bit mask of round 5's A/B is gone: all three kernels take the fast path)
 }
 int march_xcd() {
-  const char *e = getenv("DL3_DW_XCD");  // 0 = plain workgroup order (tuning aid)
-  return e ? atoi(e) : 1;
+  return 1;   // (XCD-aware workgroup order; the plain order was the round-1 A/B)
 }
 
 bool march_ok(int H, int W, int stride, int rate, int pad_t, int pad_l, int Ho, int Wo) {
@@ -909,8 +907,7 @@ DwPlan dw_plan(int N, int H, int W, int C, int stride, int rate, int Ho, int Wo,
   p.nslab = dl3_cdiv(C, 32);
   p.impl = impl;
   if (impl == DL3_IMPL_MARCH) {
-    const char *e2 = getenv("DL3_DW_TWO");  // 0 = one pixel per lane everywhere (tuning / test aid)
-    p.two = (!bwd && 32 % rate == 0 && W >= 32 && !(e2 && atoi(e2) == 0)) ? 1 : 0;
+    p.two = (!bwd && 32 % rate == 0 && W >= 32) ? 1 : 0;
     p.nxseg = dl3_cdiv(W, p.two ? 64 : 32);
     p.nphase = rate < H ? rate : H;
     const int Kmax = dl3_cdiv(H, rate);
@@ -918,8 +915,7 @@ DwPlan dw_plan(int N, int H, int W, int C, int stride, int rate, int Ho, int Wo,
     // B=16, 64x64x736 rate 2: 2048 -> row chunks of 8 with 25 % halo, in-situ 0.573 of 8 TB/s; 1024 -> chunks of 16:
     // 0.591; 512: 0.591; 3072 / 4096: 0.543; larger batches never chunk)
     int TK = Kmax;
-    long want = 1024;  // workgroups per launch to aim for (DL3_DW_BLOCKS: tuning aid)
-    if (const char *eb = getenv("DL3_DW_BLOCKS")) want = atol(eb) > 0 ? atol(eb) : want;
+    const long want = 1024;  // workgroups per launch to aim for
     while (TK > 8 && (long)N * p.nslab * p.nxseg * p.nphase * dl3_cdiv(Kmax, TK) < want) TK = (TK + 1) / 2;
     p.TK = TK;
     p.nchunk = dl3_cdiv(Kmax, TK);
@@ -1041,8 +1037,7 @@ static int dwconv3x3_bwd_impl(const float *g, const float *yraw, const float *cA
   } else {
     DwGeom G{N, H, W, C, stride, rate, pad_t, pad_l, Ho, Wo, Pmax};
     dim3 grid(p.nslab, p.PB);
-    const char *e = getenv("DL3_DW_S2");  // 0 = generic gather for stride 2 as well (tuning / test aid)
-    if (stride == 2 && rate == 1 && pad_t <= 1 && pad_l <= 1 && !(e && atoi(e) == 0))
+    if (stride == 2 && rate == 1 && pad_t <= 1 && pad_l <= 1)
       hipLaunchKernelGGL(dw_s2_bwd, grid, dim3(256), 0, st, g, yraw, cA, cB, cC, x, in_scale, in_shift, in_act, w, dx,
                          dx_add, x_mean, x_invstd, dstat_partial, dw_partial, G);
     else

@@ -633,15 +633,12 @@ int fused_env(const char *name) {
 int fused_version() { return fused_env("DL3_FUSED_V") == 1 ? 1 : 2; }  // 1: the round-4 kernel (A/B aid); else round 5
 
 int fused_rows_per_wg(int M) {
-  static const int env_wgs = fused_env("DL3_FUSED_WGS");  // tuning aid: target number of workgroups
-  static const int env_minrows = fused_env("DL3_FUSED_MINROWS");
-  long want = env_wgs > 0 ? env_wgs : 2048;  // (B = 128, 16 -> 96 at 256x256: 1024 -> 3.06 ms, 2048 -> 2.45 ms)
+  long want = 2048;  // workgroups (B = 128, 16 -> 96 at 256x256: 1024 -> 3.06 ms, 2048 -> 2.45 ms)
   long stages = dl3_cdiv(M, FMS);
-  // every workgroup leaves a K x N slab behind: with few rows (B <= 16) keep at least DL3_FUSED_MINROWS rows per workgroup,
-  // down to two workgroups per CU
-  if (!(env_wgs > 0)) {
-    const long minrows = env_minrows > 0 ? env_minrows : 512;
-    long cap = (long)M / minrows;
+  // every workgroup leaves a K x N slab behind: with few rows (B <= 16) keep at least 512 rows per workgroup, down to two
+  // workgroups per CU (round 4, calls 19 / 20)
+  {
+    long cap = (long)M / 512;
     if (cap < 512) cap = 512;
     if (want > cap) want = cap;
   }

@@ -2242,17 +2242,12 @@ __global__ __launch_bounds__(256) void pw_ksplit32_kernel(GemmArgs P) {
   }
 }
 
-// shapes and row counts the K-split kernel takes (DL3_KSPLIT=0: never, 1: without N <= 64; DL3_KSPLIT_ROWS: row limit, default 16 384)
+// shapes and row counts the K-split kernel takes: 1 024 - 16 384 rows
 inline int ksplit_tn(int M, int K, int N) {
-  // read ONCE (like ws_wanted / fused_rows_per_wg): the answer sizes the statistic partial buffers when a plan is lowered
-  // (dl3_pwconv_partials) and picks the kernel at every launch — the two must never disagree
-  static const int env = env_int("DL3_KSPLIT");
-  static const int env_rows = env_int("DL3_KSPLIT_ROWS");
-  if (env == 0) return 0;
-  const int lim = env_rows > 0 ? env_rows : 16384;
-  if (M > lim || M < 1024 || K < 192 || K > DL3_STREAM_KMAX || K % 4 != 0 || N % 4 != 0) return 0;
+  // (a pure function of the shape: the answer sizes the statistic partial buffers when a plan is lowered — dl3_pwconv_partials —
+  // and picks the kernel at every launch; the DL3_KSPLIT / DL3_KSPLIT_ROWS knobs of round 5's A/B are gone)
+  if (M > 16384 || M < 1024 || K < 192 || K > DL3_STREAM_KMAX || K % 4 != 0 || N % 4 != 0) return 0;
   const int tn = dl3_cdiv(N, 32);
-  if (tn == 2 && env == 1) return 0;   // (DL3_KSPLIT=1: without the 64-wide outputs — tuning aid)
   // 64-, 96- and 160-wide outputs: the ones the 64-column-per-wave kernels pad (to 128, 128 and 256 columns)
   return (tn == 2 || tn == 3 || tn == 5) ? tn : 0;
 }
@@ -2353,13 +2348,11 @@ int ws2_wanted(const GemmArgs &A, bool fwd, bool vec) {
   return 2;
 }
 
-// forward launch served by the weight-stationary kernel?  (DL3_FWD_WS=0 disables; the tiled kernel serves everything)
+// forward launch served by the weight-stationary kernel of the HBM-bound layers?
 bool ws_wanted(const GemmArgs &A, bool fwd, bool vec) {
-  static const int env = env_int("DL3_FWD_WS");
-  static const int minrows = env_int("DL3_FWD_WS_ROWS");
-  if (env == 0 || !fwd || !vec || A.ep_add || A.a2) return false;
+  if (!fwd || !vec || A.ep_add || A.a2) return false;
   if (A.ldc % 4 != 0 || (((uintptr_t)A.c) & 15) != 0) return false;  // 16-byte stores
-  if (A.M < (minrows > 0 ? minrows : 32768)) return false;
+  if (A.M < 32768) return false;
   return ws_tn(A.K, A.N) != 0;
 }
 
@@ -2376,8 +2369,6 @@ int env_int(const char *name) {
 
 // small: the 32-row configurations may be chosen (they exist for the stream kernel only)
 GemmCfg pick_gemm(int M, int K, int N, bool two, bool small, bool fwd = true) {
-  const int fb = env_int("DL3_GEMM_BWD_CFG");  // tuning aid: tile configuration of the two-tensor (bwd-data) launches only
-  if (two && fb >= 0 && fb < kNumGemmCfgs && (small || kGemmCfgs[fb].BM != 32)) return kGemmCfgs[fb];
   const int forced = env_int("DL3_GEMM_CFG");  // tuning aid (tools/gemm_tune.py)
   if (forced >= 0 && forced < kNumGemmCfgs && (small || kGemmCfgs[forced].BM != 32)) return kGemmCfgs[forced];
   // measured exception (tools/gemm_tune.py): a forward GEMM with a very short reduction and a wide output
@@ -2411,8 +2402,7 @@ bool pre_ok(const GemmArgs &A) {
 // ... and for which the 128x96 prefetching tile beats the cost model's choice: short reductions (the epilogue is as
 // long as the main loop) into a wide output made of whole 96-column tiles, with enough row tiles to fill the chip
 bool pre_wanted(const GemmArgs &A) {
-  const int kmax = env_int("DL3_GEMM_PRE_KMAX");
-  return A.K <= (kmax > 0 ? kmax : 320) && A.N % 96 == 0 && A.N >= 2 * A.K && A.M >= 65536;
+  return A.K <= 320 && A.N % 96 == 0 && A.N >= 2 * A.K && A.M >= 65536;
 }
 
 int gemm_grid_y(int M, int N, const GemmCfg &c, int K = 0) {
@@ -2437,9 +2427,8 @@ int gemm_grid_y(int M, int N, const GemmCfg &c, int K = 0) {
   const int even = dl3_cdiv(mtiles, iters);
   // ... unless that leaves more than a tenth of the chip's 512 slots empty (512 row tiles x 5 column tiles: 86 x 5 = 430
   // workgroups of 6 tiles, most CUs carry 12 tile-times; 102 x 5 = 510 workgroups of 5 or 6 carry 10-11: the Xception
-  // 736 -> 736 GEMM at 65536 rows 0.810 -> 0.733 ms forward, 0.924 -> 0.869 bwd-data).  DL3_GEMM_RAGGED=0/1 forces.
-  const int ragged = env_int("DL3_GEMM_RAGGED");
-  if (ragged == 1 || (ragged != 0 && (long)even * ntn * 10 < 512L * 9)) return py;
+  // 736 -> 736 GEMM at 65536 rows 0.810 -> 0.733 ms forward, 0.924 -> 0.869 bwd-data).
+  if ((long)even * ntn * 10 < 512L * 9) return py;
   return even;
 }
 
@@ -2501,7 +2490,7 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   const bool bvec = (A.N % 4 == 0) && (A.ldb % 4 == 0) && al16(A.b);
   const bool vec = avec && bvec;
   const int vmode = vec ? 1 : (avec ? 2 : 0);
-  const bool stream = vec && env_int("DL3_GEMM_IMPL") != 0 && A.K <= DL3_STREAM_KMAX;
+  const bool stream = vec && A.K <= DL3_STREAM_KMAX;
   // (a per-image addend stays on the forward instantiation when its straight-line epilogue can take it: 32-row blocks
   // inside one image)
   const bool fwd = !two && !A.ep_x && A.stat_mode != 2 && !(A.ep_add && A.add_div > 1 && A.add_div % 32 != 0);
@@ -2563,7 +2552,7 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   dim3 grid(dl3_cdiv(A.N, c.BN), gemm_grid_y(A.M, A.N, c, A.K));
   // stream-A kernel: 10-25 % faster than the LDS-staged kernel on every layer shape, forward and bwd-data
   // (tools/gemm_tune.py).  The two-tensor bwd-data operand uses 16-deep K-tiles so that its register budget does not
-  // spill.  DL3_GEMM_IMPL=0 forces the staged kernel (which also serves unaligned operands).
+  // spill.  (Unaligned operands take the LDS-staged kernel below.)
   if (stream) {
     dim3 blk(256);
     if (split_math() && c.id != 5 && c.id != 6) {  // (the 32-row small-M tiles keep the f32 MFMA: their split weight tiles exceed the LDS)
@@ -2637,8 +2626,7 @@ const WgCfg kWgCfgs[] = {{0, 64, 64},  {1, 128, 128}, {2, 160, 128}, {3, 128, 16
 // M splits the tile cost model reasons with: ~1024 workgroups, capped by slab traffic and by rows per split
 int wgrad_splits_model(int M, int K, int N, const WgCfg &c, int target = DL3_WGRAD_WGS_DEFAULT) {
   const long tiles = (long)dl3_cdiv(K, c.BKT) * dl3_cdiv(N, c.BNT);
-  const int wgs = env_int("DL3_WGRAD_WGS");  // tuning aid: target number of workgroups per weight-gradient launch
-  long S = (wgs > 0 ? wgs : target) / tiles;
+  long S = target / tiles;
   const long cap_traffic = (long)((double)M * (K + N) / (4.0 * K * N));
   const long cap_rows = M / 64;
   if (S > cap_traffic) S = cap_traffic;
@@ -2655,7 +2643,6 @@ int wgrad_splits_model(int M, int K, int N, const WgCfg &c, int target = DL3_WGR
 // M = 16384 (B=4) the 160-wide shapes lose 12 % (profiles/r04_ab_calls.txt, call 17).
 int wgrad_splits(int M, int K, int N, const WgCfg &c) {
   const int S = wgrad_splits_model(M, K, N, c);
-  if (env_int("DL3_WGRAD_WGS") > 0 || env_int("DL3_WGRAD_HALVE") == 0) return S;
   const bool wide = (c.id == 2 || c.id == 3) && (long)K * N <= 160L * 960 && M >= 32768;
   if (wide && 2.0 * (double)S * K * N > 0.1 * (double)M * (K + N)) return wgrad_splits_model(M, K, N, c, DL3_WGRAD_WGS_DEFAULT / 2);
   return S;
@@ -2697,7 +2684,7 @@ int colsum_rows(int M) {
 
 template <int TA, int TB, int WA, int WB>
 void launch_wgrad(const WgradArgs &A, dim3 grid, hipStream_t st, int vec) {
-  if (vec == 1 && split_math() && env_int("DL3_WGRAD_SPLIT") != 0)
+  if (vec == 1 && split_math())
     hipLaunchKernelGGL((pw_wgrad_kernel<TA, TB, WA, WB, 1, true>), grid, dim3(256), 0, st, A);
   else if (vec == 1) hipLaunchKernelGGL((pw_wgrad_kernel<TA, TB, WA, WB, 1>), grid, dim3(256), 0, st, A);
   else if (vec == 2) hipLaunchKernelGGL((pw_wgrad_kernel<TA, TB, WA, WB, 2>), grid, dim3(256), 0, st, A);
@@ -2756,7 +2743,31 @@ extern "C" int dl3_pwconv_fwd_impl(int M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0) return 0;
   GemmArgs A{};
   A.M = M; A.K = K; A.N = N; A.ldc = N;
-  return (ws_wanted(A, true, true) && !split_math()) ? 1 : 0;
+  if (split_math()) return 0;
+  if (ws2_wanted(A, true, true)) return 2;
+  return ws_wanted(A, true, true) ? 1 : 0;
+}
+
+extern "C" int dl3_pwconv_route(int dir, int M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0 || split_math()) return DL3_ROUTE_TILED;
+  if (dir == 2) {
+    const WgCfg c = pick_wgrad(M, K, N, true);
+    static const int row_env = env_int("DL3_WGRAD_ROW");
+    const bool row = row_env != 0 && dl3_cdiv(K, c.BKT) == 1 && K % 4 == 0 && N % 4 == 0 && (c.id == 2 || c.id == 8) && M >= 32768;
+    return row ? DL3_ROUTE_WGRAD_ROW : DL3_ROUTE_TILED;
+  }
+  GemmArgs A{};
+  if (dir == 0) {
+    A.M = M; A.K = K; A.N = N; A.ldc = N;
+    if (ws2_wanted(A, true, true)) return DL3_ROUTE_WS_MFMA;
+    if (ws_wanted(A, true, true)) return DL3_ROUTE_WS_HBM;
+  } else {
+    // bwd-data of a layer K -> N: the GEMM reduces over N and is K wide
+    A.M = M; A.K = N; A.N = K; A.ldc = K; A.ld_epx = K;
+    A.ep_x = reinterpret_cast<const float *>(uintptr_t(16));   // (an aligned mask operand is present: only its presence matters)
+    if (ws2_wanted(A, false, true) == 2) return DL3_ROUTE_WS_MFMA;
+  }
+  return ksplit_tn(A.M, A.K, A.N) ? DL3_ROUTE_KSPLIT : DL3_ROUTE_TILED;
 }
 
 static int gemm_common_check(const char *name, int M, int K, int N) {
@@ -2916,8 +2927,7 @@ static int pwconv_bwd_weight_impl(const float *x, int ldx, const float *in_scale
   const bool xvec = (K % 4 == 0) && (ldx % 4 == 0) && al16(x);
   const bool dvec = (N % 4 == 0) && (ldg % 4 == 0) && al16(g) && (!two || ((ldyraw % 4 == 0) && al16(yraw)));
   // one tile row covers the whole K (expand convolutions): the straight-line kernel with the requests in front of the stores
-  static const int row_env = env_int("DL3_WGRAD_ROW");   // (0: off — tuning aid / A-B)
-  if (row_env != 0 && grid.y == 1 && xvec && dvec && !split_math() && (c.id == 2 || c.id == 8) && M >= 32768) {
+  if (xvec && dvec && dl3_pwconv_route(2, M, K, N) == DL3_ROUTE_WGRAD_ROW) {   // (DL3_WGRAD_ROW=0: off — A/B aid)
     if (c.id == 2) {
       if (dy_out) hipLaunchKernelGGL((pw_wgrad_row_kernel<5, 1, 1, 4, true>), grid, dim3(256), 0, st, A);
       else hipLaunchKernelGGL((pw_wgrad_row_kernel<5, 1, 1, 4, false>), grid, dim3(256), 0, st, A);

@@ -73,9 +73,7 @@ def stored_channels(c):
     backward: C=728 4.03 / 3.26 TB/s, C=736 6.44 / 4.44 TB/s (tools/dw_rates.py align).  Xception's 728-channel tensors
     (entry_flow_block3 .. exit_flow_block1, 50+ depthwise layers) are therefore stored 736 wide: the 8 extra channels
     carry zero weights, zero gamma / beta, and stay exactly zero forward and backward.  Only when the padding costs
-    <= 2 % traffic (144 -> 160 would cost 11 % and gains nothing net).  DL3_CHANNEL_PAD=0 disables it."""
-    if os.environ.get("DL3_CHANNEL_PAD", "1") == "0":
-        return c
+    <= 2 % traffic (144 -> 160 would cost 11 % and gains nothing net)."""
     p = (c + 31) // 32 * 32
     return p if (p - c) <= 0.02 * c else c
 
@@ -210,7 +208,7 @@ class Engine:
         self.external_nnz = bool(external_nnz)
         self.device = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
         self.use_graph = use_graph
-        self.fold_tail = os.environ.get("DL3_FOLD_TAIL", "1") != "0"  # 0: keep the full-resolution dlogits (test aid)
+        self.fold_tail = True   # the loss kernel folds its gradient rows onto the low-resolution columns (the full-resolution dlogits never exist)
         self.dw_impl = dw_impl
         self.ops_prep, self.ops_fwd, self.ops_bwd = [], [], []
         # backward fork (round 3, opt-in: DL3_FORK=1): the 1x1-conv weight gradients are off the critical path until Adam —
@@ -224,17 +222,17 @@ class Engine:
         # ... of the folds whose partial rows are small: a deferred fold re-reads its slabs from HBM instead of the cache
         # they were just written through, which costs more than the launch it saves from ~12 MB on (Xception B=16 with
         # every fold deferred: 193.9 -> 196.4 ms)
-        self.fold_defer_bytes = int(float(os.environ.get("DL3_FOLD_DEFER_MB", "8")) * (1 << 20))
+        self.fold_defer_bytes = 8 << 20
         self.own_fold_ws_bytes = 0   # device memory of the deferred folds' own slab workspaces (reported by bench.py)
         self._folds = []
         # round 4: the weight-gradient launch of a BatchNorm'ed 1x1 convolution also writes dY = cA*g + cB*y + cC (it
         # assembles it anyway), and the bwd-data GEMM of the layer reads that ONE tensor (dl3_pwconv_bwd_weight_dy).  The
         # write is paid by the weight-gradient launch: cheap next to a wide X (project convolutions, +0.02-0.06 ms against
         # -0.3-0.7 ms of bwd-data at B=128) but not for an HBM-bound launch with a narrow X and a wide dY (16 -> 96 at
-        # 256x256: +0.88 ms against -0.65): only where N <= K or K >= DL3_DY_MAT_K (DL3_DY_MAT=0 disables)
+        # 256x256: +0.88 ms against -0.65): only where N <= K or K >= 96 (DL3_DY_MAT=0 disables)
         # (second look, same call: the criterion is the width of X against dY, not the width of dY: N <= K or K >= 96)
         self.dy_mat = os.environ.get("DL3_DY_MAT", "1") != "0"
-        self.dy_mat_mink = int(os.environ.get("DL3_DY_MAT_K", "96"))
+        self.dy_mat_mink = 96
         # both gradients of an HBM-bound 1x1 convolution with a small weight matrix in one pass (dl3_pwconv_bwd_fused):
         # layers with at least DL3_FUSED_ROWS pixel rows (DL3_FUSED_BWD=0 disables)
         self.fused_bwd = os.environ.get("DL3_FUSED_BWD", "1") != "0"
@@ -527,8 +525,6 @@ class Engine:
         """the first input of Concatenate l if it is the bilinear 'resize' of a 1x1 map — a per-image constant, e.g. the
         ASPP image-pooling branch (deeplabv3p.py:375-382) — and the Concatenate feeds exactly one 1x1 convolution: that
         branch is then never materialised; the convolution adds its contribution once per image (PwUnit img_add)"""
-        if os.environ.get("DL3_FUSE_BCAST", "1") == "0":
-            return None
         t = l.inbound[0]
         p = self._producer_of(t)
         cs = self.consumers.get(id(l.output), [])
@@ -653,7 +649,7 @@ class Engine:
                     v.buf.vptr(V_SCALE, v.off), v.buf.vptr(V_SHIFT, v.off), v.buf.vptr(V_MEAN, v.off),
                     v.buf.vptr(V_INVSTD, v.off), self.wptr(n + "/moving_mean:0") if upd else None,
                     self.wptr(n + "/moving_variance:0") if upd else None)
-        elif isinstance(unit, PwUnit) and unit.bias is None and os.environ.get("DL3_BN_CENTER", "1") != "0":
+        elif isinstance(unit, PwUnit) and unit.bias is None:
             # moving statistics, 1x1 convolution in front (round 4): the GEMM's free bias slot takes -mean, the tensor holds
             # y - mean and consumers read scale*(y - mean) + beta — the reference's own gamma*(x - mean)/sqrt(var + eps) +
             # beta instead of scale*y + (beta - mean*scale), whose shift carries half an ulp of |mean*scale| into every
@@ -1124,7 +1120,7 @@ class Engine:
         over the gradient can be reduced right there instead of by a separate dl3_grad_finish pass over g and y
         (round 3).  Returns that input's Buf or None."""
         add = self.add_of_buf.get(id(ibuf))
-        if add is None or os.environ.get("DL3_FUSE_ADDSTAT", "1") == "0":
+        if add is None:
             return None
         hits = [v for v in (add.a, add.b)
                 if v.buf.requires_grad and v.buf.bns and v.buf.expected == 1 and v.buf.done == 0 and v.buf.grad is None
@@ -1427,8 +1423,7 @@ class PwUnit(_ConvBase):
             self.stat = eng.empty(self.P * self.N * 2)
         s, t, a = inv.xform()
         w = eng.wptr(self.wname()) + 4 * self.wrow0 * self.N
-        if (img_add is None and not want_stat and inv.buf.H == 1 and inv.buf.W == 1
-                and os.environ.get("DL3_ROWS_F64", "1") != "0"):
+        if img_add is None and not want_stat and inv.buf.H == 1 and inv.buf.W == 1:
             # one row per image (the ASPP image-pooling branch and its share of concat_projection): accumulated in double
             # (dl3_pwconv_fwd_rows) — the result is added to every pixel of the map, its rounding error is coherent
             self.fwd_rec = eng.op(eng.ops_fwd, "dl3_pwconv_fwd_rows", inv.p(), inv.ld, s, t, a, w,
@@ -1646,7 +1641,7 @@ class DwUnit(_ConvBase):
             dpart = eng.empty(self.P * C * 2) if need_stat else None
             B_, H, W, _, stride, rate, pt, pl, Ho, Wo = self.geom
             if (last and not ibuf.bns and stride == 1 and Ho == H and Wo == W and pt == rate and pl == rate
-                    and eng.dw_impl in (IMPL_AUTO, capi.IMPL_MARCH) and os.environ.get("DL3_DW_ALIAS", "1") != "0"):
+                    and eng.dw_impl in (IMPL_AUTO, capi.IMPL_MARCH)):
                 # this launch completes the gradient of a residual Add's output (Xception's `sum` shortcuts): the sums of the
                 # BatchNorm it reaches unchanged through the Add ride along (round 4; PwUnit.bwd does the same for
                 # MobileNetV2's blocks) instead of a dl3_grad_finish pass over g and y

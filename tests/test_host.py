@@ -53,7 +53,9 @@ def test_sizing_queries_of_the_weight_gradient_folds():
     assert L.dl3_pwconv_bwd_fused_supported(1000, 64, 128) == 0 and L.dl3_pwconv_bwd_fused_splits(1000, 64, 128) == 0
     # the weight-stationary forward kernel writes one statistic partial row per workgroup: the partial-row query covers it
     assert L.dl3_pwconv_fwd_impl(2097152, 24, 144) == 1 and L.dl3_pwconv_partials(2097152, 24, 144) >= 768
-    assert L.dl3_pwconv_fwd_impl(8192, 24, 144) == 0 and L.dl3_pwconv_fwd_impl(2097152, 64, 384) == 0
+    assert L.dl3_pwconv_fwd_impl(8192, 24, 144) == 0 and L.dl3_pwconv_fwd_impl(65536, 64, 384) == 0
+    # (round 6: from 131 072 rows a reduction of 64 into a 384-wide output takes the MFMA-bound weight-stationary kernel)
+    assert L.dl3_pwconv_fwd_impl(2097152, 64, 384) == 2 and L.dl3_pwconv_partials(2097152, 64, 384) >= 85
     for P, n, cols in [(1, 5, 64), (32, 6400, 64), (33, 100, 32), (256, 9 * 960, 32), (257, 9, 8), (1365, 153600, 8)]:
         assert L.dl3_reduce_partials_blocks(P, n) == -(-n // cols)
     assert L.dl3_reduce_partials_blocks(0, 10) == 0 and L.dl3_reduce_partials_blocks(4, 0) == 0
@@ -529,6 +531,50 @@ def _dry_engine(monkeypatch, backbone, B, size=512, OS=16, **kw):
     m = Deeplabv3(weights=None, input_shape=(size, size, 3), classes=21, backbone=backbone, OS=OS)
     e = Engine(m, batch=B, training=True, device="cpu", **kw)
     return e, collections.Counter(op[0] for op in e.ops_fwd + e.ops_bwd)
+
+
+def test_knob_table_is_current():
+    """KNOBS.md (tools/knobs.py) lists exactly the DL3_* environment variables the sources read — 23 since round 6 removed
+    the settled tuning aids — each with default, kind and meaning"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "knobs.py"), "--check"], capture_output=True, text=True)
+    assert res.returncode == 0, "KNOBS.md is stale or a knob lacks a description: run python tools/knobs.py\n" + res.stdout
+    text = open(os.path.join(root, "KNOBS.md")).read()
+    assert text.count("| `DL3_") == 23
+
+
+def test_default_kernel_routes_by_name(monkeypatch):
+    """the routes of the benchmarked plans BY NAME (dl3_pwconv_route): what bench.py times is what this asserts.
+    cfg2 at B=128: the HBM-bound early layers on the weight-stationary streaming kernel, the 64 x 64 blocks' expand
+    convolutions (reduction 64 / 96 / 160) forward and their project convolutions' bwd-data on the MFMA-bound weight-stationary
+    kernel, the expand convolutions' weight gradients on the one-tile-row kernel, everything else tiled; B=16: no
+    weight-stationary MFMA kernel (below 131 072 rows); B=2: the K-split kernel on the 960 <-> 160 / 576 <-> 96 layers."""
+    from dl3_amd import capi
+    L = capi.lib()
+    R = dict(tiled=0, ws_hbm=1, ws_mfma=2, ksplit=3, wgrad_row=4)
+    M = 128 * 64 * 64
+    for K, N in ((160, 960), (96, 576), (64, 384)):
+        assert L.dl3_pwconv_route(0, M, K, N) == R["ws_mfma"] and L.dl3_pwconv_fwd_impl(M, K, N) == 2
+        assert L.dl3_pwconv_route(1, M, N, K) == R["ws_mfma"]         # bwd-data of the project convolution N -> K
+        assert L.dl3_pwconv_route(0, 16 * 64 * 64, K, N) == R["tiled"]  # B=16: 65 536 rows
+    for K, N in ((960, 160), (576, 96), (384, 64), (960, 320), (320, 256), (256, 256)):
+        assert L.dl3_pwconv_route(0, M, K, N) == R["tiled"] and L.dl3_pwconv_route(1, M, N, K) == R["tiled"]
+    assert L.dl3_pwconv_route(0, 128 * 256 * 256, 16, 96) == R["ws_hbm"] and L.dl3_pwconv_route(0, 128 * 128 * 128, 24, 144) == R["ws_hbm"]
+    assert L.dl3_pwconv_route(2, M, 160, 960) == R["wgrad_row"] and L.dl3_pwconv_route(2, M, 96, 576) == R["wgrad_row"]
+    assert L.dl3_pwconv_route(2, M, 960, 160) == R["tiled"] and L.dl3_pwconv_route(2, M, 64, 384) == R["tiled"]
+    assert L.dl3_pwconv_route(0, 2 * 64 * 64, 960, 160) == R["ksplit"] and L.dl3_pwconv_route(0, 2 * 64 * 64, 576, 96) == R["ksplit"]
+    assert L.dl3_pwconv_route(0, 2 * 64 * 64, 160, 960) == R["tiled"]
+    # ... and through a lowered plan: the launches of the B=128 engine that take each route
+    e, c = _dry_engine(monkeypatch, "mobilenetv2", 128)
+    fwd = [L.dl3_pwconv_route(0, op[2][9], op[2][10], op[2][11]) for op in e.ops_fwd if op[0] == "dl3_pwconv_fwd"]
+    assert fwd.count(R["ws_mfma"]) == 10 and fwd.count(R["ws_hbm"]) == 12
+    wg = [L.dl3_pwconv_route(2, op[2][14], op[2][15], op[2][16]) for op in e.ops_bwd if op[0] == "dl3_pwconv_bwd_weight_dy"]
+    assert wg.count(R["wgrad_row"]) == 6
+    # the statistic partial rows the engine sized cover the weight-stationary kernel's one row per row group
+    assert L.dl3_pwconv_partials(M, 160, 960) >= 42 and L.dl3_pwconv_partials(M, 960, 160) >= 42
 
 
 def test_benchmarked_plan_lowers_consistently_without_a_gpu(monkeypatch):
