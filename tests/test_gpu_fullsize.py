@@ -382,7 +382,9 @@ def _benchmarked_plan(backbone, OS, Bbig, monkeypatch, oracle_pair):
     # B=16 and on the tiled kernel at B=2 — another summation order.  The bound is the oracle's own fp32 distance: two fp32
     # evaluations may part by as much as ONE of them parts from float64.)
     assert e_log < max(5e-5, yard_logits or 0.0) and e_loss < 1e-5
-    assert whole < max(1e-3, 0.5 * yard if yard else 2e-3) and worst < 3e-2
+    # (gradients likewise: whole vector within the oracle's own fp32-to-float64 distance at this size — cfg4, frozen BatchNorm:
+    # 5.8e-3 between the two plans against 1.0e-2 for torch-fp32 and 9.5e-3 for the B=2 engine itself; cfg2: 9e-4)
+    assert whole < max(1e-3, yard if yard else 2e-3) and worst < 3e-2
     del small
     _drop_engines(model)
     return model, x, labels, sw
