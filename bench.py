@@ -183,7 +183,7 @@ def _pmc_traffic(family, args):
     WRITE_SIZE, separate runs, corrected as MI355X_MICROARCH.md prescribes; tools/collect_profiles.sh +
     tools/pmc_family.py).  It is a constant read from profiles/, not a measurement of this run — the line says so in
     `traffic_source` — and only reported for the configuration it was collected on, else (None, None)."""
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         rel = os.path.join("profiles", "%s_%s_b%d_pmc.json" % (rnd, family, args.batch))
         pmc = os.path.join(ROOT, rel)
         if os.path.exists(pmc) and args.head == "deeplab" and args.size == 512:
@@ -211,8 +211,9 @@ def roofline_blocks(rows, args):
         tf = g["flops"] / g["ms"] / 1e9
         out["roofline"] = {
             "bound": "mfma", "kernel": "Conv2D 1x1 GEMM family on v_mfma_f32_32x32x2_f32: pw_gemm_stream_kernel (forward, "
-            "bwd-data) + pw_fwd_ws_kernel (forward of the HBM-bound early layers, weights resident in LDS) + pw_wgrad_kernel "
-            "(bwd-weight) + pw_bwd_fused2_kernel (both gradients of the HBM-bound early layers in one pass), "
+            "bwd-data) + pw_ws2_kernel (short reductions, weight slice resident in LDS) + pw_fwd_ws_kernel (forward of the "
+            "HBM-bound early layers) + pw_wgrad_kernel / pw_wgrad_row_kernel (bwd-weight) + pw_bwd_fused2_kernel (both "
+            "gradients of the HBM-bound early layers in one pass), "
             "%d launches/step" % g["launches"],
             "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS,
             "traffic": _pmc_traffic("gemm", args)[0], "traffic_source": _pmc_traffic("gemm", args)[1],
@@ -451,15 +452,19 @@ def split_math_leg(args):
                         "::test_cfg4_xception_os8_256_train_step_split_math (same bars as the f32 tests)"}
 
 
-def fed_run(eng, steps, classes=21):
+def fed_run(eng, steps, classes=21, step=None, dp=None):
     """The same resident step FED from the host (utils.py:360-402 + :231-241 are what it replaces): every
     step a NEW batch — uint8 images + uint8 label maps, three distinct pinned host batches in rotation — crosses PCIe on a
     copy stream while the previous step runs (feed.BatchFeeder: two device slots), is widened into the engine's input and
-    turned into (Y, SW) by dl3_prepare_targets on the device.  Timed like the resident loop, on the same engine."""
+    turned into (Y, SW) by dl3_prepare_targets on the device.  Timed like the resident loop, on the same engine.
+    N > 1 (round 6): every rank feeds ITS shard (its own host batches, its own copy stream) and runs the
+    data-parallel step handed in — captured step, ONE arena all-reduce, Adam finishing the scale on the device —; barrier on both
+    sides, max over ranks, whole-job images per second."""
     from dl3_amd.feed import BatchFeeder
     B = eng.B
     H, W = eng.xbuf.H, eng.xbuf.W
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + (dp.rank if dp is not None else 0))
+    world = dp.world if dp is not None else 1
     host = []
     for _ in range(3):
         img = torch.from_numpy(rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)).pin_memory()
@@ -468,16 +473,23 @@ def fed_run(eng, steps, classes=21):
         host.append((img, torch.from_numpy(lab).pin_memory()))
     fd = BatchFeeder(eng, classes, np.uint8)
 
-    def step():
-        eng.fwd_bwd()
-        eng.adam(None, 1.0)
+    if step is None:
+        def step():
+            eng.fwd_bwd()
+            eng.adam(None, 1.0)
 
     fd.run((host[i % 3] for i in range(3)), step)      # warm-up: pinned registration, copy stream, both slots
     torch.cuda.synchronize()
+    if dp is not None:
+        dp.barrier()
     t0 = time.perf_counter()
     n = fd.run((host[i % 3] for i in range(steps)), step)
     torch.cuda.synchronize()
+    if dp is not None:
+        dp.barrier()
     dt = time.perf_counter() - t0
+    if dp is not None:
+        dt = dp.max_over_ranks(dt)
     assert n == steps
     # the link on its own: one image batch, H2D, alone on the copy stream
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -487,7 +499,7 @@ def fed_run(eng, steps, classes=21):
         e1.record(fd.copy_stream)
     torch.cuda.synchronize()
     raw = fd.nx / (e0.elapsed_time(e1) * 1e-3) / 1e9
-    return {"value": B * steps / dt, "unit": "img/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+    return {"value": B * world * steps / dt, "unit": "img/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
             "host_bytes_per_step": fd.bytes_per_batch, "pcie_gb_s_sustained_by_the_loop": fd.bytes_per_batch * steps / dt / 1e9,
             "pcie_gb_s_one_copy_alone": raw, "final_loss": eng.loss_value()}
 
@@ -635,9 +647,10 @@ def main():
     log("timed %d steps: %.1f ms/step" % (args.steps, 1e3 * dt / args.steps))
     ar_ms = allreduce_ms()
     fed = None
-    if dp.world == 1 and not args.no_legs and not eng.external_nnz:
-        fed = fed_run(eng, args.steps)
-        fed["vs_resident"] = round(fed["value"] / (args.batch * args.steps / dt), 4)
+    if not args.no_legs and (dp.world > 1 or not eng.external_nnz):
+        # (N > 1: every rank feeds its own shard into the data-parallel step; N = 1: the plain resident step)
+        fed = fed_run(eng, args.steps, step=step if dp.world > 1 else None, dp=dp if dp.world > 1 else None)
+        fed["vs_resident"] = round(fed["value"] / (args.batch * dp.world * args.steps / dt), 4)
         log("fed from the host: %.1f img/s = %.3f x resident" % (fed["value"], fed["vs_resident"]))
 
     if dp.rank == 0:

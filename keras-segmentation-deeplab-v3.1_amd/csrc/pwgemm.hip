@@ -1781,14 +1781,19 @@ __global__ __launch_bounds__(256, OC) void pw_fwd_ws_kernel(GemmArgs P) {
 // sum(v), sum(v * x_hat).  Both need x element by element — it is requested 16 bytes at a time in the SAME row-piece layout the
 // output leaves in (block j + 1's pieces while block j is finished), and the sums are kept per lane for its four columns,
 // folded over the eight row lanes once at the end.
-template <int KQ, int TN, int NW, bool BWD = false>
+// TWO (BWD only): the two-tensor gradient operand dY = cA*g + cB*y + cC assembled on load — the expand convolutions 64 -> 384,
+// whose weight-gradient launch writes no dY (a narrow x against a wide dY: the store does not pay, round 4): reduction 384
+// into a 64-wide gradient, HBM-bound, 98 KB of W^T resident.  ADD (BWD only): a residual gradient joins in the epilogue
+// (requested in the same row-piece layout as the forward input).
+template <int KQ, int TN, int NW, bool BWD = false, bool TWO = false, bool ADD = false>
 __global__ __launch_bounds__(64 * NW) void pw_ws2_kernel(GemmArgs P) {
+  static_assert(BWD || (!TWO && !ADD), "two-tensor operand / residual addend: bwd-data only");
   constexpr int KH = 4 * KQ, K = 8 * KQ, NP = 32 * TN;
   __shared__ __attribute__((aligned(16))) float Ws[K * NP];   // W[k][n0 + n], zero beyond N
-  __shared__ __attribute__((aligned(16))) float cf[2 * K];    // scale | shift of the input transform
+  __shared__ __attribute__((aligned(16))) float cf[(TWO ? 3 : 2) * K];    // scale | shift of the input transform (TWO: cA | cC | cB)
   __shared__ __attribute__((aligned(16))) float bs[BWD ? 4 * NP : NP];   // bias | BWD: mask scale, mask shift, mean, 1 / sigma of x
   __shared__ __attribute__((aligned(16))) float Cs[NW * 1024];  // per wave: one 32x32 block on its way out; at the end: the statistic fold
-  static_assert(sizeof(float) * (K * NP + 2 * K + 4 * NP + NW * 1024) <= 160 * 1024, "gfx950: 160 KB of LDS per CU");
+  static_assert(sizeof(float) * (K * NP + 3 * K + 4 * NP + NW * 1024) <= 160 * 1024, "gfx950: 160 KB of LDS per CU");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -1807,6 +1812,7 @@ __global__ __launch_bounds__(64 * NW) void pw_ws2_kernel(GemmArgs P) {
   for (int i = tid; i < K; i += 64 * NW) {
     cf[i] = xform ? P.ka[i] : 1.f;
     cf[K + i] = xform ? P.kc[i] : 0.f;
+    if constexpr (TWO) cf[2 * K + i] = P.kb[i];
   }
   for (int i = tid; i < NP; i += 64 * NW) {
     const int col = min(n0 + i, P.N - 1);
@@ -1849,12 +1855,17 @@ __global__ __launch_bounds__(64 * NW) void pw_ws2_kernel(GemmArgs P) {
   static_assert(NCH % 2 == 0, "an even number of chunks per tile");
   constexpr int SQ = KQ / NCH;                       // 16-byte pieces per chunk
   static_assert(KQ % NCH == 0, "the reduction must split into an even number of equal chunks");
-  f32x4 nx[2][SQ];
-  auto req = [&](int t, int c, f32x4 (&slot)[SQ]) __attribute__((always_inline)) {
+  f32x4 nx[2][SQ], ny[2][TWO ? SQ : 1];
+  auto req = [&](int t, int c, int sl) __attribute__((always_inline)) {
     const int row = min(t * 32 + l31, P.M - 1);
     const float *p = P.a + (size_t)row * P.lda + KH * lhi + 4 * SQ * c;
 #pragma unroll
-    for (int j = 0; j < SQ; j++) slot[j] = ld4(p + 4 * j);
+    for (int j = 0; j < SQ; j++) nx[sl][j] = ld4(p + 4 * j);
+    if constexpr (TWO) {
+      const float *p2 = P.a2 + (size_t)row * P.lda2 + KH * lhi + 4 * SQ * c;
+#pragma unroll
+      for (int j = 0; j < SQ; j++) ny[sl][j] = ld4(p2 + 4 * j);
+    }
   };
   // tile t: its chunks 0 and 1 are in flight (or landed) on entry; tn = the wave's next tile (itself again at the end:
   // harmless duplicate requests instead of a branch around requests).  The B fragments of k-step s + 1 are read from the
@@ -1873,8 +1884,14 @@ __global__ __launch_bounds__(64 * NW) void pw_ws2_kernel(GemmArgs P) {
       for (int q = 0; q < SQ; q++) {
         const int kq = SQ * c + q;
         f32x4 v;
-        if constexpr (BWD) v = nx[c & 1][q];
-        else v = dl3_act4(ld4(cfs + 4 * kq) * nx[c & 1][q] + ld4(cft + 4 * kq), P.a_act);
+        if constexpr (TWO) {
+          v = ld4(cfs + 4 * kq) * nx[c & 1][q] + ld4(cft + 4 * kq);
+          v += ld4(cf + 2 * K + KH * lhi + 4 * kq) * ny[c & 1][q];
+        } else if constexpr (BWD) {
+          v = nx[c & 1][q];
+        } else {
+          v = dl3_act4(ld4(cfs + 4 * kq) * nx[c & 1][q] + ld4(cft + 4 * kq), P.a_act);
+        }
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const int ks = 4 * kq + e, cur = ks & 1;
@@ -1889,16 +1906,16 @@ __global__ __launch_bounds__(64 * NW) void pw_ws2_kernel(GemmArgs P) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (c + 2 < NCH) req(t, c + 2, nx[c & 1]);
-      else req(tn, c + 2 - NCH, nx[c & 1]);
+      if (c + 2 < NCH) req(t, c + 2, c & 1);
+      else req(tn, c + 2 - NCH, c & 1);
       __builtin_amdgcn_sched_barrier(0);
     }
     DL3_T(tp1 += clock64() - w1;)
   };
 
   if (gw < nfull) {
-    req(gw, 0, nx[0]);
-    req(gw, 1, nx[1]);
+    req(gw, 0, 0);
+    req(gw, 1, 1);
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);
   for (int t = gw; t < nfull; t += GW) {
@@ -1933,15 +1950,22 @@ __global__ __launch_bounds__(64 * NW) void pw_ws2_kernel(GemmArgs P) {
     if constexpr (BWD) {
       float *const cp = P.c + (size_t)(t * 32 + r0) * P.ldc + n0;
       const float *const xp = P.ep_x + (size_t)(t * 32 + r0) * P.ld_epx + n0;
-      f32x4 xq[2][4];
+      const float *const ap = ADD ? P.ep_add + (size_t)(t * 32 + r0) * P.ld_add + n0 : nullptr;
+      f32x4 xq[2][4], aq[2][ADD ? 4 : 1];
 #pragma unroll
-      for (int p = 0; p < 4; p++) xq[0][p] = ld4(xp + (size_t)(8 * p) * P.ld_epx + (0 == jl ? c4l : c4));
+      for (int p = 0; p < 4; p++) {
+        xq[0][p] = ld4(xp + (size_t)(8 * p) * P.ld_epx + (0 == jl ? c4l : c4));
+        if constexpr (ADD) aq[0][p] = ld4(ap + (size_t)(8 * p) * P.ld_add + (0 == jl ? c4l : c4));
+      }
 #pragma unroll
       for (int j = 0; j < TN; j++) {
         if (j <= jl) {
           if (j + 1 <= jl) {
 #pragma unroll
-            for (int p = 0; p < 4; p++) xq[(j + 1) & 1][p] = ld4(xp + (size_t)(8 * p) * P.ld_epx + (j + 1) * 32 + (j + 1 == jl ? c4l : c4));
+            for (int p = 0; p < 4; p++) {
+              xq[(j + 1) & 1][p] = ld4(xp + (size_t)(8 * p) * P.ld_epx + (j + 1) * 32 + (j + 1 == jl ? c4l : c4));
+              if constexpr (ADD) aq[(j + 1) & 1][p] = ld4(ap + (size_t)(8 * p) * P.ld_add + (j + 1) * 32 + (j + 1 == jl ? c4l : c4));
+            }
           }
 #pragma unroll
           for (int r = 0; r < 16; r++) cw[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 32 + l31] = acc[j][r];
@@ -1954,7 +1978,8 @@ __global__ __launch_bounds__(64 * NW) void pw_ws2_kernel(GemmArgs P) {
 #pragma unroll
           for (int p = 0; p < 4; p++) {
             const f32x4 x = xq[j & 1][p];
-            const f32x4 o = ld4(cw + (r0 + 8 * p) * 32 + cc) * dl3_mask4(es * x + et, P.ep_act);
+            f32x4 o = ld4(cw + (r0 + 8 * p) * 32 + cc) * dl3_mask4(es * x + et, P.ep_act);
+            if constexpr (ADD) o += P.add_scale * aq[j & 1][p];
             st4_nt(cp + (size_t)(8 * p) * P.ldc + j * 32 + cc, o);
             q1[j] += own * o;
             q2[j] += own * (o * ((x - mu) * is));
@@ -2002,8 +2027,8 @@ __global__ __launch_bounds__(64 * NW) void pw_ws2_kernel(GemmArgs P) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    req(nfull, 0, nx[0]);
-    req(nfull, 1, nx[1]);
+    req(nfull, 0, 0);
+    req(nfull, 1, 1);
     mfma_tile(acc, nfull, nfull);
     const int m0 = nfull * 32;
 #pragma unroll
@@ -2018,6 +2043,7 @@ __global__ __launch_bounds__(64 * NW) void pw_ws2_kernel(GemmArgs P) {
           if constexpr (BWD) {
             const float x = P.ep_x[(size_t)row * P.ld_epx + col];
             v *= dl3_act_mask(bs[j * 32 + l31] * x + bs[NP + j * 32 + l31], P.ep_act);
+            if constexpr (ADD) v += P.add_scale * P.ep_add[(size_t)row * P.ld_add + col];
             st1[j] += v;
             st2[j] += v * ((x - bs[2 * NP + j * 32 + l31]) * bs[3 * NP + j * 32 + l31]);
           } else {
@@ -2339,10 +2365,18 @@ bool ws2_shape(int M, int K, int N) {
   return M >= 131072 && N % 4 == 0 && ((K == 160 && N >= 320) || (K == 96 && N >= 192) || (K == 64 && N >= 128));
 }
 inline int ws2_tn(int K) { return K == 160 ? 5 : (K == 96 ? 3 : 4); }
-// 1: forward, 2: bwd-data (single-tensor dY, mask and BatchNorm-backward sums from the forward input, no addend), 0: no
+// 1: forward, 2: bwd-data (single-tensor dY, mask and BatchNorm-backward sums from the forward input, no addend), 3: bwd-data
+// of the expand convolutions 64 -> 384 (two-tensor operand over a reduction of 384, 64-wide gradient, optional residual), 0: no
 int ws2_wanted(const GemmArgs &A, bool fwd, bool vec) {
-  if (!vec || A.ep_add || A.a2 || A.bias && !fwd) return 0;
-  if (A.ldc % 4 != 0 || (((uintptr_t)A.c) & 15) != 0 || !ws2_shape(A.M, A.K, A.N)) return 0;
+  static const int env = env_int("DL3_WS2");
+  if (env == 0 || !vec || (A.bias && !fwd) || A.ldc % 4 != 0 || (((uintptr_t)A.c) & 15) != 0) return 0;
+  if (!fwd && A.a2) {
+    if (A.M < 131072 || A.K != 384 || A.N != 64 || !A.ka || A.bias || A.stat_mode == 1 || !A.ep_x) return 0;
+    if (A.ld_epx % 4 != 0 || (((uintptr_t)A.ep_x) & 15) != 0) return 0;
+    if (A.ep_add && (A.add_div != 1 || A.ld_add % 4 != 0 || (((uintptr_t)A.ep_add) & 15) != 0)) return 0;
+    return 3;
+  }
+  if (A.ep_add || A.a2 || !ws2_shape(A.M, A.K, A.N)) return 0;
   if (fwd) return 1;
   if (A.ka || !A.ep_x || A.ld_epx % 4 != 0 || (((uintptr_t)A.ep_x) & 15) != 0 || A.stat_mode == 1) return 0;
   return 2;
@@ -2495,6 +2529,13 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   // inside one image)
   const bool fwd = !two && !A.ep_x && A.stat_mode != 2 && !(A.ep_add && A.add_div > 1 && A.add_div % 32 != 0);
   if (const int w2 = split_math() ? 0 : ws2_wanted(A, fwd, vec)) {
+    if (w2 == 3) {
+      const int nrg = ws2_groups(A.M, 1);
+      const dim3 grid(1, nrg);
+      if (A.ep_add) hipLaunchKernelGGL((pw_ws2_kernel<48, 2, DL3_WS2_NW, true, true, true>), grid, dim3(64 * DL3_WS2_NW), 0, st, A);
+      else hipLaunchKernelGGL((pw_ws2_kernel<48, 2, DL3_WS2_NW, true, true, false>), grid, dim3(64 * DL3_WS2_NW), 0, st, A);
+      return nrg;
+    }
     const int tn = ws2_tn(A.K), ntn = dl3_cdiv(A.N, 32 * tn), nrg = ws2_groups(A.M, ntn);
     if (w2 == 2) {
       const dim3 grid(ntn, nrg);
@@ -2726,6 +2767,10 @@ extern "C" int dl3_pwconv_partials(int M, int K, int N) {
   }
   if (ws2_shape(M, K, N)) {
     const int q = ws2_groups(M, dl3_cdiv(N, 32 * ws2_tn(K)));
+    p = q > p ? q : p;
+  }
+  if (M >= 131072 && K == 384 && N == 64) {   // (the two-tensor bwd-data route of the expand convolutions: one column tile)
+    const int q = ws2_groups(M, 1);
     p = q > p ? q : p;
   }
   if (ksplit_tn(M, K, N)) {  // the K-split kernel of the small batches: one row per 32-row tile

@@ -550,7 +550,10 @@ def test_pwconv_fwd_weight_stationary_short_reductions(L, case):
 @pytest.mark.parametrize("case", [(262144 + 19, 960, 160, 2, False, 0, True), (131072, 576, 96, 2, False, 0, True),
                                   (140000, 1000, 160, 1, False, 0, True), (133000, 384, 96, None, False, 0, True),
                                   (131072 + 7, 320, 160, 2, False, 0, False), (131072 + 40, 384, 64, None, False, 0, True),
-                                  (150000, 200, 64, 2, False, 0, True)])
+                                  (150000, 200, 64, 2, False, 0, True),
+                                  # the expand convolutions 64 -> 384: two-tensor operand over a reduction of 384, residual gradient
+                                  (131072 + 50, 64, 384, None, True, 1, True), (140000, 64, 384, None, True, 0, True),
+                                  (131072, 64, 384, 1, True, 1, False)])
 def test_pwconv_bwd_data_weight_stationary_short_reductions(L, case):
     """... and its bwd-data instantiation (single-tensor dY): activation mask from the forward input requested in the row-piece
     layout the output leaves in, BatchNorm-backward sums kept per lane for four columns and folded over the row lanes at the

@@ -232,6 +232,9 @@ def test_bench_self_spawns_its_ranks():
     assert rec["config"]["gradient_exchange"] == "gloo (host staged)" and rec["config"]["rccl_ranks"] is None
     assert rec["allreduce_ms"] > 0 and rec["config"]["dist_strict"] is False
     assert abs(rec["value"] - 4 * 3 / (rec["ms_per_step"] * 3e-3)) < 1e-6 * rec["value"]
+    # round 6: the N > 1 line carries the fed leg too — every rank feeds its own shard into the data-parallel step
+    assert rec["fed"]["value"] > 0 and rec["fed"]["steps"] == 3 and np.isfinite(rec["fed"]["final_loss"])
+    assert abs(rec["fed"]["value"] - 4 * 3 / (rec["fed"]["ms_per_step"] * 3e-3)) < 1e-6 * rec["fed"]["value"]
     # a launcher environment that disagrees with --gpus is refused, not silently reinterpreted
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     res = subprocess.run(cmd, env=env2, capture_output=True, text=True, timeout=300)
