@@ -2793,14 +2793,15 @@ extern "C" int dl3_pwconv_fwd_impl(int M, int K, int N) {
   return ws_wanted(A, true, true) ? 1 : 0;
 }
 
+// the weight gradient of a launch with tile configuration c takes the one-tile-row kernel (DL3_WGRAD_ROW=0: off — A/B aid)
+static bool wgrad_row_ok(const WgCfg &c, int M, int K, int N) {
+  static const int row_env = env_int("DL3_WGRAD_ROW");
+  return row_env != 0 && !split_math() && dl3_cdiv(K, c.BKT) == 1 && K % 4 == 0 && N % 4 == 0 && (c.id == 2 || c.id == 8) && M >= 32768;
+}
+
 extern "C" int dl3_pwconv_route(int dir, int M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0 || split_math()) return DL3_ROUTE_TILED;
-  if (dir == 2) {
-    const WgCfg c = pick_wgrad(M, K, N, true);
-    static const int row_env = env_int("DL3_WGRAD_ROW");
-    const bool row = row_env != 0 && dl3_cdiv(K, c.BKT) == 1 && K % 4 == 0 && N % 4 == 0 && (c.id == 2 || c.id == 8) && M >= 32768;
-    return row ? DL3_ROUTE_WGRAD_ROW : DL3_ROUTE_TILED;
-  }
+  if (dir == 2) return wgrad_row_ok(pick_wgrad(M, K, N, true), M, K, N) ? DL3_ROUTE_WGRAD_ROW : DL3_ROUTE_TILED;
   GemmArgs A{};
   if (dir == 0) {
     A.M = M; A.K = K; A.N = N; A.ldc = N;
@@ -2972,7 +2973,7 @@ static int pwconv_bwd_weight_impl(const float *x, int ldx, const float *in_scale
   const bool xvec = (K % 4 == 0) && (ldx % 4 == 0) && al16(x);
   const bool dvec = (N % 4 == 0) && (ldg % 4 == 0) && al16(g) && (!two || ((ldyraw % 4 == 0) && al16(yraw)));
   // one tile row covers the whole K (expand convolutions): the straight-line kernel with the requests in front of the stores
-  if (xvec && dvec && dl3_pwconv_route(2, M, K, N) == DL3_ROUTE_WGRAD_ROW) {   // (DL3_WGRAD_ROW=0: off — A/B aid)
+  if (xvec && dvec && wgrad_row_ok(c, M, K, N)) {   // (c: the configuration THIS launch's grid was sized for)
     if (c.id == 2) {
       if (dy_out) hipLaunchKernelGGL((pw_wgrad_row_kernel<5, 1, 1, 4, true>), grid, dim3(256), 0, st, A);
       else hipLaunchKernelGGL((pw_wgrad_row_kernel<5, 1, 1, 4, false>), grid, dim3(256), 0, st, A);

@@ -536,6 +536,15 @@ def test_pwconv_bwd_weight_dy_benchmark_routes(L, case):
     test_pwconv_bwd_weight_writes_dy(L, case)
 
 
+@pytest.mark.parametrize("case", [(40000, 160, 960, 2, False, False), (40000 + 9, 96, 576, None, False, False),
+                                  (33000, 160, 328, 1, True, False), (32768 + 3, 96, 576, 2, True, False)])
+def test_pwconv_bwd_weight_one_tile_row(L, case):
+    """round 6 (pw_wgrad_row_kernel): K fits one tile row — plain dY (no BatchNorm behind the convolution) and the two-tensor
+    operand, without the dY store; N ragged against the 128-wide tiles (idle waves), M not a multiple of the 16-row stage"""
+    assert L.dl3_pwconv_route(2, case[0], case[1], case[2]) == 4
+    test_pwconv_bwd_weight(L, case)
+
+
 @pytest.mark.parametrize("case", [(266000 + 17, 160, 960, 0, 0, False, 2), (140000, 96, 576, 0, 0, True, 1),
                                   (133000, 160, 320, 0, 64, False, None), (131072 + 5, 160, 1000, 0, 0, False, 2),
                                   (131072 + 33, 64, 384, 64, 0, False, 2), (140000, 64, 200, 0, 0, False, None)])
