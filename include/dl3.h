@@ -104,16 +104,21 @@ int dl3_pwconv_partials(int M, int K, int N);
  * no addend): 0 the tiled MFMA GEMM, 1 the weight-stationary streaming kernel of the HBM-bound layers (round 5: the
  * whole K x N matrix in LDS, every wave walks 32-row tiles on its own, 16-byte stores; deeplabv3p.py:175-198 at
  * 16..192 channels, M >= 32768), 2 the weight-stationary kernel of the MFMA-bound short reductions (round 6: K = 160 / 96 /
- * 64 into an output at least twice as wide, M >= 131072; DL3_WS2=0 disables it).  Diagnostic only. */
+ * 64 into an output at least twice as wide, M >= 131072; DL3_WS2=0 disables it — and its packed-output variant for the
+ * logits layer, K = 256, N <= 32, ldy == N, M >= 8192; DL3_NARROW=0).  Diagnostic only. */
 int dl3_pwconv_fwd_impl(int M, int K, int N);
 /* ... and the route of a launch by name, for plans that want to assert what they benchmark (tests/test_host.py):
  * dir 0 = forward (as dl3_pwconv_fwd_impl), 1 = bwd-data with the single-tensor dY, a mask operand and no addend, 2 = the
- * weight gradient (two-tensor operand).  Returns DL3_ROUTE_*.  Diagnostic only. */
+ * weight gradient (two-tensor operand), 3 = bwd-data with the single-tensor dY (rows back to back) and neither mask, addend
+ * nor BatchNorm sums, 4 = the weight gradient with a single-tensor dY and a bias gradient (3, 4: the logits layer).
+ * Returns DL3_ROUTE_*.  Diagnostic only. */
 #define DL3_ROUTE_TILED 0      /* pw_gemm_stream_kernel / pw_gemm_kernel / pw_wgrad_kernel */
 #define DL3_ROUTE_WS_HBM 1     /* pw_fwd_ws_kernel */
 #define DL3_ROUTE_WS_MFMA 2    /* pw_ws2_kernel */
 #define DL3_ROUTE_KSPLIT 3     /* pw_ksplit32_kernel (1 024 - 16 384 rows) */
 #define DL3_ROUTE_WGRAD_ROW 4  /* pw_wgrad_row_kernel (one tile row over K) */
+#define DL3_ROUTE_NARROW 5     /* the logits layer, N = classes <= 32 off a 256-wide input: pw_ws2_kernel FLAT (dir 0),
+                                  pw_narrowk_kernel (dir 3), pw_wgrad_narrow_kernel (dir 4) */
 int dl3_pwconv_route(int dir, int M, int K, int N);
 /* y[M,N](ldy) = T(x)[M,K](ldx) . w[K,N] (+bias[N]); stat_partial (nullable) [P][N][2] = sum(y), sum(y^2) */
 int dl3_pwconv_fwd(const float *x, int ldx, const float *in_scale, const float *in_shift, int in_act,

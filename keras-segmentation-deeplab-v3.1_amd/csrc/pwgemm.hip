@@ -1785,9 +1785,14 @@ __global__ __launch_bounds__(256, OC) void pw_fwd_ws_kernel(GemmArgs P) {
 // whose weight-gradient launch writes no dY (a narrow x against a wide dY: the store does not pay, round 4): reduction 384
 // into a 64-wide gradient, HBM-bound, 98 KB of W^T resident.  ADD (BWD only): a residual gradient joins in the epilogue
 // (requested in the same row-piece layout as the forward input).
-template <int KQ, int TN, int NW, bool BWD = false, bool TWO = false, bool ADD = false>
+// FLAT (forward only, one column block): the logits layer (deeplabv3p.py:438) — N = classes <= 32 columns, rows of N floats
+// back to back (ldc == N, N any number): a 32-row tile of the output is ONE contiguous run of 128 N bytes, which starts on a
+// 16-byte boundary whatever N is.  The block goes through the wave's LDS square packed N floats per row and leaves as 8 N
+// 16-byte pieces — the tiled kernel's scalar stores into 84-byte rows were what held this HBM-bound launch at 0.40 of peak.
+template <int KQ, int TN, int NW, bool BWD = false, bool TWO = false, bool ADD = false, bool FLAT = false>
 __global__ __launch_bounds__(64 * NW) void pw_ws2_kernel(GemmArgs P) {
   static_assert(BWD || (!TWO && !ADD), "two-tensor operand / residual addend: bwd-data only");
+  static_assert(!FLAT || (!BWD && TN == 1), "packed narrow output: forward, one column block");
   constexpr int KH = 4 * KQ, K = 8 * KQ, NP = 32 * TN;
   __shared__ __attribute__((aligned(16))) float Ws[K * NP];   // W[k][n0 + n], zero beyond N
   __shared__ __attribute__((aligned(16))) float cf[(TWO ? 3 : 2) * K];    // scale | shift of the input transform (TWO: cA | cC | cB)
@@ -1841,9 +1846,9 @@ __global__ __launch_bounds__(64 * NW) void pw_ws2_kernel(GemmArgs P) {
   const float *const wfrag = Ws + KH * lhi * NP + l31;
   const float *const cfs = cf + KH * lhi, *const cft = cf + K + KH * lhi;
   const int c4 = (lane & 7) * 4, r0 = lane >> 3;
-  const int ncol = min(NP, P.N - n0);                   // columns of this tile inside the matrix (a multiple of 4)
+  const int ncol = min(NP, P.N - n0);                   // columns of this tile inside the matrix (a multiple of 4; FLAT: any)
   const int jl = (ncol - 1) >> 5;                        // its last column block
-  const int c4l = c4 % (ncol - 32 * jl);                 // lanes beyond the last block's columns repeat a valid column group
+  const int c4l = FLAT ? 0 : c4 % (ncol - 32 * jl);      // lanes beyond the last block's columns repeat a valid column group
 
   // The lane's K/2 operand values arrive as a stream of NCH chunks per tile through a ring of two register slots: while the
   // MFMAs of chunk c run, chunk c + 1 is in flight and chunk c + 2 — of this tile or, behind its last two chunks, of the wave's
@@ -1987,6 +1992,24 @@ __global__ __launch_bounds__(64 * NW) void pw_ws2_kernel(GemmArgs P) {
           __builtin_amdgcn_wave_barrier();
         }
       }
+    } else if constexpr (FLAT) {
+      const float bj = bs[l31];
+      float *const cq = cw + 4 * lhi * P.N + l31;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float v = acc[0][r] + bj;
+        st1[0] += v;
+        st2[0] += v * v;
+        if (l31 < P.N) cq[((r & 3) + 8 * (r >> 2)) * P.N] = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+      float *const cp = P.c + (size_t)t * 32 * P.N;
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        const int piece = lane + 64 * p;
+        if (piece < 8 * P.N) st4_nt(cp + 4 * piece, ld4(cw + 4 * piece));
+      }
+      __builtin_amdgcn_wave_barrier();
     } else {
     float *const cp = P.c + (size_t)(t * 32 + r0) * P.ldc + n0;
 #pragma unroll
@@ -2109,6 +2132,206 @@ __global__ __launch_bounds__(64 * NW) void pw_ws2_kernel(GemmArgs P) {
         }
       }
     }
+  }
+}
+
+// ---- round 6: the logits layer's backward (deeplabv3p.py:438: Conv2D(classes, (1, 1)) on the 256-wide decoder output) --------
+// Both are HBM-bound streams whose narrow side is `classes` = 21 floats per row — 84-byte rows that no 16-byte access lines up
+// with, which is why the tiled kernels ran them at 0.35 / 0.21 of the HBM peak (scalar loads of the narrow operand, 16-row
+// stages with eight MFMAs per barrier).  The narrow operand is handled as what it is in memory: one contiguous run.
+//
+// bwd-data: dX[M, 32 TN] = dY[M, K] . W^T[K, 32 TN] with K = classes <= 32 and dY rows back to back (lda == K): a wave takes the
+// 32 K floats of its row tile as 8 K 16-byte pieces of one contiguous, 16-byte-aligned run (three loads per lane at K = 21,
+// requested one tile ahead), parks them in a wave-private LDS strip and reads its MFMA A-fragments from there (row l31, k =
+// lhi ceil(K/2) + s: stride K, conflict-free for odd K); W^T sits in LDS for the workgroup's lifetime, zero rows up to 2 ceil(K/2).
+// No transform, mask, addend or BatchNorm sums: the layer's input is the Dropout output (a materialised buffer).
+template <int TN, int NW>
+__global__ __launch_bounds__(64 * NW) void pw_narrowk_kernel(GemmArgs P) {
+  constexpr int NP = 32 * TN;
+  __shared__ __attribute__((aligned(16))) float Bs[32 * NP];     // W^T[k][n], zero for k >= K
+  __shared__ __attribute__((aligned(16))) float As[NW * 1024];   // per wave: its tile of dY, 32 rows of K floats, packed
+  __shared__ __attribute__((aligned(16))) float Cs[NW * 1024];   // per wave: one 32x32 block on its way out
+  static_assert(sizeof(float) * (32 * NP + 2 * NW * 1024) <= 160 * 1024, "gfx950: 160 KB of LDS per CU");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int n0 = blockIdx.y * NP;
+  for (int i = tid; i < 32 * NP; i += 64 * NW) {
+    const int k = i / NP, n = n0 + i % NP;
+    Bs[i] = (k < P.K && n < P.N) ? P.b[(size_t)k * P.ldb + n] : 0.f;
+  }
+  __syncthreads();
+  const int KS = (P.K + 1) >> 1;                 // k-steps: lane half lhi owns k = lhi KS .. lhi KS + KS - 1
+  const int npc = 8 * P.K;                       // 16-byte pieces per row tile (<= 256)
+  const int nfull = P.M >> 5;
+  const int gw = blockIdx.x * NW + wave, GW = gridDim.x * NW;
+  float *const as = As + wave * 1024, *const cw = Cs + wave * 1024;
+  const int c4 = (lane & 7) * 4, r0 = lane >> 3;
+  f32x4 f[4];
+  auto req = [&](int t) __attribute__((always_inline)) {
+    const float *p = P.a + (size_t)t * 32 * P.K;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (lane + 64 * q < npc) f[q] = ld4(p + 4 * (lane + 64 * q));
+  };
+  auto products = [&](f32x16 (&acc)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+    const float *ap = as + l31 * P.K + lhi * KS;
+    const float *bp = Bs + lhi * KS * NP + l31;
+    for (int s = 0; s < KS; s++) {
+      const float a = (lhi * KS + s < P.K) ? ap[s] : 0.f;
+#pragma unroll
+      for (int j = 0; j < TN; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[s * NP + j * 32], acc[j], 0, 0, 0);
+    }
+  };
+  if (gw < nfull) req(gw);
+  for (int t = gw; t < nfull; t += GW) {
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (lane + 64 * q < npc) st4(as + 4 * (lane + 64 * q), f[q]);
+    __builtin_amdgcn_wave_barrier();
+    req(t + GW < nfull ? t + GW : t);
+    f32x16 acc[TN];
+    products(acc);
+    float *const cp = P.c + (size_t)(t * 32 + r0) * P.ldc + n0 + c4;
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      if (n0 + j * 32 < P.N) {      // (the output width is a multiple of 32: whole blocks)
+#pragma unroll
+        for (int r = 0; r < 16; r++) cw[((r & 3) + 8 * (r >> 2) + 4 * lhi) * 32 + l31] = acc[j][r];
+        __builtin_amdgcn_wave_barrier();
+        f32x4 o[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) o[p] = ld4(cw + (r0 + 8 * p) * 32 + c4);
+#pragma unroll
+        for (int p = 0; p < 4; p++) st4_nt(cp + (size_t)(8 * p) * P.ldc + j * 32, o[p]);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  if ((P.M & 31) != 0 && gw == nfull % GW) {   // the ragged last tile: element by element
+    const int m0 = nfull * 32;
+    const size_t total = (size_t)P.M * P.K;
+    for (int i = lane; i < 32 * P.K; i += 64) {
+      const size_t e = (size_t)m0 * P.K + i;
+      as[i] = e < total ? P.a[e] : 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    f32x16 acc[TN];
+    products(acc);
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const int col = n0 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (row < P.M && col < P.N) P.c[(size_t)row * P.ldc + col] = acc[j][r];
+      }
+    }
+  }
+}
+
+// bwd-weight: dW[K][N] = T(x)^T[K, M] . dY[M, N] (+ db[N] = column sums of dY) with N = classes <= 32 and K = 128 HB.  No LDS
+// stage, no barrier in the loop: the reduction index of the MFMA is the pixel row, so a lane's A operand is x[row + lhi][its
+// channel] — and WHICH channel an accumulator row stands for is ours to choose.  Lane (l31, lhi) requests 16 bytes at channel
+// 128 h + 4 l31 of row r + lhi (a half-wave reads 512 contiguous bytes): element e of that piece is the A operand of block
+// (h, e), whose accumulator row i is channel 128 h + 4 i + e.  Every 2-row k-step is HB 16-byte loads + one 4-byte load of dY
+// and 4 HB MFMAs; a wave keeps all 4 HB accumulators (the whole K x 32 gradient), walks 4-row chunks chunk = gw, gw + GW, ...
+// through a ring of D register slots (three chunks in flight while one is multiplied), and the NW waves of a workgroup meet
+// in LDS once at the end, in wave order: one [K][N] slab (and one row of column sums) per workgroup.
+template <int HB, int NW>
+__global__ __launch_bounds__(64 * NW) void pw_wgrad_narrow_kernel(WgradArgs P, float *cpart) {
+  constexpr int NB = 4 * HB, K = 128 * HB, D = 4;
+  __shared__ __attribute__((aligned(16))) float red[NB * 16 * 64];   // the workgroup's sum, accumulator layout
+  __shared__ __attribute__((aligned(16))) float cfx[2 * K];
+  __shared__ float dbs[NW * 32];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const bool xform = P.xs != nullptr;
+  for (int i = tid; i < K; i += 64 * NW) {
+    cfx[i] = xform ? P.xs[i] : 1.f;
+    cfx[K + i] = xform ? P.xt[i] : 0.f;
+  }
+  __syncthreads();
+  const int nchunks = (P.M + 3) >> 2;
+  const int gw = blockIdx.x * NW + wave, GW = gridDim.x * NW;
+  const int gcol = min(l31, P.N - 1);
+  const float colmask = l31 < P.N ? 1.f : 0.f;
+  f32x16 acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[b][r] = 0.f;
+  float gsum = 0.f;
+  f32x4 xr[D][2][HB];
+  float gr[D][2];
+  auto req = [&](int c, int sl) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      const int row = min(4 * c + 2 * ks + lhi, P.M - 1);   // (rows beyond M: a valid row, masked when it is multiplied)
+      const float *xp = P.x + (size_t)row * P.ldx + 4 * l31;
+#pragma unroll
+      for (int h = 0; h < HB; h++) xr[sl][ks][h] = ld4(xp + 128 * h);
+      gr[sl][ks] = P.g[(size_t)row * P.ldg + gcol];
+    }
+  };
+  auto multiply = [&](int c, int sl) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      const float gv = (4 * c + 2 * ks + lhi < P.M) ? gr[sl][ks] * colmask : 0.f;
+      gsum += gv;
+#pragma unroll
+      for (int h = 0; h < HB; h++) {
+        f32x4 v = xr[sl][ks][h];
+        if (xform) v = dl3_act4(ld4(cfx + 128 * h + 4 * l31) * v + ld4(cfx + K + 128 * h + 4 * l31), P.x_act);
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[4 * h + e] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[e], gv, acc[4 * h + e], 0, 0, 0);
+      }
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < D; d++) req(gw + d * GW, d);
+  for (int c = gw; c < nchunks; c += D * GW) {
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+      multiply(c + d * GW, d);
+      __builtin_amdgcn_sched_barrier(0);
+      req(c + (d + D) * GW, d);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // the NW waves' accumulators, in wave order
+  for (int w = 0; w < NW; w++) {
+    if (wave == w) {
+#pragma unroll
+      for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int i = (b * 16 + r) * 64 + lane;
+          red[i] = (w == 0 ? 0.f : red[i]) + acc[b][r];
+        }
+    }
+    __syncthreads();
+  }
+  gsum += __shfl_xor(gsum, 32, 64);
+  if (lhi == 0) dbs[wave * 32 + l31] = gsum;
+  float *slab = P.ws + (size_t)blockIdx.x * K * P.N;
+  for (int i = tid; i < K * P.N; i += 64 * NW) {
+    const int ch = i / P.N, n = i - ch * P.N;
+    const int h = ch >> 7, ii = (ch & 127) >> 2, e = ch & 3;
+    const int r = (ii & 3) + 4 * (ii >> 3), hi = (ii >> 2) & 1;
+    slab[i] = red[((4 * h + e) * 16 + r) * 64 + hi * 32 + n];
+  }
+  __syncthreads();
+  if (cpart && tid < P.N) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; w++) a += dbs[w * 32 + tid];
+    cpart[(size_t)blockIdx.x * P.N + tid] = a;
   }
 }
 
@@ -2390,6 +2613,34 @@ bool ws_wanted(const GemmArgs &A, bool fwd, bool vec) {
   return ws_tn(A.K, A.N) != 0;
 }
 
+// round 6: the logits layer (N = classes <= 32 off a 256-wide input): 1 = forward with the packed narrow output (pw_ws2_kernel
+// FLAT), 2 = bwd-data over the narrow reduction (pw_narrowk_kernel), 0 = no.  DL3_NARROW=0: the tiled kernels (A/B aid).
+bool narrow_on() {
+  static const int env = env_int("DL3_NARROW");
+  return env != 0;
+}
+bool narrow_shape(int M, int K, int N) { return narrow_on() && M >= 8192 && K == 256 && N <= 32; }
+int narrow_wanted(const GemmArgs &A, bool fwd, bool avec) {
+  if (A.a2 || A.ep_add || A.M < 8192 || !narrow_on()) return 0;
+  if (fwd && avec && narrow_shape(A.M, A.K, A.N) && A.ldc == A.N && (((uintptr_t)A.c) & 15) == 0) return 1;
+  // (16 384 rows: measured 8 192 rows 0.011 -> 0.013 ms, 65 536 rows 0.039 -> 0.023)
+  if (A.M >= 16384 && A.K <= 32 && A.N == 256 && !A.ka && A.a_act == DL3_ACT_NONE && !A.ep_x && !A.bias && A.stat_mode == 0 && A.lda == A.K &&
+      A.ldc % 4 == 0 && ((((uintptr_t)A.a) | ((uintptr_t)A.c)) & 15) == 0)
+    return 2;
+  return 0;
+}
+int narrow_groups(int M) {
+  const int cap = dl3_cdiv(dl3_cdiv(M, 32), DL3_WS2_NW);
+  return cap < 256 ? cap : 256;
+}
+// ... and its weight gradient (pw_wgrad_narrow_kernel): slabs = workgroups, one per CU, never more waves than 16-row spans
+// (from 131 072 rows: at 65 536 the eight-wave meeting and the 256-slab fold cost what the loop saves, 0.053 -> 0.056 ms)
+bool wgrad_narrow_shape(int M, int K, int N) { return narrow_on() && M >= 131072 && K == 256 && N <= 32; }
+int wgrad_narrow_slabs(int M) {
+  const int cap = dl3_cdiv(dl3_cdiv(M, 16), DL3_WS2_NW);
+  return cap < 256 ? cap : 256;
+}
+
 // ---- configuration choice -------------------------------------------------------------
 struct GemmCfg { int id, BM, BN; };
 const GemmCfg kGemmCfgs[] = {{0, 128, 128}, {1, 256, 64}, {2, 256, 32}, {3, 128, 160}, {4, 128, 96},
@@ -2528,6 +2779,15 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   // (a per-image addend stays on the forward instantiation when its straight-line epilogue can take it: 32-row blocks
   // inside one image)
   const bool fwd = !two && !A.ep_x && A.stat_mode != 2 && !(A.ep_add && A.add_div > 1 && A.add_div % 32 != 0);
+  if (const int nr = split_math() ? 0 : narrow_wanted(A, fwd, avec)) {
+    if (nr == 1) {
+      const int nrg = ws2_groups(A.M, 1);
+      hipLaunchKernelGGL((pw_ws2_kernel<32, 1, DL3_WS2_NW, false, false, false, true>), dim3(1, nrg), dim3(64 * DL3_WS2_NW), 0, st, A);
+      return nrg;
+    }
+    hipLaunchKernelGGL((pw_narrowk_kernel<8, DL3_WS2_NW>), dim3(narrow_groups(A.M), A.N / 256), dim3(64 * DL3_WS2_NW), 0, st, A);
+    return 0;
+  }
   if (const int w2 = split_math() ? 0 : ws2_wanted(A, fwd, vec)) {
     if (w2 == 3) {
       const int nrg = ws2_groups(A.M, 1);
@@ -2769,6 +3029,10 @@ extern "C" int dl3_pwconv_partials(int M, int K, int N) {
     const int q = ws2_groups(M, dl3_cdiv(N, 32 * ws2_tn(K)));
     p = q > p ? q : p;
   }
+  if (narrow_shape(M, K, N)) {   // (the logits layer's forward: one column tile)
+    const int q = ws2_groups(M, 1);
+    p = q > p ? q : p;
+  }
   if (M >= 131072 && K == 384 && N == 64) {   // (the two-tensor bwd-data route of the expand convolutions: one column tile)
     const int q = ws2_groups(M, 1);
     p = q > p ? q : p;
@@ -2789,6 +3053,7 @@ extern "C" int dl3_pwconv_fwd_impl(int M, int K, int N) {
   GemmArgs A{};
   A.M = M; A.K = K; A.N = N; A.ldc = N;
   if (split_math()) return 0;
+  if (narrow_wanted(A, true, true) == 1) return 2;
   if (ws2_wanted(A, true, true)) return 2;
   return ws_wanted(A, true, true) ? 1 : 0;
 }
@@ -2802,9 +3067,15 @@ static bool wgrad_row_ok(const WgCfg &c, int M, int K, int N) {
 extern "C" int dl3_pwconv_route(int dir, int M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0 || split_math()) return DL3_ROUTE_TILED;
   if (dir == 2) return wgrad_row_ok(pick_wgrad(M, K, N, true), M, K, N) ? DL3_ROUTE_WGRAD_ROW : DL3_ROUTE_TILED;
+  if (dir == 4) return wgrad_narrow_shape(M, K, N) ? DL3_ROUTE_NARROW : DL3_ROUTE_TILED;
   GemmArgs A{};
+  if (dir == 3) {   // bwd-data of a layer K -> N without a mask operand: reduces over N, K wide
+    A.M = M; A.K = N; A.N = K; A.ldc = K; A.lda = N;
+    return narrow_wanted(A, true, false) == 2 ? DL3_ROUTE_NARROW : DL3_ROUTE_TILED;
+  }
   if (dir == 0) {
     A.M = M; A.K = K; A.N = N; A.ldc = N;
+    if (narrow_wanted(A, true, true) == 1) return DL3_ROUTE_NARROW;
     if (ws2_wanted(A, true, true)) return DL3_ROUTE_WS_MFMA;
     if (ws_wanted(A, true, true)) return DL3_ROUTE_WS_HBM;
   } else {
@@ -2928,8 +3199,13 @@ extern "C" size_t dl3_pwconv_bwd_weight_workspace(int M, int K, int N) {
   // S depends on the operand form; size for the larger
   const WgCfg c1 = pick_wgrad(M, K, N, false), c2 = pick_wgrad(M, K, N, true);
   int S1 = wgrad_splits(M, K, N, c1), S2 = wgrad_splits(M, K, N, c2);
-  const int S = S1 > S2 ? S1 : S2;
-  return ((size_t)S * K * N + (size_t)colsum_rows(M) * N) * sizeof(float);
+  int S = S1 > S2 ? S1 : S2, crows = colsum_rows(M);
+  if (wgrad_narrow_shape(M, K, N)) {   // (one slab and one row of column sums per workgroup)
+    const int Sn = wgrad_narrow_slabs(M);
+    S = Sn > S ? Sn : S;
+    crows = Sn > crows ? Sn : crows;
+  }
+  return ((size_t)S * K * N + (size_t)crows * N) * sizeof(float);
 }
 
 extern "C" int dl3_pwconv_bwd_weight_splits(int M, int K, int N, int two_tensor_dy) {
@@ -2972,6 +3248,16 @@ static int pwconv_bwd_weight_impl(const float *x, int ldx, const float *in_scale
   dim3 grid(dl3_cdiv(N, c.BNT), dl3_cdiv(K, c.BKT), S);
   const bool xvec = (K % 4 == 0) && (ldx % 4 == 0) && al16(x);
   const bool dvec = (N % 4 == 0) && (ldg % 4 == 0) && al16(g) && (!two || ((ldyraw % 4 == 0) && al16(yraw)));
+  // the logits layer: N = classes, the whole K x N gradient in every wave's accumulators
+  if (xvec && !two && !dy_out && dw && !split_math() && wgrad_narrow_shape(M, K, N)) {
+    const int Sn = wgrad_narrow_slabs(M);
+    float *cpart = dbias ? A.ws + (size_t)Sn * K * N : nullptr;
+    hipLaunchKernelGGL((pw_wgrad_narrow_kernel<2, DL3_WS2_NW>), dim3(Sn), dim3(64 * DL3_WS2_NW), 0, st, A, cpart);
+    DL3_LAUNCH_CHECK("pwconv_bwd_weight(narrow)");
+    rc = dl3_reduce_partials(A.ws, Sn, K * N, dw, stream);
+    if (rc || !dbias) return rc;
+    return dl3_reduce_partials(cpart, Sn, N, dbias, stream);
+  }
   // one tile row covers the whole K (expand convolutions): the straight-line kernel with the requests in front of the stores
   if (xvec && dvec && wgrad_row_ok(c, M, K, N)) {   // (c: the configuration THIS launch's grid was sized for)
     if (c.id == 2) {

@@ -570,6 +570,48 @@ def test_pwconv_bwd_data_weight_stationary_short_reductions(L, case):
     test_pwconv_bwd_data(L, case)
 
 
+@pytest.mark.parametrize("case", [(32768, 256, 21, 0, 0, True, None), (40000 + 13, 256, 21, 0, 0, True, 1),
+                                  (8192 + 31, 256, 2, 0, 0, False, 2), (20000, 256, 32, 0, 0, True, None),
+                                  (9000, 256, 19, 64, 0, True, 1), (16384, 256, 24, 0, 0, False, 1)])
+def test_pwconv_fwd_logits_packed_rows(L, case):
+    """round 6 (pw_ws2_kernel FLAT): the logits layer (deeplabv3p.py:438) — N = classes <= 32 columns, rows of N floats back to
+    back: a 32-row tile leaves as one contiguous run of 16-byte pieces.  Odd N (21, 19), binary segmentation (2), a full
+    column block (32), N a multiple of 4 (24), ragged last row tile, an input that is a channel slice, BatchNorm sums"""
+    M, K, N = case[:3]
+    assert L.dl3_pwconv_route(0, M, K, N) == 5 and L.dl3_pwconv_route(0, 4096, K, N) != 5
+    test_pwconv_fwd(L, case)
+
+
+@pytest.mark.parametrize("case", [(32768, 256, 21), (40000 + 13, 256, 21), (16384 + 5, 256, 2), (20000, 256, 32), (19000, 256, 19),
+                                  (16384, 256, 24), (16400, 256, 1)])
+def test_pwconv_bwd_data_logits_narrow_reduction(L, case):
+    """round 6 (pw_narrowk_kernel): bwd-data of the logits layer — dX[M, 256] over a reduction of `classes` floats per row, the
+    gradient rows taken as one contiguous run per 32-row tile; odd / even / single-class reductions, ragged last row tile"""
+    M, K, N = case
+    assert L.dl3_pwconv_route(3, M, K, N) == 5 and L.dl3_pwconv_route(3, 4096, K, N) != 5
+    test_pwconv_bwd_data(L, (M, K, N, None, False, 0, False))
+
+
+@pytest.mark.parametrize("case", [(131072, 256, 21, None, False, True), (140000 + 13, 256, 21, 1, False, True),
+                                  (131072 + 5, 256, 2, 2, False, True), (132000 + 2, 256, 32, None, False, False),
+                                  (133000 + 1, 256, 19, 1, False, True), (300000 + 3, 256, 21, None, False, True)])
+def test_pwconv_bwd_weight_logits_narrow_output(L, case):
+    """round 6 (pw_wgrad_narrow_kernel): the logits layer's weight and bias gradient — every wave holds the whole 256 x N
+    gradient, 4-row chunks through a register ring, the waves of a workgroup meet in LDS in wave order; M not a multiple of the
+    4-row chunk, with / without an input transform, without the bias gradient"""
+    M, K, N = case[:3]
+    assert L.dl3_pwconv_route(4, M, K, N) == 5 and L.dl3_pwconv_route(4, 4096, K, N) != 5
+    test_pwconv_bwd_weight(L, case)
+
+
+def test_logits_layer_narrow_kernels_off_is_the_tiled_path(L, monkeypatch):
+    """DL3_NARROW is read once per process: the A/B switch is exercised in a child (tools/ab.sh style), here only that the
+    default process reports the narrow routes for the benchmarked logits shape"""
+    M = 128 * 128 * 128
+    assert [L.dl3_pwconv_route(d, M, 256, 21) for d in (0, 3, 4)] == [5, 5, 5]
+    assert L.dl3_pwconv_partials(M, 256, 21) >= 256
+
+
 WIDE_CASES = [(1300, 736, 736), (52480 + 37, 736, 736), (700, 64, 416), (256, 2048, 256)]
 
 

@@ -543,7 +543,7 @@ def test_knob_table_is_current():
     res = subprocess.run([sys.executable, os.path.join(root, "tools", "knobs.py"), "--check"], capture_output=True, text=True)
     assert res.returncode == 0, "KNOBS.md is stale or a knob lacks a description: run python tools/knobs.py\n" + res.stdout
     text = open(os.path.join(root, "KNOBS.md")).read()
-    assert text.count("| `DL3_") == 23
+    assert text.count("| `DL3_") == 24
 
 
 def test_default_kernel_routes_by_name(monkeypatch):
@@ -554,8 +554,12 @@ def test_default_kernel_routes_by_name(monkeypatch):
     weight-stationary MFMA kernel (below 131 072 rows); B=2: the K-split kernel on the 960 <-> 160 / 576 <-> 96 layers."""
     from dl3_amd import capi
     L = capi.lib()
-    R = dict(tiled=0, ws_hbm=1, ws_mfma=2, ksplit=3, wgrad_row=4)
+    R = dict(tiled=0, ws_hbm=1, ws_mfma=2, ksplit=3, wgrad_row=4, narrow=5)
     M = 128 * 64 * 64
+    # the logits layer (deeplabv3p.py:438): forward from B=2, bwd-data from B=4, weight gradient from B=32
+    assert [L.dl3_pwconv_route(d, M, 256, 21) for d in (0, 3, 4)] == [R["narrow"]] * 3
+    assert [L.dl3_pwconv_route(d, 16 * 64 * 64, 256, 21) for d in (0, 3, 4)] == [R["narrow"], R["narrow"], R["tiled"]]
+    assert [L.dl3_pwconv_route(d, 2 * 64 * 64, 256, 21) for d in (0, 3, 4)] == [R["narrow"], R["tiled"], R["tiled"]]
     for K, N in ((160, 960), (96, 576), (64, 384)):
         assert L.dl3_pwconv_route(0, M, K, N) == R["ws_mfma"] and L.dl3_pwconv_fwd_impl(M, K, N) == 2
         assert L.dl3_pwconv_route(1, M, N, K) == R["ws_mfma"]         # bwd-data of the project convolution N -> K
@@ -570,7 +574,7 @@ def test_default_kernel_routes_by_name(monkeypatch):
     # ... and through a lowered plan: the launches of the B=128 engine that take each route
     e, c = _dry_engine(monkeypatch, "mobilenetv2", 128)
     fwd = [L.dl3_pwconv_route(0, op[2][9], op[2][10], op[2][11]) for op in e.ops_fwd if op[0] == "dl3_pwconv_fwd"]
-    assert fwd.count(R["ws_mfma"]) == 10 and fwd.count(R["ws_hbm"]) == 12
+    assert fwd.count(R["ws_mfma"]) == 10 and fwd.count(R["ws_hbm"]) == 12 and fwd.count(R["narrow"]) == 1
     wg = [L.dl3_pwconv_route(2, op[2][14], op[2][15], op[2][16]) for op in e.ops_bwd if op[0] == "dl3_pwconv_bwd_weight_dy"]
     assert wg.count(R["wgrad_row"]) == 6
     # the statistic partial rows the engine sized cover the weight-stationary kernel's one row per row group

@@ -50,6 +50,24 @@ def run(kind, M, K, N):
         P = L.dl3_pwconv_partials(M, K, N)
         part = torch.empty(P, N, 2, device="cuda")
         fn = lambda i: capi.call("dl3_pwconv_fwd", ptr(xs[i]), K, ptr(s), ptr(t), 1, ptr(w), None, ptr(ys[i]), N, M, K, N, ptr(part), ST())
+    elif kind in ("lfwd", "lbwd", "lwgrad"):
+        # the logits layer (deeplabv3p.py:438): bias, no BatchNorm behind it, no mask in front of it
+        bias = rnd(N)
+        gs = [rnd(M, N) for _ in range(ns)]
+        if kind == "lfwd":
+            ys = [torch.empty(M, N, device="cuda") for _ in range(ns)]
+            fn = lambda i: capi.call("dl3_pwconv_fwd", ptr(xs[i]), K, None, None, 0, ptr(w), ptr(bias), ptr(ys[i]), N, M, K, N, None, ST())
+        elif kind == "lbwd":
+            wT = w.t().contiguous()
+            dxs = [torch.empty(M, K, device="cuda") for _ in range(ns)]
+            fn = lambda i: capi.call("dl3_pwconv_bwd_data", ptr(gs[i]), N, None, N, None, None, None, ptr(wT), ptr(dxs[i]), K, None, K,
+                                     None, None, 0, None, K, 1, 1.0, None, None, None, M, K, N, ST())
+        else:
+            nbytes = L.dl3_pwconv_bwd_weight_workspace(M, K, N)
+            ws = torch.empty(nbytes // 4 + 4, device="cuda")
+            dw, db = torch.empty(K, N, device="cuda"), torch.empty(N, device="cuda")
+            fn = lambda i: capi.call("dl3_pwconv_bwd_weight", ptr(xs[i]), K, None, None, 0, ptr(gs[i]), N, None, N, None, None, None,
+                                     ptr(dw), ptr(db), M, K, N, ptr(ws), nbytes, ST())
     else:
         gs = [rnd(M, N) for _ in range(ns)]
         two = kind in ("bwd2", "wgrad", "wgraddy")
