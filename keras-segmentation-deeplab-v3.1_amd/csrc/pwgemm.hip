@@ -39,6 +39,7 @@ struct GemmArgs {
   const float *ep_mean, *ep_invstd;
   float *part;
   int part_rows;  // rows the caller's partial buffer holds: the launch writes gridDim.y of them and zeroes the rest itself
+  int part_ld;    // columns per partial row (0: N) — a launch over a column slice of the output (run_gemm) writes into the whole matrix's rows
   int mtiles;
   const void *bp; int nsub;  // split math: weights pre-split into 3 bf16 planes in MFMA fragment order (pack_b_kernel)
 #ifdef DL3_PHASE_TIMING
@@ -326,13 +327,14 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(GemmArgs P) {
           a1 += sred[(w * BN + cl) * 2 + 0];
           a2 += sred[(w * BN + cl) * 2 + 1];
         }
-        P.part[((size_t)by * P.N + col) * 2 + 0] = a1;
-        P.part[((size_t)by * P.N + col) * 2 + 1] = a2;
+        const int pld = P.part_ld ? P.part_ld : P.N;
+        P.part[((size_t)by * pld + col) * 2 + 0] = a1;
+        P.part[((size_t)by * pld + col) * 2 + 1] = a2;
         // rows of the buffer no workgroup owns (it is sized for the largest grid any tile choice uses): zeroed here, by
         // the row groups in turn, instead of by a memset node behind every launch
         for (int r = by + (int)gridDim.y; r < P.part_rows; r += (int)gridDim.y) {
-          P.part[((size_t)r * P.N + col) * 2 + 0] = 0.f;
-          P.part[((size_t)r * P.N + col) * 2 + 1] = 0.f;
+          P.part[((size_t)r * pld + col) * 2 + 0] = 0.f;
+          P.part[((size_t)r * pld + col) * 2 + 1] = 0.f;
         }
       }
     }
@@ -933,13 +935,14 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_stream_kernel(GemmArgs P) {
           a1 += sred[(w * BN + cl) * 2 + 0];
           a2 += sred[(w * BN + cl) * 2 + 1];
         }
-        P.part[((size_t)by * P.N + col) * 2 + 0] = a1;
-        P.part[((size_t)by * P.N + col) * 2 + 1] = a2;
+        const int pld = P.part_ld ? P.part_ld : P.N;
+        P.part[((size_t)by * pld + col) * 2 + 0] = a1;
+        P.part[((size_t)by * pld + col) * 2 + 1] = a2;
         // rows of the buffer no workgroup owns (it is sized for the largest grid any tile choice uses): zeroed here, by
         // the row groups in turn, instead of by a memset node behind every launch
         for (int r = by + (int)gridDim.y; r < P.part_rows; r += (int)gridDim.y) {
-          P.part[((size_t)r * P.N + col) * 2 + 0] = 0.f;
-          P.part[((size_t)r * P.N + col) * 2 + 1] = 0.f;
+          P.part[((size_t)r * pld + col) * 2 + 0] = 0.f;
+          P.part[((size_t)r * pld + col) * 2 + 1] = 0.f;
         }
       }
     }
@@ -2769,7 +2772,7 @@ void launch_gemm(const GemmArgs &A, dim3 grid, hipStream_t st, int vec) {
 inline bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
 // returns the number of stat partial rows the launch writes (= grid.y)
-int run_gemm(GemmArgs A, hipStream_t st) {
+int run_gemm_one(GemmArgs A, hipStream_t st) {
   const bool two = A.a2 != nullptr;
   const bool avec = (A.K % 4 == 0) && (A.lda % 4 == 0) && al16(A.a) && (!two || ((A.lda2 % 4 == 0) && al16(A.a2)));
   const bool bvec = (A.N % 4 == 0) && (A.ldb % 4 == 0) && al16(A.b);
@@ -2920,6 +2923,46 @@ int run_gemm(GemmArgs A, hipStream_t st) {
   return (int)grid.y;
 }
 
+// round 6: Xception's 728-channel layers (deeplabv3p.py:300-306) are stored 736 wide — 23 column blocks of 32,
+// which no tile width divides: six 128-wide tiles compute 24 (the stream kernel multiplies zero weight columns like any other).
+// 23 = 2 x 4 + 3 x 5: such a launch is issued as TWO over disjoint column ranges of the same output, [0, N - 480) on the
+// 128-wide tiles and the last 480 columns on the 160-wide ones — 23 blocks exactly, both launches several full rounds of the
+// chip.  The operand rows are read by both (the second pass over a 65 536 x 736 operand is 0.19 GB against 0.65 ms of MFMA
+// time); partial sums land in disjoint columns of the same rows.  (First cut, 640 + 96 columns: the 128 x 96 tile of the
+// narrow launch costs 0.78 of a 128-wide one — forward 0.749 -> 0.712 ms, bwd-data 0.798 -> 0.796.)  DL3_COLSPLIT=0: one launch.
+constexpr int kColsplitTail = 480;
+bool colsplit_shape(int M, int K, int N) {
+  static const int env = env_int("DL3_COLSPLIT");
+  return env != 0 && M >= 32768 && K >= 256 && K <= DL3_STREAM_KMAX && N >= kColsplitTail + 128 && N % 128 == 96 && N % 160 != 0;
+}
+int run_gemm(GemmArgs A, hipStream_t st) {
+  const bool two = A.a2 != nullptr;
+  const bool vec = (A.K % 4 == 0) && (A.lda % 4 == 0) && al16(A.a) && (!two || ((A.lda2 % 4 == 0) && al16(A.a2))) &&
+                   (A.N % 4 == 0) && (A.ldb % 4 == 0) && al16(A.b);
+  // (single-tensor operand only: the two-tensor bwd-data form, which the engine does not use once the weight-gradient launch
+  // has written dY, came out 2 % slower in two launches — 0.834 -> 0.851 ms)
+  if (!vec || two || split_math() || !colsplit_shape(A.M, A.K, A.N)) return run_gemm_one(A, st);
+  const int n1 = A.N - kColsplitTail;
+  GemmArgs S[2] = {A, A};
+  S[0].N = n1;
+  S[1].N = kColsplitTail;
+  S[1].b += n1; S[1].c += n1;
+  if (A.bias) S[1].bias += n1;
+  if (A.ep_x) S[1].ep_x += n1;
+  if (A.ep_scale) { S[1].ep_scale += n1; S[1].ep_shift += n1; }
+  if (A.ep_mean) { S[1].ep_mean += n1; S[1].ep_invstd += n1; }
+  if (A.ep_add) S[1].ep_add += n1;
+  if (A.part) S[1].part += 2 * (size_t)n1;
+  int rows = 0;
+  for (GemmArgs &q : S) {
+    q.part_ld = A.N;
+    const int r = run_gemm_one(q, st);
+    if (r < 0) return r;
+    rows = r > rows ? r : rows;
+  }
+  return rows;
+}
+
 struct WgCfg { int id, BKT, BNT; };
 const WgCfg kWgCfgs[] = {{0, 64, 64},  {1, 128, 128}, {2, 160, 128}, {3, 128, 160}, {4, 64, 128},
                          {5, 128, 64}, {6, 32, 128},  {7, 128, 32},  {8, 96, 128},  {9, 128, 96}};
@@ -3040,6 +3083,11 @@ extern "C" int dl3_pwconv_partials(int M, int K, int N) {
   if (ksplit_tn(M, K, N)) {  // the K-split kernel of the small batches: one row per 32-row tile
     const int q = dl3_cdiv(M, 32);
     p = q > p ? q : p;
+  }
+  if (colsplit_shape(M, K, N)) {   // (two launches over column slices: each sizes its own grid)
+    const int a = dl3_pwconv_partials(M, K, N - kColsplitTail), b = dl3_pwconv_partials(M, K, kColsplitTail);
+    p = a > p ? a : p;
+    p = b > p ? b : p;
   }
   if (N % 96 == 0) {  // the prefetching bwd-data variant overrides the choice with the 128x96 tile (run_gemm)
     const int q = gemm_grid_y(M, N, kGemmCfgs[4], K);
@@ -3213,6 +3261,33 @@ extern "C" int dl3_pwconv_bwd_weight_splits(int M, int K, int N, int two_tensor_
   return wgrad_splits(M, K, N, pick_wgrad(M, K, N, two_tensor_dy != 0));
 }
 
+// one weight-gradient launch on tile configuration c (row: K fits one tile row of it — the straight-line kernel of the
+// expand convolutions, with the requests in front of the dY stores)
+static void launch_wgrad_cfg(const WgradArgs &A, const WgCfg &c, dim3 grid, hipStream_t st, int vec, bool row) {
+  if (row) {   // (c.id 2 or 8, 16-byte loads on both operands: wgrad_row_ok)
+    if (c.id == 2) {
+      if (A.dyout) hipLaunchKernelGGL((pw_wgrad_row_kernel<5, 1, 1, 4, true>), grid, dim3(256), 0, st, A);
+      else hipLaunchKernelGGL((pw_wgrad_row_kernel<5, 1, 1, 4, false>), grid, dim3(256), 0, st, A);
+    } else {
+      if (A.dyout) hipLaunchKernelGGL((pw_wgrad_row_kernel<3, 1, 1, 4, true>), grid, dim3(256), 0, st, A);
+      else hipLaunchKernelGGL((pw_wgrad_row_kernel<3, 1, 1, 4, false>), grid, dim3(256), 0, st, A);
+    }
+    return;
+  }
+  switch (c.id) {
+    case 0: launch_wgrad<1, 1, 2, 2>(A, grid, st, vec); break;
+    case 1: launch_wgrad<2, 2, 2, 2>(A, grid, st, vec); break;
+    case 2: launch_wgrad<5, 1, 1, 4>(A, grid, st, vec); break;
+    case 3: launch_wgrad<1, 5, 4, 1>(A, grid, st, vec); break;
+    case 4: launch_wgrad<2, 1, 1, 4>(A, grid, st, vec); break;
+    case 5: launch_wgrad<1, 2, 4, 1>(A, grid, st, vec); break;
+    case 6: launch_wgrad<1, 1, 1, 4>(A, grid, st, vec); break;
+    case 7: launch_wgrad<1, 1, 4, 1>(A, grid, st, vec); break;
+    case 8: launch_wgrad<3, 1, 1, 4>(A, grid, st, vec); break;
+    default: launch_wgrad<1, 3, 4, 1>(A, grid, st, vec); break;
+  }
+}
+
 static int pwconv_bwd_weight_impl(const float *x, int ldx, const float *in_scale, const float *in_shift,
                                      int in_act, const float *g, int ldg, const float *yraw, int ldyraw,
                                      const float *cA, const float *cB, const float *cC, float *dw, float *dbias,
@@ -3258,31 +3333,7 @@ static int pwconv_bwd_weight_impl(const float *x, int ldx, const float *in_scale
     if (rc || !dbias) return rc;
     return dl3_reduce_partials(cpart, Sn, N, dbias, stream);
   }
-  // one tile row covers the whole K (expand convolutions): the straight-line kernel with the requests in front of the stores
-  if (xvec && dvec && wgrad_row_ok(c, M, K, N)) {   // (c: the configuration THIS launch's grid was sized for)
-    if (c.id == 2) {
-      if (dy_out) hipLaunchKernelGGL((pw_wgrad_row_kernel<5, 1, 1, 4, true>), grid, dim3(256), 0, st, A);
-      else hipLaunchKernelGGL((pw_wgrad_row_kernel<5, 1, 1, 4, false>), grid, dim3(256), 0, st, A);
-    } else {
-      if (dy_out) hipLaunchKernelGGL((pw_wgrad_row_kernel<3, 1, 1, 4, true>), grid, dim3(256), 0, st, A);
-      else hipLaunchKernelGGL((pw_wgrad_row_kernel<3, 1, 1, 4, false>), grid, dim3(256), 0, st, A);
-    }
-    DL3_LAUNCH_CHECK("pwconv_bwd_weight");
-    if (!dw) return DL3_OK;
-    return dl3_reduce_partials(A.ws, S, K * N, dw, stream);
-  }
-  switch (c.id) {
-    case 0: launch_wgrad<1, 1, 2, 2>(A, grid, st, (xvec && dvec) ? 1 : (xvec ? 2 : 0)); break;
-    case 1: launch_wgrad<2, 2, 2, 2>(A, grid, st, (xvec && dvec) ? 1 : (xvec ? 2 : 0)); break;
-    case 2: launch_wgrad<5, 1, 1, 4>(A, grid, st, (xvec && dvec) ? 1 : (xvec ? 2 : 0)); break;
-    case 3: launch_wgrad<1, 5, 4, 1>(A, grid, st, (xvec && dvec) ? 1 : (xvec ? 2 : 0)); break;
-    case 4: launch_wgrad<2, 1, 1, 4>(A, grid, st, (xvec && dvec) ? 1 : (xvec ? 2 : 0)); break;
-    case 5: launch_wgrad<1, 2, 4, 1>(A, grid, st, (xvec && dvec) ? 1 : (xvec ? 2 : 0)); break;
-    case 6: launch_wgrad<1, 1, 1, 4>(A, grid, st, (xvec && dvec) ? 1 : (xvec ? 2 : 0)); break;
-    case 7: launch_wgrad<1, 1, 4, 1>(A, grid, st, (xvec && dvec) ? 1 : (xvec ? 2 : 0)); break;
-    case 8: launch_wgrad<3, 1, 1, 4>(A, grid, st, (xvec && dvec) ? 1 : (xvec ? 2 : 0)); break;
-    default: launch_wgrad<1, 3, 4, 1>(A, grid, st, (xvec && dvec) ? 1 : (xvec ? 2 : 0)); break;
-  }
+  launch_wgrad_cfg(A, c, grid, st, (xvec && dvec) ? 1 : (xvec ? 2 : 0), xvec && dvec && wgrad_row_ok(c, M, K, N));
   DL3_LAUNCH_CHECK("pwconv_bwd_weight");
   if (!dw) return DL3_OK;  // the caller folds the [S][K][N] slabs itself (dl3_reduce_partials / _batched)
   rc = dl3_reduce_partials(A.ws, S, K * N, dw, stream);

@@ -630,6 +630,21 @@ def test_pwconv_long_reduction_few_row_tiles(L, M, K, N):
         test_pwconv_bwd_data(L, (M, N, K, 1, True, 0, True))    # (the GEMM's output width is the layer's K)
 
 
+@pytest.mark.parametrize("M,K,N", [(32768 + 64, 256, 608), (40000, 736, 736), (32768, 512, 864)])
+def test_pwconv_column_split_23_blocks(L, M, K, N):
+    """round 6 (run_gemm, colsplit_shape): an output width of q x 128 + 96 columns (Xception's 728 channels stored 736 wide =
+    23 blocks of 32 = 2 x 4 + 3 x 5) is issued as two launches over disjoint column ranges — [0, N - 480) on the 128-wide
+    tiles, the last 480 columns on the 160-wide ones — that share the operand rows and the partial-sum rows: forward with bias,
+    BatchNorm sums and an output that is a channel slice; bwd-data with two-tensor / single-tensor operand, mask, residual
+    gradient (per row / per image) and sums"""
+    assert L.dl3_pwconv_partials(M, K, N) >= max(L.dl3_pwconv_partials(M, K, N - 480), L.dl3_pwconv_partials(M, K, 480))
+    test_pwconv_fwd(L, (M, K, N, 0, 0, True, 1))
+    test_pwconv_fwd(L, (M, K, N, 0, 32, False, None))
+    test_pwconv_bwd_data(L, (M, N, K, 1, True, 1, True))     # (the GEMM's output width is the layer's K)
+    test_pwconv_bwd_data(L, (M, N, K, 2, False, 0, True))
+    test_pwconv_bwd_data(L, (M, N, K, None, False, 2, False))
+
+
 FUSED_CASES = [
     # M, K, N, act, two-tensor dY, residual addend, stats (0 none, 1 on the forward input, 2 on another tensor)
     (4096 + 17, 16, 96, None, True, True, 1),    # block 1 expand: K below one 32-block, 3 column blocks, ragged rows

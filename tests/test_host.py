@@ -543,7 +543,7 @@ def test_knob_table_is_current():
     res = subprocess.run([sys.executable, os.path.join(root, "tools", "knobs.py"), "--check"], capture_output=True, text=True)
     assert res.returncode == 0, "KNOBS.md is stale or a knob lacks a description: run python tools/knobs.py\n" + res.stdout
     text = open(os.path.join(root, "KNOBS.md")).read()
-    assert text.count("| `DL3_") == 24
+    assert text.count("| `DL3_") == 25
 
 
 def test_default_kernel_routes_by_name(monkeypatch):

@@ -39,6 +39,7 @@ KNOBS = {
     "DL3_GEMM_PY": ("512 / 2048 / 4096 by shape", "A/B", "target number of workgroups of a 1x1 GEMM launch (round 6: profiles/r06_ab_calls.txt call 6)"),
     "DL3_WS2": ("1", "A/B", "0: no weight-stationary kernel for the MFMA-bound short reductions (round 6, calls 12 / 14)"),
     "DL3_NARROW": ("1", "A/B", "0: the logits layer (N = classes off a 256-wide input) on the tiled kernels (round 6, call 24: forward / bwd-data / weight gradient 0.166 / 0.222 / 0.339 -> 0.124 / 0.112 / 0.139 ms at 524 288 rows)"),
+    "DL3_COLSPLIT": ("1", "A/B", "0: a 736-wide output (Xception's 728 channels, 23 column blocks) in one launch of six 128-wide tiles instead of 256 + 480 columns in two (round 6, calls 26 / 27: cfg4 87.3 -> 88.6 img/s)"),
     "DL3_WGRAD_ROW": ("1", "A/B", "0: the expand convolutions' weight gradient on the tiled kernel (round 6, call 18)"),
 }
 
