@@ -213,7 +213,7 @@ def roofline_blocks(rows, args):
             "bound": "mfma", "kernel": "Conv2D 1x1 GEMM family on v_mfma_f32_32x32x2_f32: pw_gemm_stream_kernel (forward, "
             "bwd-data) + pw_ws2_kernel (short reductions, weight slice resident in LDS) + pw_fwd_ws_kernel (forward of the "
             "HBM-bound early layers) + pw_wgrad_kernel / pw_wgrad_row_kernel (bwd-weight) + pw_bwd_fused2_kernel (both "
-            "gradients of the HBM-bound early layers in one pass), "
+            "gradients of the HBM-bound early layers in one pass) + the logits layer's pw_narrowk_kernel / pw_wgrad_narrow_kernel, "
             "%d launches/step" % g["launches"],
             "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TFLOPS,
             "traffic": _pmc_traffic("gemm", args)[0], "traffic_source": _pmc_traffic("gemm", args)[1],

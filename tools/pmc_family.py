@@ -45,7 +45,7 @@ def gemm_family(fetch_dir, write_dir, plan):
             for r in csv.DictReader(open(f)):
                 k = r["Kernel_Name"]
                 steps += "adam_kernel" in k
-                if any(t in k for t in ("pw_gemm", "pw_ksplit32", "pw_wgrad", "pw_bwd_fused", "pw_fwd_ws", "pw_ws2", "pw_rows_f64")):
+                if any(t in k for t in ("pw_gemm", "pw_ksplit32", "pw_wgrad", "pw_bwd_fused", "pw_fwd_ws", "pw_ws2", "pw_narrowk", "pw_rows_f64")):
                     tot += float(r["Counter_Value"])
         return tot / max(steps, 1), steps
     f, fs = load(fetch_dir)

@@ -37,7 +37,7 @@ def fam(t):
     rows = list(csv.DictReader(open(S + t + "_kernel_stats.csv")))
     steps = [int(x["Calls"]) for x in rows if "adam_kernel" in x["Name"]][0]
     tot = sum(float(x["TotalDurationNs"]) for x in rows)
-    g = sum(float(x["TotalDurationNs"]) for x in rows if any(t in x["Name"] for t in ("pw_gemm", "pw_ksplit32", "pw_fwd_ws", "pw_ws2", "pw_rows_f64", "pw_wgrad", "pw_bwd_fused")))
+    g = sum(float(x["TotalDurationNs"]) for x in rows if any(t in x["Name"] for t in ("pw_gemm", "pw_ksplit32", "pw_fwd_ws", "pw_ws2", "pw_narrowk", "pw_rows_f64", "pw_wgrad", "pw_bwd_fused")))
     d = sum(float(x["TotalDurationNs"]) for x in rows if "dw_march" in x["Name"])
     return steps, tot, g, d
 
