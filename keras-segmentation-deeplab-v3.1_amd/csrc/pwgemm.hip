@@ -1796,6 +1796,7 @@ template <int KQ, int TN, int NW, bool BWD = false, bool TWO = false, bool ADD =
 __global__ __launch_bounds__(64 * NW) void pw_ws2_kernel(GemmArgs P) {
   static_assert(BWD || (!TWO && !ADD), "two-tensor operand / residual addend: bwd-data only");
   static_assert(!FLAT || (!BWD && TN == 1), "packed narrow output: forward, one column block");
+  constexpr bool XPRE = BWD && !TWO && TN <= 4;   // the epilogue's forward-input pieces requested two column blocks ahead (below)
   constexpr int KH = 4 * KQ, K = 8 * KQ, NP = 32 * TN;
   __shared__ __attribute__((aligned(16))) float Ws[K * NP];   // W[k][n0 + n], zero beyond N
   __shared__ __attribute__((aligned(16))) float cf[(TWO ? 3 : 2) * K];    // scale | shift of the input transform (TWO: cA | cC | cB)
@@ -1932,6 +1933,27 @@ __global__ __launch_bounds__(64 * NW) void pw_ws2_kernel(GemmArgs P) {
     for (int j = 0; j < TN; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+    // BWD, XPRE: the forward-input (and addend) pieces of the first TWO column blocks are requested in front of the tile's MFMAs
+    // (they retire before the operand ring's requests: in-order vmcnt) and block j + 2's as soon as block j has used its slot —
+    // the epilogue runs two blocks ahead of its HBM round trip instead of one, which a block's own ~1 us of work did not cover
+    // (same-call A/B, 524 288 rows: 576 <- 96 0.737 -> 0.703 ms, 384 <- 96 0.495 -> 0.471, 384 <- 64 0.392 -> 0.383).  Not at
+    // TN = 5 and not for the two-tensor operand: 32 more live registers across the MFMA loop spill there (144 -> 236 B of scratch,
+    // 960 <- 160 1.93 -> 1.99 ms; 64 <- 384 0.505 -> 0.516)
+    f32x4 xq[BWD ? 2 : 1][BWD ? 4 : 1], aq[BWD ? 2 : 1][ADD ? 4 : 1];
+    if constexpr (XPRE) {
+      const float *const xp0 = P.ep_x + (size_t)(t * 32 + r0) * P.ld_epx + n0;
+      const float *const ap0 = ADD ? P.ep_add + (size_t)(t * 32 + r0) * P.ld_add + n0 : nullptr;
+#pragma unroll
+      for (int jj = 0; jj < (TN < 2 ? TN : 2); jj++) {
+        // (a block beyond the tile's last one: block jl's columns again — a valid address, never used)
+        const int cc_ = jj < jl ? jj * 32 + c4 : jl * 32 + c4l;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+          xq[jj][p] = ld4(xp0 + (size_t)(8 * p) * P.ld_epx + cc_);
+          if constexpr (ADD) aq[jj][p] = ld4(ap0 + (size_t)(8 * p) * P.ld_add + cc_);
+        }
+      }
+    }
     mfma_tile(acc, t, t + GW < nfull ? t + GW : t);
     DL3_T(const long long e0 = clock64(); ntl++;)
 #ifdef DL3_WS2_DIRECT_EPILOGUE   // (measured: 160 -> 960 at 524 288 rows 1.51 -> 1.59 ms; kept for the record)
@@ -1959,16 +1981,17 @@ __global__ __launch_bounds__(64 * NW) void pw_ws2_kernel(GemmArgs P) {
       float *const cp = P.c + (size_t)(t * 32 + r0) * P.ldc + n0;
       const float *const xp = P.ep_x + (size_t)(t * 32 + r0) * P.ld_epx + n0;
       const float *const ap = ADD ? P.ep_add + (size_t)(t * 32 + r0) * P.ld_add + n0 : nullptr;
-      f32x4 xq[2][4], aq[2][ADD ? 4 : 1];
+      if constexpr (!XPRE) {
 #pragma unroll
-      for (int p = 0; p < 4; p++) {
-        xq[0][p] = ld4(xp + (size_t)(8 * p) * P.ld_epx + (0 == jl ? c4l : c4));
-        if constexpr (ADD) aq[0][p] = ld4(ap + (size_t)(8 * p) * P.ld_add + (0 == jl ? c4l : c4));
+        for (int p = 0; p < 4; p++) {
+          xq[0][p] = ld4(xp + (size_t)(8 * p) * P.ld_epx + (0 == jl ? c4l : c4));
+          if constexpr (ADD) aq[0][p] = ld4(ap + (size_t)(8 * p) * P.ld_add + (0 == jl ? c4l : c4));
+        }
       }
 #pragma unroll
       for (int j = 0; j < TN; j++) {
         if (j <= jl) {
-          if (j + 1 <= jl) {
+          if (!XPRE && j + 1 <= jl) {
 #pragma unroll
             for (int p = 0; p < 4; p++) {
               xq[(j + 1) & 1][p] = ld4(xp + (size_t)(8 * p) * P.ld_epx + (j + 1) * 32 + (j + 1 == jl ? c4l : c4));
@@ -1991,6 +2014,14 @@ __global__ __launch_bounds__(64 * NW) void pw_ws2_kernel(GemmArgs P) {
             st4_nt(cp + (size_t)(8 * p) * P.ldc + j * 32 + cc, o);
             q1[j] += own * o;
             q2[j] += own * (o * ((x - mu) * is));
+          }
+          if (XPRE && j + 2 <= jl) {   // (slot j & 1 is free again: block j + 2)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+              xq[j & 1][p] = ld4(xp + (size_t)(8 * p) * P.ld_epx + (j + 2) * 32 + (j + 2 == jl ? c4l : c4));
+              if constexpr (ADD) aq[j & 1][p] = ld4(ap + (size_t)(8 * p) * P.ld_add + (j + 2) * 32 + (j + 2 == jl ? c4l : c4));
+            }
           }
           __builtin_amdgcn_wave_barrier();
         }
