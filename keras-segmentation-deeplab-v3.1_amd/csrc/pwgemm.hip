@@ -1792,11 +1792,14 @@ __global__ __launch_bounds__(256, OC) void pw_fwd_ws_kernel(GemmArgs P) {
 // back to back (ldc == N, N any number): a 32-row tile of the output is ONE contiguous run of 128 N bytes, which starts on a
 // 16-byte boundary whatever N is.  The block goes through the wave's LDS square packed N floats per row and leaves as 8 N
 // 16-byte pieces — the tiled kernel's scalar stores into 84-byte rows were what held this HBM-bound launch at 0.40 of peak.
+#ifndef DL3_WS2_XPRE_TN
+#define DL3_WS2_XPRE_TN 4
+#endif
 template <int KQ, int TN, int NW, bool BWD = false, bool TWO = false, bool ADD = false, bool FLAT = false>
 __global__ __launch_bounds__(64 * NW) void pw_ws2_kernel(GemmArgs P) {
   static_assert(BWD || (!TWO && !ADD), "two-tensor operand / residual addend: bwd-data only");
   static_assert(!FLAT || (!BWD && TN == 1), "packed narrow output: forward, one column block");
-  constexpr bool XPRE = BWD && !TWO && TN <= 4;   // the epilogue's forward-input pieces requested two column blocks ahead (below)
+  constexpr bool XPRE = BWD && !TWO && TN <= DL3_WS2_XPRE_TN;   // the epilogue's forward-input pieces requested two column blocks ahead (below)
   constexpr int KH = 4 * KQ, K = 8 * KQ, NP = 32 * TN;
   __shared__ __attribute__((aligned(16))) float Ws[K * NP];   // W[k][n0 + n], zero beyond N
   __shared__ __attribute__((aligned(16))) float cf[(TWO ? 3 : 2) * K];    // scale | shift of the input transform (TWO: cA | cC | cB)
@@ -1941,6 +1944,9 @@ __global__ __launch_bounds__(64 * NW) void pw_ws2_kernel(GemmArgs P) {
     // 960 <- 160 1.93 -> 1.99 ms; 64 <- 384 0.505 -> 0.516)
     f32x4 xq[BWD ? 2 : 1][BWD ? 4 : 1], aq[BWD ? 2 : 1][ADD ? 4 : 1];
     if constexpr (XPRE) {
+      int le = lane, c4le = c4l;   // (laundered like the epilogue's: see there)
+      asm volatile("" : "+v"(le), "+v"(c4le));
+      const int c4 = (le & 7) * 4, r0 = le >> 3, c4l = c4le;
       const float *const xp0 = P.ep_x + (size_t)(t * 32 + r0) * P.ld_epx + n0;
       const float *const ap0 = ADD ? P.ep_add + (size_t)(t * 32 + r0) * P.ld_add + n0 : nullptr;
 #pragma unroll
@@ -1978,6 +1984,12 @@ __global__ __launch_bounds__(64 * NW) void pw_ws2_kernel(GemmArgs P) {
     }
 #else
     if constexpr (BWD) {
+      // The epilogue's lane-derived addresses depend only on the lane: left alone, the scheduler computes them once in front of
+      // the tile loop and — at TN = 5, 256 registers — parks 25 of them in scratch, reloaded here tile after tile.  Laundering
+      // the lane id through an empty asm behind the last MFMA makes them a handful of VALU instructions per tile instead.
+      int le = lane, c4le = c4l;
+      asm volatile("" : "+v"(le), "+v"(c4le));
+      const int c4 = (le & 7) * 4, r0 = le >> 3, l31 = le & 31, lhi = le >> 5, c4l = c4le;
       float *const cp = P.c + (size_t)(t * 32 + r0) * P.ldc + n0;
       const float *const xp = P.ep_x + (size_t)(t * 32 + r0) * P.ld_epx + n0;
       const float *const ap = ADD ? P.ep_add + (size_t)(t * 32 + r0) * P.ld_add + n0 : nullptr;
