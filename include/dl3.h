@@ -104,7 +104,7 @@ int dl3_pwconv_partials(int M, int K, int N);
  * no addend): 0 the tiled MFMA GEMM, 1 the weight-stationary streaming kernel of the HBM-bound layers (round 5: the
  * whole K x N matrix in LDS, every wave walks 32-row tiles on its own, 16-byte stores; deeplabv3p.py:175-198 at
  * 16..192 channels, M >= 32768), 2 the weight-stationary kernel of the MFMA-bound short reductions (round 6: K = 160 / 96 /
- * 64 into an output at least twice as wide, M >= 131072; DL3_WS2=0 disables it — and its packed-output variant for the
+ * 64 into an output at least twice as wide, M >= 98304 forward / 65536 bwd-data, 131072 for K = 64; DL3_WS2=0 disables it — and its packed-output variant for the
  * logits layer, K = 256, N <= 32, ldy == N, M >= 8192; DL3_NARROW=0).  Diagnostic only. */
 int dl3_pwconv_fwd_impl(int M, int K, int N);
 /* ... and the route of a launch by name, for plans that want to assert what they benchmark (tests/test_host.py):

@@ -2626,12 +2626,15 @@ int ws2_groups(int M, int ntn) {
   return g < cap ? g : cap;
 }
 // shapes it takes: a reduction of 160, 96 or 64 (MobileNetV2's 64 x 64 blocks, deeplabv3p.py:175-198) into an output at least twice
-// as wide, from 131 072 rows (B >= 32: below, a wave walks too few tiles to pay for loading its 60-100 KB weight slice;
-// 65 536 rows: 0.195 -> 0.22 ms).  DL3_WS2=0: the tiled stream kernel serves everything (read once).
-bool ws2_shape(int M, int K, int N) {
+// as wide, from a row count below which a wave walks too few tiles to pay for loading its 60-100 KB weight slice — measured per
+// direction (profiles/r06_ab_calls.txt calls 34 / 35, tiled -> weight-stationary): forward 160 -> 960 at 65 536 rows 0.218 -> 0.228 ms,
+// at 98 304 0.339 -> 0.312; bwd-data 960 <- 160 at 32 768 rows 0.151 -> 0.158, at 65 536 0.295 -> 0.261 (the tiled kernel's masked
+// epilogue is the longer one); reduction 64: 131 072 rows either way.  DL3_WS2=0: the tiled stream kernel serves everything.
+bool ws2_shape(int M, int K, int N, bool bwd = false) {
   static const int env = env_int("DL3_WS2");
   if (env == 0) return false;
-  return M >= 131072 && N % 4 == 0 && ((K == 160 && N >= 320) || (K == 96 && N >= 192) || (K == 64 && N >= 128));
+  const int minrows = K == 64 ? 131072 : (bwd ? 65536 : 98304);
+  return M >= minrows && N % 4 == 0 && ((K == 160 && N >= 320) || (K == 96 && N >= 192) || (K == 64 && N >= 128));
 }
 inline int ws2_tn(int K) { return K == 160 ? 5 : (K == 96 ? 3 : 4); }
 // 1: forward, 2: bwd-data (single-tensor dY, mask and BatchNorm-backward sums from the forward input, no addend), 3: bwd-data
@@ -2645,7 +2648,7 @@ int ws2_wanted(const GemmArgs &A, bool fwd, bool vec) {
     if (A.ep_add && (A.add_div != 1 || A.ld_add % 4 != 0 || (((uintptr_t)A.ep_add) & 15) != 0)) return 0;
     return 3;
   }
-  if (A.ep_add || A.a2 || !ws2_shape(A.M, A.K, A.N)) return 0;
+  if (A.ep_add || A.a2 || !ws2_shape(A.M, A.K, A.N, !fwd)) return 0;
   if (fwd) return 1;
   if (A.ka || !A.ep_x || A.ld_epx % 4 != 0 || (((uintptr_t)A.ep_x) & 15) != 0 || A.stat_mode == 1) return 0;
   return 2;
@@ -3111,7 +3114,7 @@ extern "C" int dl3_pwconv_partials(int M, int K, int N) {
     const int q = ws_grid(M);
     p = q > p ? q : p;
   }
-  if (ws2_shape(M, K, N)) {
+  if (ws2_shape(M, K, N, true)) {   // (the lower of the two directions' row thresholds)
     const int q = ws2_groups(M, dl3_cdiv(N, 32 * ws2_tn(K)));
     p = q > p ? q : p;
   }

@@ -547,12 +547,13 @@ def test_pwconv_bwd_weight_one_tile_row(L, case):
 
 @pytest.mark.parametrize("case", [(266000 + 17, 160, 960, 0, 0, False, 2), (140000, 96, 576, 0, 0, True, 1),
                                   (133000, 160, 320, 0, 64, False, None), (131072 + 5, 160, 1000, 0, 0, False, 2),
-                                  (131072 + 33, 64, 384, 64, 0, False, 2), (140000, 64, 200, 0, 0, False, None)])
+                                  (131072 + 33, 64, 384, 64, 0, False, 2), (140000, 64, 200, 0, 0, False, None),
+                                  (98304 + 7, 160, 960, 0, 0, False, 2), (100000, 96, 576, 0, 0, True, 1)])
 def test_pwconv_fwd_weight_stationary_short_reductions(L, case):
     """round 6 (pw_ws2_kernel, forward): a reduction of 160 / 96 into an output at least twice as wide from 131 072 rows — the
     whole weight slice of a column tile resident in LDS, eight waves walking 32-row tiles without a barrier: ragged last row
     tile, a last column tile with 8 of its 160 columns (N = 1 000), bias, an output that is a channel slice"""
-    assert L.dl3_pwconv_partials(case[0], case[1], case[2]) >= 1
+    assert L.dl3_pwconv_partials(case[0], case[1], case[2]) >= 1 and L.dl3_pwconv_route(0, case[0], case[1], case[2]) == 2
     test_pwconv_fwd(L, case)
 
 
@@ -560,6 +561,7 @@ def test_pwconv_fwd_weight_stationary_short_reductions(L, case):
                                   (140000, 1000, 160, 1, False, 0, True), (133000, 384, 96, None, False, 0, True),
                                   (131072 + 7, 320, 160, 2, False, 0, False), (131072 + 40, 384, 64, None, False, 0, True),
                                   (150000, 200, 64, 2, False, 0, True),
+                                  (65536 + 40, 960, 160, 2, False, 0, True), (70000, 576, 96, 2, False, 0, True),   # B=16's row count
                                   # the expand convolutions 64 -> 384: two-tensor operand over a reduction of 384, residual gradient
                                   (131072 + 50, 64, 384, None, True, 1, True), (140000, 64, 384, None, True, 0, True),
                                   (131072, 64, 384, 1, True, 1, False)])

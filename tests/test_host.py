@@ -563,7 +563,10 @@ def test_default_kernel_routes_by_name(monkeypatch):
     for K, N in ((160, 960), (96, 576), (64, 384)):
         assert L.dl3_pwconv_route(0, M, K, N) == R["ws_mfma"] and L.dl3_pwconv_fwd_impl(M, K, N) == 2
         assert L.dl3_pwconv_route(1, M, N, K) == R["ws_mfma"]         # bwd-data of the project convolution N -> K
-        assert L.dl3_pwconv_route(0, 16 * 64 * 64, K, N) == R["tiled"]  # B=16: 65 536 rows
+        assert L.dl3_pwconv_route(0, 16 * 64 * 64, K, N) == R["tiled"]  # B=16: 65 536 rows — forward tiled, ...
+        assert L.dl3_pwconv_route(1, 16 * 64 * 64, N, K) == (R["ws_mfma"] if K != 64 else R["tiled"])   # ... bwd-data from 65 536
+        assert L.dl3_pwconv_route(0, 24 * 64 * 64, K, N) == (R["ws_mfma"] if K != 64 else R["tiled"])   # forward from 98 304
+        assert L.dl3_pwconv_route(1, 8 * 64 * 64, N, K) == R["tiled"]
     for K, N in ((960, 160), (576, 96), (384, 64), (960, 320), (320, 256), (256, 256)):
         assert L.dl3_pwconv_route(0, M, K, N) == R["tiled"] and L.dl3_pwconv_route(1, M, N, K) == R["tiled"]
     assert L.dl3_pwconv_route(0, 128 * 256 * 256, 16, 96) == R["ws_hbm"] and L.dl3_pwconv_route(0, 128 * 128 * 128, 24, 144) == R["ws_hbm"]
