@@ -606,9 +606,9 @@ def test_pwconv_bwd_weight_logits_narrow_output(L, case):
     test_pwconv_bwd_weight(L, case)
 
 
-def test_logits_layer_narrow_kernels_off_is_the_tiled_path(L, monkeypatch):
-    """DL3_NARROW is read once per process: the A/B switch is exercised in a child (tools/ab.sh style), here only that the
-    default process reports the narrow routes for the benchmarked logits shape"""
+def test_logits_layer_routes_at_the_benchmarked_shape(L):
+    """the three launches of the logits layer take their narrow kernels at the benchmarked row count (DL3_NARROW, read once per
+    process, is the A/B switch: profiles/r06_ab_calls.txt calls 24 / 25), and the forward's partial rows are sized for it"""
     M = 128 * 128 * 128
     assert [L.dl3_pwconv_route(d, M, 256, 21) for d in (0, 3, 4)] == [5, 5, 5]
     assert L.dl3_pwconv_partials(M, 256, 21) >= 256
